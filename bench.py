@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Benchmark of the exact-inference hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic requests: `--batch` exact posterior
+queries (1 query node + 4 evidence nodes, the BASELINE C3 stream from default_rng(1)) on the
+synthetic 10x10 grid BN with 4 states per node (Dirichlet(1) CPTs from default_rng(0)).  Inputs
+(the flattened network) are resident in HBM before the timed region; the timed region covers
+planning, program upload, the VE kernel, result download and - for N > 1 - the RCCL all-gather of
+the posteriors.  Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), requests
+are independent so every rank processes its own contiguous shard of the stream (weak scaling, no
+data-path collective besides the final gather).
+
+Rank 0 prints ONE JSON line with the driver's contract fields plus `roofline` (dominant kernel:
+algorithmic bytes per launch / HIP-event duration, vs the 8 TB/s HBM peak) and `cpu_baseline` (the C
+oracle = port of the reference's sparse VE, timed on a bounded sample of the same stream).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(spec, qv, ev, ec, gpu_post, budget_s):
+    """Time the C oracle (oracle/ve_oracle.c, kind="port": sparse-table VE restating
+    bayes_net.py:739-794 with ascending-id elimination, the order the hash-ordered reference uses) on
+    the first requests of the stream until `budget_s` seconds are spent; also returns the max-abs
+    marginal error of the GPU posteriors on that sample."""
+    from oracle.oracle import OracleNet
+
+    on = OracleNet(spec)
+    oid = np.array([on.id[f"{i:03d}"] for i in range(len(on.names))], np.int32)  # grid id -> oracle id
+    prio = np.empty(len(on.names), np.int32)  # eliminate in ascending *name* order (row-major), like
+    prio[oid] = np.arange(len(on.names), dtype=np.int32)  # the hash-ordered reference (oracle/refload.py)
+    t0 = time.perf_counter()
+    n, err = 0, 0.0
+    while n < len(qv) and time.perf_counter() - t0 < budget_s:
+        codes, vals = on.query_codes([int(oid[qv[n]])], oid[ev[n]].tolist(), ec[n].tolist(), order=prio)
+        dense = np.zeros(int(on.card[int(oid[qv[n]])]))
+        dense[codes[:, 0]] = vals
+        err = max(err, float(np.max(np.abs(dense - gpu_post[n]))))
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} requests of the C3 stream (rng seed 1), {dt:.1f} s, "
+                      "oracle/ve_oracle.c single thread, row-major (ascending name) elimination order"}, err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16384, help="requests per step per GPU")
+    ap.add_argument("--n-evidence", type=int, default=4)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        a.gpus = world
+
+    import torch  # plumbing only: barrier / synchronize / RCCL gather
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import netspec
+    import sorobn_amd
+
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, sorobn_amd.BayesNet).use_device(local_rank)
+    be = bn.backend  # flatten + upload: network resident in HBM from here on
+    eng = be.engine
+
+    total_steps = a.warmup + a.steps
+    n_req = total_steps * world * a.batch
+    qv, ev, ec = netspec.c3_requests(100, 4, n_req, a.n_evidence, seed=1)
+    # names "000".."099" sort like the ids, but variable ids follow bn.nodes: map stream ids -> var ids
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+
+    def shard(step):
+        lo = (step * world + rank) * a.batch
+        return to_var[qv[lo:lo + a.batch]], to_var[ev[lo:lo + a.batch]], ec[lo:lo + a.batch], lo
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = None
+    if world > 1:
+        gathered = torch.empty((world, a.batch, 4), dtype=torch.float64, device="cuda")
+
+    def run_step(step):
+        q, e, c, lo = shard(step)
+        post = eng.query_fixed(q[:, None], e, c)
+        if world > 1:  # final gather of the posteriors over xGMI (RCCL)
+            mine = torch.from_numpy(post).to("cuda", non_blocking=False)
+            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
+        return post, eng.stats()
+
+    for s in range(a.warmup):
+        run_step(s)
+    barrier()
+    t0 = time.perf_counter()
+    agg = {}
+    first_post = None
+    for s in range(a.warmup, total_steps):
+        post, st = run_step(s)
+        if first_post is None:
+            first_post, first_lo = post, shard(s)[3]
+        for k, v in st.items():
+            agg[k] = agg.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_queries = a.steps * world * a.batch
+        launches = max(1.0, agg["n_launches"])
+        bytes_per_launch = agg["alg_bytes"] / launches
+        ms_per_launch = agg["kernel_ms"] / launches
+        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9
+        out = {
+            "metric": "exact posterior queries/sec on 100-node 4-state grid BN",
+            "value": n_queries / dt,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C3: 10x10 grid BN, 4 states/node, Dirichlet(1) CPTs rng(0); requests = "
+                                   f"1 query + {a.n_evidence} evidence nodes, rng(1) stream",
+                       "requests_per_step_per_gpu": a.batch, "parallelism": f"dp{world} (independent shards)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ve_kernel", "alg_bytes_per_launch": bytes_per_launch,
+                         "ms_per_launch": ms_per_launch,
+                         "alg_bytes_per_query": agg["alg_bytes"] / (a.steps * a.batch)},
+            "breakdown_ms_per_step": {k: agg[k] / a.steps for k in ("plan_ms", "h2d_ms", "kernel_ms", "d2h_ms", "total_ms")},
+        }
+        if world == 1 and not a.no_cpu:
+            lo = first_lo
+            cb, err = cpu_baseline(spec, qv[lo:lo + a.batch], ev[lo:lo + a.batch], ec[lo:lo + a.batch],
+                                   first_post, a.cpu_seconds)
+            out["cpu_baseline"] = cb
+            out["max_abs_marginal_err_vs_oracle"] = err
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/*
+ * mibn - MI355X-native exact inference backend for sorobn-style Bayesian networks.
+ *
+ * C-ABI drop-in boundary for the hot path of MaxHalford/sorobn:
+ *
+ *   BayesNet.query(..., algorithm="exact")   sorobn/bayes_net.py:796-875
+ *     -> BayesNet._variable_elimination      sorobn/bayes_net.py:739-794
+ *          -> pointwise_mul / pointwise_mul_two   sorobn/bayes_net.py:233-256
+ *          -> CDTAccessor.sum_out                 sorobn/bayes_net.py:100-103
+ *   BayesNet.query(..., algorithm="gibbs")   sorobn/bayes_net.py:665-737
+ *
+ * The reference is pure Python with no FFI; the seam is the method boundary
+ * `_variable_elimination(*query, event=...) -> pd.Series` (bayes_net.py:739, called from 848) and
+ * `_gibbs_sampling(*query, event=..., n_iterations=...)` (bayes_net.py:665, called from 851-853).
+ * A Python caller flattens the pandas CPTs once (mibn_set_network) and then answers batches of
+ * requests through mibn_query_batch; labels <-> codes and pandas objects stay on the Python side
+ * (sorobn_amd/bayes_net.py; binding shown in INTEGRATION.md).
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative MIBN_E_*
+ * code, with a message available from mibn_last_error(); the caller owns all host buffers, the
+ * library owns all device memory; one host thread per handle (thread-compatible, not thread-safe).
+ * There is NO CPU fallback: mibn_create fails with MIBN_E_NODEVICE when no gfx950 device is
+ * visible.
+ */
+#ifndef MIBN_H
+#define MIBN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIBN_OK 0
+#define MIBN_E_ARG (-1)       /* invalid argument */
+#define MIBN_E_NODEVICE (-2)  /* no HIP device / wrong architecture */
+#define MIBN_E_HIP (-3)       /* HIP runtime error */
+#define MIBN_E_NOMEM (-4)     /* plan needs more device memory than the arena budget */
+#define MIBN_E_STATE (-5)     /* call order (e.g. query before set_network) */
+#define MIBN_E_LIMIT (-6)     /* a compile-time limit (scope size, axes) was exceeded */
+
+typedef struct mibn_ctx mibn_t;
+
+/* Number of visible HIP devices (0 when there is no GPU/driver). Never fails hard. */
+int mibn_device_count(int *count);
+
+/* Library version string (static storage). */
+const char *mibn_version(void);
+
+/* Create a context bound to HIP device `device`. */
+int mibn_create(int device, mibn_t **out);
+void mibn_destroy(mibn_t *h);
+const char *mibn_last_error(const mibn_t *h);
+
+/*
+ * Install the network (replaces `self.P` of the reference, bayes_net.py:324, after prepare()).
+ *   n_vars             variables 0..n_vars-1; variable v owns exactly one CPT, factor v
+ *   card[n_vars]       cardinality of each variable (size of its sorted label domain)
+ *   scope_off[n_vars+1], scope_vars[]   CSR: scope of factor v = scope_vars[scope_off[v]..]
+ *                      = [*parents(v), v] - the level order of the reference's CPT Series
+ *   value_off[n_vars+1], values[]       dense float64 table of factor v in C-order over its scope
+ *                      (last scope entry fastest), absent rows = 0.0
+ */
+int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64_t *scope_off,
+                     const int32_t *scope_vars, const int64_t *value_off, const double *values);
+
+/*
+ * Optional elimination-order hints: n_hints priority arrays of n_vars entries (lower = earlier).
+ * The planner evaluates every hint next to its built-in candidate orders with the section 8(d)
+ * cost model and executes the cheapest.  Orders change only floating-point rounding (~1e-16), not
+ * the answer (the reference's own order is an arbitrary set-iteration order, bayes_net.py:766,779).
+ */
+int mibn_set_order_hints(mibn_t *h, int32_t n_hints, const int32_t *priorities);
+
+/*
+ * Answer a batch of exact posterior queries (= B calls of BayesNet._variable_elimination followed
+ * by the normalisation of bayes_net.py:790).
+ *   q_off[B+1], q_vars[]   CSR: query variables of request b, in the caller's argument order
+ *   e_off[B+1], e_vars[], e_codes[]   CSR: evidence variables and their label codes; a code of -1
+ *                          (label outside the domain) yields an all-zero posterior, like the
+ *                          reference's empty Series
+ *   out_off[B+1], out[]    dense posterior of request b at out[out_off[b]..out_off[b+1]) in C-order
+ *                          over its query variables (last query variable fastest); all zeros when
+ *                          the evidence has probability 0
+ * Errors: MIBN_E_ARG for unknown variables, duplicates or query/evidence overlap.
+ */
+int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                     const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
+                     const int64_t *out_off, double *out);
+
+/* Statistics of the last mibn_query_batch call (for the roofline report). */
+typedef struct mibn_stats {
+    double alg_bytes;      /* sum over steps of 8*(sum input cells + output cells) */
+    double alg_flops;      /* sum over steps of n_inputs * product-scope cells */
+    double n_steps;        /* elimination + final product steps executed */
+    double kernel_ms;      /* HIP-event time of the VE kernel launches (sum) */
+    double plan_ms;        /* host planning wall time */
+    double h2d_ms;         /* program upload */
+    double d2h_ms;         /* result download */
+    double total_ms;       /* whole call, host wall clock */
+    double n_launches;     /* kernel launches */
+    double arena_bytes;    /* device scratch arena in use */
+    double max_step_cells; /* largest product scope of any step */
+    double n_workgroups;   /* persistent workgroups launched (last launch) */
+} mibn_stats;
+int mibn_last_stats(const mibn_t *h, mibn_stats *out);
+
+/* Plan only (no device work): fills alg_bytes / alg_flops / n_steps / max_step_cells for one
+ * request.  Also usable without a device through a context created by mibn_create_planner(). */
+int mibn_plan_stats(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e,
+                    const int32_t *e_vars, mibn_stats *out);
+int mibn_create_planner(mibn_t **out); /* host-only context: set_network/plan_stats work, queries fail */
+
+/* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "wg_per_cu". */
+int mibn_set_option(mibn_t *h, const char *name, double value);
+
+/*
+ * Gibbs sampling (replaces BayesNet._gibbs_sampling, bayes_net.py:665-737): n_chains independent
+ * chains of n_iterations single-site updates each (the reference's n_iterations counts single-site
+ * updates, bayes_net.py:720-733; every iteration is recorded, no burn-in, no thinning).
+ *   cycle     update order: every non-evidence variable exactly once (the reference cycles through
+ *             sorted(nodes - event), bayes_net.py:697,718); NULL = ascending variable id
+ *   counts[prod card(q_vars)]   int64 histogram over the joint query state (C-order over q_vars,
+ *             last fastest), summed over all chains and iterations; the estimate of the reference
+ *             (bayes_net.py:736-737) is counts / (n_chains * n_iterations)
+ * Random stream: counter-based Philox4x32-10 keyed by (seed, chain); statistical parity only (the
+ * reference's stream depends on the third-party `vose` sampler, see oracle/README.md).
+ */
+int mibn_gibbs(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+               const int32_t *e_codes, const int32_t *cycle, int64_t n_chains, int64_t n_iterations,
+               uint64_t seed, int64_t *counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIBN_H */

@@ -1,0 +1,207 @@
+"""ctypes binding of the C-ABI in include/mibn.h (libmibn.so, built in-tree by __graft_entry__.build()).
+
+There is deliberately no fallback: if the library is missing or no gfx950 device is visible the
+calls raise, they never route to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmibn.so")
+
+# every symbol include/mibn.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "mibn_device_count", "mibn_version", "mibn_create", "mibn_destroy", "mibn_last_error",
+    "mibn_set_network", "mibn_set_order_hints", "mibn_query_batch", "mibn_last_stats",
+    "mibn_plan_stats", "mibn_create_planner", "mibn_set_option", "mibn_gibbs",
+]
+
+OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+
+
+class MibnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mibn error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "alg_bytes", "alg_flops", "n_steps", "kernel_ms", "plan_ms", "h2d_ms", "d2h_ms",
+        "total_ms", "n_launches", "arena_bytes", "max_step_cells", "n_workgroups")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        i32p, i64p, f64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        vp = C.c_void_p
+        L.mibn_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.mibn_version.restype = C.c_char_p
+        L.mibn_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.mibn_create_planner.argtypes = [C.POINTER(vp)]
+        L.mibn_destroy.argtypes = [vp]
+        L.mibn_destroy.restype = None
+        L.mibn_last_error.argtypes = [vp]
+        L.mibn_last_error.restype = C.c_char_p
+        L.mibn_set_network.argtypes = [vp, C.c_int32, i32p, i64p, i32p, i64p, f64p]
+        L.mibn_set_order_hints.argtypes = [vp, C.c_int32, i32p]
+        L.mibn_query_batch.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p]
+        L.mibn_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mibn_plan_stats.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, C.POINTER(Stats)]
+        L.mibn_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+        L.mibn_gibbs.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, i32p, i32p, C.c_int64,
+                                 C.c_int64, C.c_uint64, i64p]
+        _lib = L
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().mibn_device_count(C.byref(n))
+    return n.value
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class Engine:
+    """One mibn context (= one GPU) holding one flattened network."""
+
+    def __init__(self, device=0, planner_only=False):
+        self._h = C.c_void_p()
+        self._L = lib()
+        if planner_only:
+            rc = self._L.mibn_create_planner(C.byref(self._h))
+        else:
+            rc = self._L.mibn_create(int(device), C.byref(self._h))
+        if rc != OK:
+            why = {E_NODEVICE: "no gfx950 HIP device visible (there is no CPU fallback)",
+                   E_ARG: "bad device index", E_HIP: "HIP runtime error"}.get(rc, "?")
+            raise MibnError(rc, f"mibn_create failed: {why}")
+        self.planner_only = planner_only
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.mibn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise MibnError(rc, self._L.mibn_last_error(self._h).decode())
+
+    def set_network(self, card, scope_off, scope_vars, value_off, values):
+        card, scope_vars = _i32(card), _i32(scope_vars)
+        scope_off, value_off = _i64(scope_off), _i64(value_off)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self._L.mibn_set_network(
+            self._h, len(card), _p(card, C.c_int32), _p(scope_off, C.c_int64),
+            _p(scope_vars, C.c_int32), _p(value_off, C.c_int64), _p(values, C.c_double)))
+        self.card = card
+
+    def set_order_hints(self, hints):
+        h = _i32(np.asarray(hints).reshape(-1, len(self.card)))
+        self._check(self._L.mibn_set_order_hints(self._h, h.shape[0], _p(h, C.c_int32)))
+
+    def set_option(self, name, value):
+        self._check(self._L.mibn_set_option(self._h, name.encode(), float(value)))
+
+    def query_batch(self, q_off, q_vars, e_off, e_vars, e_codes, out_off=None):
+        """CSR request batch -> flat float64 posteriors (+ out_off)."""
+        q_off, e_off = _i64(q_off), _i64(e_off)
+        q_vars, e_vars, e_codes = _i32(q_vars), _i32(e_vars), _i32(e_codes)
+        B = len(q_off) - 1
+        if out_off is None:
+            cells = np.ones(B, np.int64)
+            if B:
+                nq = np.diff(q_off)
+                if nq.min() == nq.max() and nq[0] > 0:
+                    cells = np.prod(self.card[q_vars].reshape(B, -1).astype(np.int64), axis=1)
+                else:
+                    cells = np.array([int(np.prod(self.card[q_vars[a:b]].astype(np.int64)))
+                                      for a, b in zip(q_off[:-1], q_off[1:])], np.int64)
+            out_off = np.concatenate([[0], np.cumsum(cells)]).astype(np.int64)
+        out_off = _i64(out_off)
+        out = np.zeros(int(out_off[-1]), np.float64)
+        e_vars_ = e_vars if len(e_vars) else np.zeros(1, np.int32)
+        e_codes_ = e_codes if len(e_codes) else np.zeros(1, np.int32)
+        q_vars_ = q_vars if len(q_vars) else np.zeros(1, np.int32)
+        out_ = out if len(out) else np.zeros(1, np.float64)
+        self._check(self._L.mibn_query_batch(
+            self._h, B, _p(q_off, C.c_int64), _p(q_vars_, C.c_int32), _p(e_off, C.c_int64),
+            _p(e_vars_, C.c_int32), _p(e_codes_, C.c_int32), _p(out_off, C.c_int64),
+            _p(out_, C.c_double)))
+        return out, out_off
+
+    def query_fixed(self, qvars, evars, ecodes):
+        """Fixed-shape batch: qvars[B, nq], evars[B, ne], ecodes[B, ne] -> posteriors[B, cells]
+        (all requests must have the same query-table size)."""
+        qvars = _i32(qvars).reshape(len(qvars), -1)
+        B, nq = qvars.shape
+        evars = _i32(evars).reshape(B, -1)
+        ecodes = _i32(ecodes).reshape(B, -1)
+        ne = evars.shape[1]
+        q_off = np.arange(B + 1, dtype=np.int64) * nq
+        e_off = np.arange(B + 1, dtype=np.int64) * ne
+        out, out_off = self.query_batch(q_off, qvars.reshape(-1), e_off, evars.reshape(-1),
+                                        ecodes.reshape(-1))
+        return out.reshape(B, -1) if B else out.reshape(0, 0)
+
+    def stats(self):
+        s = Stats()
+        self._check(self._L.mibn_last_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def plan_stats(self, qvars, evars):
+        q, e = _i32(qvars), _i32(evars)
+        e_ = e if len(e) else np.zeros(1, np.int32)
+        s = Stats()
+        self._check(self._L.mibn_plan_stats(self._h, len(q), _p(q, C.c_int32), len(e),
+                                            _p(e_, C.c_int32), C.byref(s)))
+        return s.as_dict()
+
+    def gibbs(self, qvars, evars, ecodes, n_chains, n_iterations, seed=0, cycle=None):
+        q, e, c = _i32(qvars), _i32(evars), _i32(ecodes)
+        e_ = e if len(e) else np.zeros(1, np.int32)
+        c_ = c if len(c) else np.zeros(1, np.int32)
+        cells = int(np.prod(self.card[q].astype(np.int64)))
+        counts = np.zeros(cells, np.int64)
+        cyc = None
+        if cycle is not None:
+            cyc_arr = _i32(cycle)
+            cyc = _p(cyc_arr, C.c_int32)
+        self._check(self._L.mibn_gibbs(self._h, len(q), _p(q, C.c_int32), len(e),
+                                       _p(e_, C.c_int32), _p(c_, C.c_int32), cyc, int(n_chains),
+                                       int(n_iterations), int(seed) & (2**64 - 1),
+                                       _p(counts, C.c_int64)))
+        return counts

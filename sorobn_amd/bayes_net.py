@@ -1,0 +1,358 @@
+"""Host-side mirror of the reference's `BayesNet` for the exact-inference hot path.
+
+Same constructor, attributes (`P`, `parents`, `children`, `nodes`), `prepare()`, `query()` and
+`impute()` as MaxHalford/sorobn (sorobn/bayes_net.py:259-371, 796-908) - names, argument meaning,
+return types and error behaviour - but `query(algorithm="exact")` runs on an MI355X: the pandas
+CPTs are flattened once (flatten.py) and the variable-elimination loop (bayes_net.py:739-794) is
+executed by hand-written gfx950 kernels behind the C-ABI of include/mibn.h.  There is no CPU
+fallback: without the HIP extension or without a gfx950 device `query` raises.
+
+Out of scope here (use the reference for them): fit/partial_fit, sample,
+full_joint_dist/predict_proba, likelihood weighting and rejection sampling, graph drawing.
+
+`accelerate(bn)` attaches the same backend to an *existing reference object* by replacing the two
+methods `query` dispatches to (bayes_net.py:848, 851-853); see INTEGRATION.md.
+"""
+import collections
+import graphlib
+import itertools
+import os
+import types
+
+import numpy as np
+import pandas as pd
+
+from . import _capi
+from .flatten import flatten
+
+__all__ = ["BayesNet", "accelerate", "Backend"]
+
+
+def _default_device():
+    for key in ("MIBN_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(key, "") != "":
+            return int(os.environ[key])
+    return 0
+
+
+class Backend:
+    """Flattened network + one mibn engine.  Built lazily from any object exposing the reference's
+    `nodes` / `parents` / `P`; rebuilt when the CPT objects change."""
+
+    def __init__(self, bn, device=None, planner_only=False):
+        self.flat = flatten(bn)
+        self.fingerprint = Backend.fingerprint_of(bn)
+        self.engine = _capi.Engine(_default_device() if device is None else device,
+                                   planner_only=planner_only)
+        f = self.flat
+        self.engine.set_network(f.card, f.scope_off, f.scope_vars, f.value_off, f.values)
+        if f.hints:
+            self.engine.set_order_hints(np.stack(f.hints))
+        self._anc = {}
+
+    @staticmethod
+    def fingerprint_of(bn):
+        return tuple((id(k), id(v), len(v)) for k, v in bn.P.items())
+
+    # ---- id / code conversion -------------------------------------------------------------------
+    def var_id(self, name):
+        try:
+            return self.flat.id[name]
+        except (KeyError, TypeError):
+            raise KeyError(name)  # bayes_net.py:770 / 373-375: unknown node -> KeyError(name)
+
+    def _ancestors(self, v):
+        if v not in self._anc:
+            s = set()
+            for p in self.flat.parents[v]:
+                s.add(p)
+                s |= self._ancestors(p)
+            self._anc[v] = s
+        return self._anc[v]
+
+    def encode(self, query, event):
+        """names/labels -> (qvars, evars, ecodes); raises KeyError like the reference when a relevant
+        node is unknown or has no CPT."""
+        q = [self.var_id(n) for n in query]
+        ev = [self.var_id(n) for n in event]
+        codes = [self.flat.code_of(v, lab) for v, lab in zip(ev, event.values())]
+        if self.flat.missing:
+            rel = set(q) | set(ev)
+            for v in list(rel):
+                rel |= self._ancestors(v)
+            for v in sorted(rel & self.flat.missing):
+                raise KeyError(self.flat.names[v])
+        return q, ev, codes
+
+    # ---- result construction --------------------------------------------------------------------
+    def posterior_series(self, query, dense):
+        """Dense C-order posterior over `query` (caller order) -> the Series
+        `_variable_elimination` returns (bayes_net.py:789-794): zero rows absent, one level per query
+        variable, plain Index for a single variable."""
+        f = self.flat
+        ids = [f.id[n] for n in query]
+        keep = np.flatnonzero(dense > 0)
+        vals = dense[keep]
+        if len(ids) == 1:
+            idx = f.dom_index[ids[0]][keep]
+            idx = idx.rename(query[0])
+            return pd.Series(vals, index=idx)
+        shape = [int(f.card[v]) for v in ids]
+        codes = np.unravel_index(keep, shape)
+        idx = pd.MultiIndex(levels=[f.dom_index[v] for v in ids], codes=list(codes),
+                            names=list(query), verify_integrity=False)
+        return pd.Series(vals, index=idx)
+
+    # ---- the two replaced methods ---------------------------------------------------------------
+    def variable_elimination(self, *query, event):
+        q, ev, codes = self.encode(query, event)
+        out = self.engine.query_fixed([q], [ev], [codes])
+        return self.posterior_series(query, out[0])
+
+    def variable_elimination_many(self, requests):
+        """requests: iterable of (query tuple, event dict) -> list of Series (one launch)."""
+        requests = list(requests)
+        q_off, e_off, qv, evs, ecs = [0], [0], [], [], []
+        for query, event in requests:
+            q, ev, codes = self.encode(query, event)
+            qv += q
+            evs += ev
+            ecs += codes
+            q_off.append(len(qv))
+            e_off.append(len(evs))
+        out, out_off = self.engine.query_batch(q_off, qv, e_off, evs, ecs)
+        return [self.posterior_series(query, out[a:b])
+                for (query, _), a, b in zip(requests, out_off[:-1], out_off[1:])]
+
+    def gibbs_sampling(self, *query, event, n_iterations, n_chains=1, seed=0):
+        q, ev, codes = self.encode(query, event)
+        f = self.flat
+        # the reference cycles through sorted(nodes - event) (bayes_net.py:697,718)
+        free = [v for v in range(len(f.names)) if v not in set(ev)]
+        try:
+            cycle = sorted(free, key=lambda v: f.names[v])
+        except TypeError:
+            cycle = free
+        counts = self.engine.gibbs(q, ev, codes, n_chains, n_iterations, seed=seed, cycle=cycle)
+        dense = counts.astype(np.float64) / float(max(1, n_chains * n_iterations))
+        return self.posterior_series(query, dense)
+
+
+class BayesNet:
+    """Bayesian network with an MI355X exact-inference backend.
+
+    Parameters follow the reference (bayes_net.py:259-289): `structure` is a sequence of
+    `(parent(s), child(ren))` tuples (lists are expanded to their cartesian product) and bare node
+    names; `prior_count` and `seed` are accepted for signature compatibility (`seed` seeds the Gibbs
+    kernel).
+    """
+
+    def __init__(self, *structure, prior_count: int = None, seed: int = None):
+        self.prior_count = prior_count
+        self.seed = seed
+        as_list = lambda o: o if isinstance(o, list) else [o]
+        parents = collections.defaultdict(set)
+        children = collections.defaultdict(set)
+        loose = set()
+        for item in structure:
+            if isinstance(item, tuple):
+                ps, cs = item
+                for p, c in itertools.product(as_list(ps), as_list(cs)):
+                    parents[c].add(p)
+                    children[p].add(c)
+            else:
+                loose.add(item)
+        self.parents = {n: sorted(ps) for n, ps in parents.items()}
+        self.children = {n: sorted(cs) for n, cs in children.items()}
+        # topological order, ties lexicographic - same construction as bayes_net.py:319-322 so that
+        # `nodes` (and with it variable ids) are identical to the reference's
+        sorter = graphlib.TopologicalSorter()
+        for n in sorted({*self.parents, *self.children, *loose}):
+            sorter.add(n, *self.parents.get(n, []))
+        self.nodes = list(sorter.static_order())
+        self.P = {}
+        self._backend = None
+        self._device = None
+
+    # ---- pickling / copying: device handles are rebuilt lazily -----------
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_backend"] = None
+        return d
+
+    # ---- CPT house-keeping (bayes_net.py:327-371) ------------------------------------------------
+    def prepare(self) -> "BayesNet":
+        """Normalise the user's CPTs: DataFrame with a 'p' column -> Series; name / order the
+        index levels as [*parents, node]; sort; name the Series.  Raises the reference's
+        ValueErrors (bayes_net.py:341-344, 349-352)."""
+        for node in list(self.P):
+            P = self.P[node]
+            parents = self.parents.get(node, [])
+            if isinstance(P, pd.DataFrame):
+                if "p" not in P.columns:
+                    raise ValueError(f"DataFrame for '{node}' must have a 'p' column "
+                                     f"containing probabilities")
+                cols = [c for c in P.columns if c != "p"]
+                expected = set(parents) | {node}
+                if set(cols) != expected:
+                    raise ValueError(f"DataFrame for '{node}' has columns {cols}, "
+                                     f"but expected {sorted(expected)} (plus 'p')")
+                P = P.set_index([*parents, node])["p"]
+            wanted = [*parents, node]
+            if not parents:
+                P = P.copy() if P is self.P[node] else P
+                P.index.name = node
+            elif set(P.index.names) == set(wanted):
+                # NOTE: the reference computes this reordering but never stores it back
+                # (SURVEY.md section 3.4); here the reordered, sorted table is what is kept
+                P = P.reorder_levels(wanted)
+            else:
+                P = P.copy() if P is self.P[node] else P
+                P.index.names = wanted
+            P = P.sort_index()
+            P.name = f"P({node} | {', '.join(map(str, parents))})" if parents else f"P({node})"
+            self.P[node] = P
+        self._backend = None
+        return self
+
+    # ---- graph helpers on the hot path ----------------------------------------------------------
+    def ancestors(self, node):
+        """Set of ancestors (bayes_net.py:373-378), memoised instead of re-walked."""
+        memo = {}
+
+        def walk(n):
+            if n not in memo:
+                s = set()
+                for p in self.parents.get(n, ()):
+                    s.add(p)
+                    s |= walk(p)
+                memo[n] = s
+            return memo[n]
+
+        return set(walk(node))
+
+    @property
+    def roots(self):
+        return [n for n in self.nodes if n not in self.parents]
+
+    @property
+    def leaves(self):
+        return [n for n in self.nodes if n not in self.children]
+
+    # ---- backend --------------------------------------------------------------------------------
+    def use_device(self, device: int):
+        """Bind to a HIP device index (default: $MIBN_DEVICE, $LOCAL_RANK, else 0)."""
+        self._device = device
+        self._backend = None
+        return self
+
+    @property
+    def backend(self) -> Backend:
+        if self._backend is None or self._backend.fingerprint != Backend.fingerprint_of(self):
+            self._backend = Backend(self, device=self._device)
+        return self._backend
+
+    def _variable_elimination(self, *query, event):
+        return self.backend.variable_elimination(*query, event=event)
+
+    def _gibbs_sampling(self, *query, event, n_iterations, n_chains=1):
+        return self.backend.gibbs_sampling(*query, event=event, n_iterations=n_iterations,
+                                           n_chains=n_chains, seed=self.seed or 0)
+
+    # ---- public API (bayes_net.py:796-908) ------------------------------------------------------
+    @staticmethod
+    def _check_request(query, event):
+        if not query:
+            raise ValueError("At least one query variable has to be specified")
+        for q in query:
+            if q in event:
+                raise ValueError("A query variable cannot be part of the event")
+
+    @staticmethod
+    def _finish(answer, query):
+        """rename + level sort + row sort, exactly the tail of `query` (bayes_net.py:869-875)."""
+        answer = answer.rename(f"P({', '.join(query)})")
+        if isinstance(answer.index, pd.MultiIndex):
+            answer = answer.reorder_levels(sorted(answer.index.names))
+        return answer.sort_index()
+
+    def query(self, *query, event: dict, algorithm="exact", n_iterations=100, n_chains=1) -> pd.Series:
+        """Answer a probabilistic query; same contract as the reference (bayes_net.py:796-875).
+
+        `algorithm`: "exact" (variable elimination on the GPU) or "gibbs" (GPU chains; `n_chains` is
+        an extension, default 1 like the reference).  "likelihood" and "rejection" are not part of
+        this backend and raise NotImplementedError; anything else raises the reference's ValueError.
+        """
+        self._check_request(query, event)
+        if algorithm == "exact":
+            answer = self._variable_elimination(*query, event=event)
+        elif algorithm == "gibbs":
+            answer = self._gibbs_sampling(*query, event=event, n_iterations=n_iterations,
+                                          n_chains=n_chains)
+        elif algorithm in ("likelihood", "rejection"):
+            raise NotImplementedError(
+                f"algorithm={algorithm!r} is outside the MI355X hot path (SURVEY.md section 8f); "
+                "use the reference implementation for it")
+        else:
+            raise ValueError("Unknown algorithm, must be one of: exact, gibbs, likelihood, "
+                             + "rejection")
+        return self._finish(answer, query)
+
+    def query_many(self, requests):
+        """Batched extension: `requests` = iterable of (query tuple, event dict); returns the list of
+        Series `query(*q, event=e)` would return, computed in one device launch."""
+        requests = [((q,) if isinstance(q, str) else tuple(q), e) for q, e in requests]
+        for q, e in requests:
+            self._check_request(q, e)
+        answers = self.backend.variable_elimination_many(requests)
+        return [self._finish(a, q) for a, (q, _) in zip(answers, requests)]
+
+    def impute(self, sample: dict, **query_params) -> pd.Series:
+        """Replace the `None` entries of `sample` by the most probable joint assignment
+        (bayes_net.py:877-908).  With a single missing variable the reference zips the *scalar*
+        `idxmax()` (TypeError for bool labels, character-zip for strings - SURVEY.md section 3.2);
+        here that case simply works."""
+        missing = [k for k, v in sample.items() if v is None]
+        event = {k: v for k, v in sample.items() if v is not None}
+        posterior = self.query(*missing, event=event, **query_params)
+        best = posterior.idxmax()
+        if len(missing) == 1:
+            best = (best,)
+        for k, v in zip(posterior.index.names, best):
+            event[k] = v
+        return pd.Series(event)
+
+    # ---- out of scope ---------------------------------------------------------------------------
+    def _out_of_scope(self, *a, **k):
+        raise NotImplementedError("outside the MI355X hot path (SURVEY.md section 8f); "
+                                  "use the reference implementation")
+
+    fit = partial_fit = sample = full_joint_dist = predict_proba = predict_log_proba = _out_of_scope
+
+
+def accelerate(bn, device=None):
+    """Attach the MI355X backend to an existing *reference* `sorobn.BayesNet` instance.
+
+    Replaces the two bound methods `BayesNet.query` dispatches to - `_variable_elimination`
+    (bayes_net.py:848) and `_gibbs_sampling` (851-853) - and leaves `query`'s own post-processing
+    (869-875) and `impute` (877-908) untouched, so naming / sorting stay byte-identical.
+    """
+    state = {"backend": None}
+
+    def backend():
+        b = state["backend"]
+        if b is None or b.fingerprint != Backend.fingerprint_of(bn):
+            b = state["backend"] = Backend(bn, device=device)
+        return b
+
+    def _variable_elimination(self, *query, event):
+        return backend().variable_elimination(*query, event=event)
+
+    def _gibbs_sampling(self, *query, event, n_iterations):
+        return backend().gibbs_sampling(*query, event=event, n_iterations=n_iterations,
+                                        seed=getattr(self, "seed", None) or 0)
+
+    bn._variable_elimination = types.MethodType(_variable_elimination, bn)
+    bn._gibbs_sampling = types.MethodType(_gibbs_sampling, bn)
+    bn._mibn_backend = backend
+    return bn

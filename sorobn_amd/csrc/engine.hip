@@ -1,0 +1,398 @@
+// mibn engine: C-ABI (include/mibn.h) over the planner and the gfx950 kernels.
+// No CPU fallback: every query entry point needs a live HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mibn.h"
+#include "gibbs_kernel.hip.h"
+#include "planner.h"
+#include "ve_kernel.hip.h"
+
+using namespace mibn;
+
+namespace {
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+struct mibn_ctx {
+    Network net;
+    bool has_net = false;
+    bool planner_only = false;
+    int device = -1;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *d_pool = nullptr;
+    double *d_arena = nullptr;
+    size_t arena_bytes = 0;
+    uint32_t *d_prog = nullptr;
+    size_t prog_cap = 0;  // words
+    uint64_t *d_prog_off = nullptr;
+    int32_t *d_order = nullptr;
+    size_t prog_off_cap = 0, order_cap = 0;
+    double *d_results = nullptr;
+    size_t results_cap = 0;  // doubles
+    uint32_t *d_ticket = nullptr;
+    std::string err;
+    mibn_stats stats{};
+    // options
+    double arena_gb = 64.0;
+    int threads = 0;
+    int wg_per_cu = 8;
+    int64_t chunk = 32768;  // requests per internal launch
+};
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                             \
+            return MIBN_E_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+
+extern "C" {
+
+const char *mibn_version(void) { return "mibn 0.1 (gfx950)"; }
+
+int mibn_device_count(int *count) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (count) *count = n;
+    return MIBN_OK;
+}
+
+int mibn_create_planner(mibn_t **out) {
+    if (!out) return MIBN_E_ARG;
+    auto *h = new mibn_ctx();
+    h->planner_only = true;
+    *out = h;
+    return MIBN_OK;
+}
+
+int mibn_create(int device, mibn_t **out) {
+    if (!out) return MIBN_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIBN_E_NODEVICE;
+    if (device < 0 || device >= n) return MIBN_E_ARG;
+    auto *h = new mibn_ctx();
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete h; return MIBN_E_NODEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete h; return MIBN_E_NODEVICE; }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {  // kernels are built for gfx950 only
+        delete h;
+        return MIBN_E_NODEVICE;
+    }
+    h->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipMalloc(&h->d_ticket, 64) != hipSuccess) {
+        delete h;
+        return MIBN_E_HIP;
+    }
+    *out = h;
+    return MIBN_OK;
+}
+
+void mibn_destroy(mibn_t *h) {
+    if (!h) return;
+    if (!h->planner_only) {
+        hipSetDevice(h->device);
+        hipFree(h->d_pool);
+        hipFree(h->d_arena);
+        hipFree(h->d_prog);
+        hipFree(h->d_prog_off);
+        hipFree(h->d_order);
+        hipFree(h->d_results);
+        hipFree(h->d_ticket);
+        if (h->ev0) hipEventDestroy(h->ev0);
+        if (h->ev1) hipEventDestroy(h->ev1);
+        if (h->stream) hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+const char *mibn_last_error(const mibn_t *h) { return h ? h->err.c_str() : "null handle"; }
+
+int mibn_set_option(mibn_t *h, const char *name, double value) {
+    if (!h || !name) return MIBN_E_ARG;
+    std::string n(name);
+    if (n == "arena_gb") h->arena_gb = value;
+    else if (n == "threads") h->threads = (int)value;
+    else if (n == "wg_per_cu") h->wg_per_cu = std::max(1, std::min(8, (int)value));
+    else if (n == "chunk") h->chunk = std::max<int64_t>(1, (int64_t)value);
+    else { h->err = "unknown option " + n; return MIBN_E_ARG; }
+    return MIBN_OK;
+}
+
+int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64_t *scope_off,
+                     const int32_t *scope_vars, const int64_t *value_off, const double *values) {
+    if (!h || !card || !scope_off || !scope_vars || !value_off || !values) return MIBN_E_ARG;
+    std::string e = h->net.set(n_vars, card, scope_off, scope_vars, value_off, values);
+    if (!e.empty()) { h->err = e; h->has_net = false; return MIBN_E_ARG; }
+    h->has_net = true;
+    if (!h->planner_only) {
+        HIP_TRY(h, hipSetDevice(h->device));
+        if (h->d_pool) { HIP_TRY(h, hipFree(h->d_pool)); h->d_pool = nullptr; }
+        size_t bytes = std::max<size_t>(8, h->net.pool.size() * sizeof(double));
+        HIP_TRY(h, hipMalloc(&h->d_pool, bytes));
+        HIP_TRY(h, hipMemcpy(h->d_pool, h->net.pool.data(), h->net.pool.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return MIBN_OK;
+}
+
+int mibn_set_order_hints(mibn_t *h, int32_t n_hints, const int32_t *priorities) {
+    if (!h || n_hints < 0 || (n_hints && !priorities)) return MIBN_E_ARG;
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    h->net.hints.clear();
+    for (int i = 0; i < n_hints; ++i)
+        h->net.hints.emplace_back(priorities + (size_t)i * h->net.n_vars, priorities + (size_t)(i + 1) * h->net.n_vars);
+    return MIBN_OK;
+}
+
+int mibn_last_stats(const mibn_t *h, mibn_stats *out) {
+    if (!h || !out) return MIBN_E_ARG;
+    *out = h->stats;
+    return MIBN_OK;
+}
+
+int mibn_plan_stats(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                    mibn_stats *out) {
+    if (!h || !out) return MIBN_E_ARG;
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    Request rq;
+    rq.nq = n_q; rq.qvars = q_vars; rq.ne = n_e; rq.evars = e_vars;
+    std::string e = validate_request(h->net, rq);
+    if (!e.empty()) { h->err = e; return MIBN_E_ARG; }
+    std::vector<uint32_t> prog;
+    PlanStats st;
+    e = plan_request(h->net, rq, prog, st);
+    if (!e.empty()) { h->err = e; return MIBN_E_LIMIT; }
+    std::memset(out, 0, sizeof(*out));
+    out->alg_bytes = st.alg_bytes;
+    out->alg_flops = st.alg_flops;
+    out->n_steps = st.n_steps;
+    out->max_step_cells = st.max_step_cells;
+    out->arena_bytes = 8.0 * (double)st.arena_cells;
+    return MIBN_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <class T>
+int ensure(mibn_ctx *h, T *&ptr, size_t &cap, size_t need) {
+    if (need <= cap) return MIBN_OK;
+    if (ptr) { HIP_TRY(h, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    size_t n = need + need / 4 + 1024;
+    HIP_TRY(h, hipMalloc(&ptr, n * sizeof(T)));
+    cap = n;
+    return MIBN_OK;
+}
+
+struct Chunk {
+    std::vector<std::vector<uint32_t>> progs;      // per planning thread
+    std::vector<uint64_t> prog_off;                // per request (global word offset)
+    std::vector<double> cost;                      // alg_bytes per request
+    std::vector<int32_t> order;
+    int64_t arena_cells = 0;
+    size_t total_words = 0;
+    PlanStats st;
+    std::string err;
+};
+
+// plan requests [b0, b1) on T threads
+void plan_chunk(const mibn_ctx *h, int64_t b0, int64_t b1, const int64_t *q_off, const int32_t *q_vars,
+                const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes, const int64_t *out_off,
+                const std::vector<char> &skip, Chunk &ck) {
+    const int64_t n = b1 - b0;
+    int T = h->threads > 0 ? h->threads : (int)std::thread::hardware_concurrency();
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(T, 64), (n + 63) / 64));
+    ck.progs.assign(T, {});
+    ck.prog_off.assign(n, 0);
+    ck.cost.assign(n, 0.0);
+    std::vector<PlanStats> tst(T);
+    std::vector<std::string> terr(T);
+    std::vector<std::vector<uint64_t>> local_off(T);
+    auto work = [&](int t) {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        auto &prog = ck.progs[t];
+        prog.reserve((size_t)(hi - lo) * 512);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t b = b0 + i;
+            ck.prog_off[i] = prog.size();
+            if (skip[b]) { prog.push_back(0); continue; }  // zero steps: result stays all-zero
+            Request rq;
+            rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
+            rq.qvars = q_vars + q_off[b];
+            rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
+            rq.evars = e_vars + e_off[b];
+            rq.ecodes = e_codes + e_off[b];
+            rq.out_off = out_off[b] - out_off[b0];
+            PlanStats st;
+            std::string e = plan_request(h->net, rq, prog, st);
+            if (!e.empty()) { terr[t] = e; return; }
+            ck.cost[i] = st.alg_bytes;
+            tst[t].alg_bytes += st.alg_bytes;
+            tst[t].alg_flops += st.alg_flops;
+            tst[t].n_steps += st.n_steps;
+            tst[t].max_step_cells = std::max(tst[t].max_step_cells, st.max_step_cells);
+            tst[t].arena_cells = std::max(tst[t].arena_cells, st.arena_cells);
+        }
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    size_t base = 0;
+    for (int t = 0; t < T; ++t) {
+        if (!terr[t].empty()) ck.err = terr[t];
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        for (int64_t i = lo; i < hi; ++i) ck.prog_off[i] += base;
+        base += ck.progs[t].size();
+        ck.st.alg_bytes += tst[t].alg_bytes;
+        ck.st.alg_flops += tst[t].alg_flops;
+        ck.st.n_steps += tst[t].n_steps;
+        ck.st.max_step_cells = std::max(ck.st.max_step_cells, tst[t].max_step_cells);
+        ck.arena_cells = std::max(ck.arena_cells, tst[t].arena_cells);
+    }
+    ck.total_words = base;
+    ck.order.resize(n);
+    std::iota(ck.order.begin(), ck.order.end(), 0);
+    std::stable_sort(ck.order.begin(), ck.order.end(), [&](int32_t a, int32_t b) { return ck.cost[a] > ck.cost[b]; });
+}
+
+}  // namespace
+
+extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                                const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
+                                const int64_t *out_off, double *out) {
+    if (!h || B < 0 || !q_off || !e_off || !out_off || (B && !out)) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    const double t_start = now_ms();
+    h->stats = mibn_stats{};
+    HIP_TRY(h, hipSetDevice(h->device));
+    // validation (bayes_net.py:840-845) and the out-of-domain-evidence short cut
+    std::vector<char> skip((size_t)B, 0);
+    for (int64_t b = 0; b < B; ++b) {
+        Request rq;
+        rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
+        rq.qvars = q_vars + q_off[b];
+        rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
+        rq.evars = e_vars + e_off[b];
+        std::string e = validate_request(h->net, rq);
+        if (!e.empty()) { h->err = "request " + std::to_string(b) + ": " + e; return MIBN_E_ARG; }
+        int64_t cells = 1;
+        for (int i = 0; i < rq.nq; ++i) cells *= h->net.card[rq.qvars[i]];
+        if (out_off[b + 1] - out_off[b] != cells) { h->err = "request " + std::to_string(b) + ": out_off does not match the query table size"; return MIBN_E_ARG; }
+        for (int i = 0; i < rq.ne; ++i) {
+            int32_t c = e_codes[e_off[b] + i];
+            if (c < 0 || c >= h->net.card[rq.evars[i]]) skip[b] = 1;  // label outside the domain -> empty posterior
+        }
+    }
+    for (int64_t b0 = 0; b0 < B; b0 += h->chunk) {
+        const int64_t b1 = std::min(B, b0 + h->chunk);
+        const int64_t n = b1 - b0;
+        double t0 = now_ms();
+        Chunk ck;
+        plan_chunk(h, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip, ck);
+        if (!ck.err.empty()) { h->err = ck.err; return MIBN_E_LIMIT; }
+        h->stats.plan_ms += now_ms() - t0;
+        // arena: one slot per persistent workgroup
+        const size_t slot_cells = (size_t)std::max<int64_t>(2, (ck.arena_cells + 1) & ~int64_t(1));
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
+        const double budget = std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes));
+        int64_t n_wg = (int64_t)h->n_cu * h->wg_per_cu;
+        n_wg = std::min<int64_t>(n_wg, n);
+        n_wg = std::min<int64_t>(n_wg, (int64_t)(budget / (8.0 * (double)slot_cells)));
+        if (n_wg < 1) { h->err = "a request needs " + std::to_string(8.0 * slot_cells / 1e9) + " GB of scratch, above the arena budget"; return MIBN_E_NOMEM; }
+        const size_t need = (size_t)n_wg * slot_cells * sizeof(double);
+        if (need > h->arena_bytes) {
+            if (h->d_arena) { HIP_TRY(h, hipFree(h->d_arena)); h->d_arena = nullptr; h->arena_bytes = 0; }
+            HIP_TRY(h, hipMalloc(&h->d_arena, need));
+            h->arena_bytes = need;
+        }
+        const size_t res_cells = (size_t)(out_off[b1] - out_off[b0]);
+        int rc;
+        if ((rc = ensure(h, h->d_prog, h->prog_cap, ck.total_words))) return rc;
+        if ((rc = ensure(h, h->d_prog_off, h->prog_off_cap, (size_t)n))) return rc;
+        if ((rc = ensure(h, h->d_order, h->order_cap, (size_t)n))) return rc;
+        if ((rc = ensure(h, h->d_results, h->results_cap, res_cells))) return rc;
+        // upload
+        t0 = now_ms();
+        size_t base = 0;
+        for (auto &p : ck.progs) {
+            if (!p.empty()) HIP_TRY(h, hipMemcpyAsync(h->d_prog + base, p.data(), p.size() * 4, hipMemcpyHostToDevice, h->stream));
+            base += p.size();
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_prog_off, ck.prog_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_order, ck.order.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_ticket, 0, 64, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_results, 0, res_cells * 8, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->stats.h2d_ms += now_ms() - t0;
+        // launch
+        KernelArgs A;
+        A.prog = h->d_prog;
+        A.prog_off = h->d_prog_off;
+        A.order = h->d_order;
+        A.pool = h->d_pool;
+        A.arena = h->d_arena;
+        A.slot_cells = slot_cells;
+        A.results = h->d_results;
+        A.ticket = h->d_ticket;
+        A.n_requests = (int32_t)n;
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(ve_kernel, dim3((unsigned)n_wg), dim3(kWG), 0, h->stream, A);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->stats.kernel_ms += ms;
+        h->stats.n_launches += 1;
+        t0 = now_ms();
+        HIP_TRY(h, hipMemcpy(out + out_off[b0], h->d_results, res_cells * 8, hipMemcpyDeviceToHost));
+        h->stats.d2h_ms += now_ms() - t0;
+        h->stats.alg_bytes += ck.st.alg_bytes;
+        h->stats.alg_flops += ck.st.alg_flops;
+        h->stats.n_steps += ck.st.n_steps;
+        h->stats.max_step_cells = std::max(h->stats.max_step_cells, ck.st.max_step_cells);
+        h->stats.arena_bytes = (double)need;
+        h->stats.n_workgroups = (double)n_wg;
+    }
+    h->stats.total_ms = now_ms() - t_start;
+    return MIBN_OK;
+}
+
+extern "C" int mibn_gibbs(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                          const int32_t *e_codes, const int32_t *cycle, int64_t n_chains, int64_t n_iterations,
+                          uint64_t seed, int64_t *counts) {
+    if (!h || !q_vars || !counts || n_chains < 1 || n_iterations < 0) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    Request rq;
+    rq.nq = n_q; rq.qvars = q_vars; rq.ne = n_e; rq.evars = e_vars;
+    std::string e = validate_request(h->net, rq);
+    if (!e.empty()) { h->err = e; return MIBN_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return gibbs_run(h->net, h->d_pool, h->stream, n_q, q_vars, n_e, e_vars, e_codes, cycle, n_chains, n_iterations, seed,
+                     counts, h->err, h->stats.kernel_ms);
+}

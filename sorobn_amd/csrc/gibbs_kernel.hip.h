@@ -1,0 +1,265 @@
+// Gibbs sampling on gfx950: one chain per lane, all 64 chains of a wave update the SAME variable in
+// the same iteration (the reference cycles deterministically through the non-evidence variables,
+// sorobn/bayes_net.py:697,718-722), so there is no divergence; the Markov-blanket conditional
+//     P(v | mb(v))  ~  P(v | pa(v)) * prod_{c in children(v)} P(c | pa(c))      (bayes_net.py:700-710)
+// is evaluated on the fly from the dense CPTs (L1/L2 resident) instead of materialising the
+// reference's per-node posterior tables (8^7 rows = 16 MiB per interior node in config 5).
+// Chain state lives in LDS as state[var][lane] bytes.  Random numbers: Philox4x32-10 keyed by
+// (seed, chain), counter = update index; statistical parity only (see include/mibn.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mibn.h"
+#include "planner.h"
+
+namespace mibn {
+
+struct GibbsVar {
+    int32_t card, table_off, scope_begin, scope_len, child_begin, child_len, is_evidence, ev_code;
+};
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// uniform double in [0,1) from Philox4x32-10(counter = (i_lo, i_hi, stream, 0), key = (k0, k1))
+__device__ __forceinline__ double philox_uniform(uint64_t i, uint32_t stream, uint32_t k0, uint32_t k1) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), stream, 0u};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const uint64_t m = ((uint64_t)c[0] << 21) ^ (uint64_t)(c[1] >> 11);  // 53 bits
+    return (double)(m & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
+}
+
+struct GibbsArgs {
+    const double *pool;
+    const GibbsVar *vars;
+    const int32_t *scope_var;     // flattened (variable, stride) of every CPT scope
+    const int32_t *scope_stride;
+    const int32_t *children;      // flattened children lists
+    const int32_t *cycle;         // update order (non-evidence variables)
+    const int32_t *qvars;
+    const int32_t *qstride;       // stride of each query variable in the joint histogram
+    unsigned long long *counts;   // global histogram
+    int32_t n_vars, n_cycle, n_q, hist_cells;
+    int64_t n_chains, n_iterations;
+    uint64_t seed;
+};
+
+constexpr int kGibbsWaves = 1;  // waves per workgroup (each wave = 64 independent chains)
+
+// weight of value x of variable v given the rest of the lane's state
+__device__ __forceinline__ double gibbs_weight(const GibbsArgs &A, const GibbsVar &V, int v, int x,
+                                               const uint8_t *st /* state[var*64 + lane] */, int lane) {
+    // own CPT: scope = [*parents, v], v last with stride 1
+    int off = V.table_off + x;
+    for (int k = 0; k + 1 < V.scope_len; ++k)
+        off += (int)st[A.scope_var[V.scope_begin + k] * 64 + lane] * A.scope_stride[V.scope_begin + k];
+    double w = A.pool[off];
+    for (int ci = 0; ci < V.child_len; ++ci) {
+        const int c = A.children[V.child_begin + ci];
+        const GibbsVar C = A.vars[c];
+        int o = C.table_off;
+        for (int k = 0; k < C.scope_len; ++k) {
+            const int u = A.scope_var[C.scope_begin + k];
+            const int s = A.scope_stride[C.scope_begin + k];
+            o += (u == v ? x : (int)st[u * 64 + lane]) * s;
+        }
+        w *= A.pool[o];
+    }
+    return w;
+}
+
+__global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    uint8_t *st = smem;                                        // n_vars * 64 bytes
+    unsigned int *hist = (unsigned int *)(smem + ((A.n_vars * 64 + 15) & ~15));  // hist_cells
+    const int64_t chain = (int64_t)blockIdx.x * 64 + lane;
+    const bool active = chain < A.n_chains;
+    for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x) hist[i] = 0;
+    const uint32_t k0 = (uint32_t)A.seed ^ (uint32_t)chain * 0x9E3779B1u;
+    const uint32_t k1 = (uint32_t)(A.seed >> 32) ^ (uint32_t)(chain >> 32) ^ 0x85EBCA6Bu;
+
+    // forward (ancestral) sample with the evidence clamped - BayesNet.sample(init=event), bayes_net.py:715
+    for (int v = 0; v < A.n_vars; ++v) {
+        const GibbsVar V = A.vars[v];
+        int val = V.ev_code;
+        if (!V.is_evidence) {
+            int off = V.table_off;
+            for (int k = 0; k + 1 < V.scope_len; ++k)
+                off += (int)st[A.scope_var[V.scope_begin + k] * 64 + lane] * A.scope_stride[V.scope_begin + k];
+            double total = 0;
+            for (int x = 0; x < V.card; ++x) total += A.pool[off + x];
+            const double u = philox_uniform((uint64_t)v, 1u, k0, k1) * total;
+            double acc = 0;
+            val = V.card - 1;
+            for (int x = 0; x < V.card; ++x) {
+                acc += A.pool[off + x];
+                if (u < acc) { val = x; break; }
+            }
+        }
+        st[v * 64 + lane] = (uint8_t)val;
+    }
+    __syncthreads();
+
+    int cyc = 0;
+    for (int64_t it = 0; it < A.n_iterations; ++it) {
+        const int v = A.cycle[cyc];
+        cyc = cyc + 1 == A.n_cycle ? 0 : cyc + 1;
+        const GibbsVar V = A.vars[v];
+        double total = 0;
+        for (int x = 0; x < V.card; ++x) total += gibbs_weight(A, V, v, x, st, lane);
+        if (total > 0) {
+            const double u = philox_uniform((uint64_t)it, 0u, k0, k1) * total;
+            double acc = 0;
+            int val = -1, last = 0;
+            for (int x = 0; x < V.card; ++x) {
+                const double w = gibbs_weight(A, V, v, x, st, lane);
+                if (w > 0) last = x;
+                acc += w;
+                if (val < 0 && u < acc) val = x;
+            }
+            st[v * 64 + lane] = (uint8_t)(val < 0 ? last : val);
+        }
+        // record the joint query state (bayes_net.py:732-733: every iteration, no burn-in)
+        if (active) {
+            int cell = 0;
+            for (int q = 0; q < A.n_q; ++q) cell += (int)st[A.qvars[q] * 64 + lane] * A.qstride[q];
+            atomicAdd(&hist[cell], 1u);
+        }
+        if ((it & 0xffffff) == 0xffffff) {  // flush before a 32-bit LDS counter can overflow
+            __syncthreads();
+            for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x) {
+                if (hist[i]) atomicAdd(&A.counts[i], (unsigned long long)hist[i]);
+                hist[i] = 0;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x)
+        if (hist[i]) atomicAdd(&A.counts[i], (unsigned long long)hist[i]);
+}
+
+// host driver; returns MIBN_* code
+inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t stream, int32_t n_q, const int32_t *q_vars,
+                     int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle_in, int64_t n_chains,
+                     int64_t n_iterations, uint64_t seed, int64_t *counts, std::string &err, double &kernel_ms) {
+    const int n = net.n_vars;
+    std::vector<GibbsVar> vars(n);
+    std::vector<int32_t> scope_var, scope_stride, children, cycle;
+    std::vector<std::vector<int32_t>> ch(n);
+    for (int v = 0; v < n; ++v)
+        for (size_t k = 0; k + 1 < net.scope[v].size(); ++k) ch[net.scope[v][k]].push_back(v);
+    for (int v = 0; v < n; ++v) {
+        if (net.card[v] > 255) { err = "gibbs: cardinality above 255"; return MIBN_E_LIMIT; }
+        GibbsVar g{};
+        g.card = net.card[v];
+        g.table_off = (int32_t)net.pool_off[v];
+        g.scope_begin = (int32_t)scope_var.size();
+        g.scope_len = (int32_t)net.scope[v].size();
+        for (size_t k = 0; k < net.scope[v].size(); ++k) {
+            scope_var.push_back(net.scope[v][k]);
+            scope_stride.push_back((int32_t)net.cstride[v][k]);
+        }
+        g.child_begin = (int32_t)children.size();
+        g.child_len = (int32_t)ch[v].size();
+        for (int c : ch[v]) children.push_back(c);
+        vars[v] = g;
+    }
+    for (int i = 0; i < n_e; ++i) {
+        if (e_codes[i] < 0 || e_codes[i] >= net.card[e_vars[i]]) { err = "gibbs: evidence label outside the domain"; return MIBN_E_ARG; }
+        vars[e_vars[i]].is_evidence = 1;
+        vars[e_vars[i]].ev_code = e_codes[i];
+    }
+    int n_free = 0;
+    for (int v = 0; v < n; ++v) n_free += !vars[v].is_evidence;
+    if (cycle_in) {  // caller's update order (the reference cycles through sorted(nodes - event), bayes_net.py:697,718)
+        std::vector<char> seen(n, 0);
+        for (int i = 0; i < n_free; ++i) {
+            const int v = cycle_in[i];
+            if (v < 0 || v >= n || vars[v].is_evidence || seen[v]) { err = "gibbs: cycle must list every non-evidence variable once"; return MIBN_E_ARG; }
+            seen[v] = 1;
+            cycle.push_back(v);
+        }
+    } else {
+        for (int v = 0; v < n; ++v)
+            if (!vars[v].is_evidence) cycle.push_back(v);
+    }
+    if (cycle.empty()) { err = "gibbs: every variable is evidence"; return MIBN_E_ARG; }
+    std::vector<int32_t> qstride(n_q);
+    int64_t cells = 1;
+    for (int i = n_q - 1; i >= 0; --i) { qstride[i] = (int32_t)cells; cells *= net.card[q_vars[i]]; }
+    const size_t lds = ((size_t)n * 64 + 15) / 16 * 16 + (size_t)cells * 4;
+    if (lds > 150 * 1024) { err = "gibbs: network/query too large for the LDS-resident chain state"; return MIBN_E_LIMIT; }
+
+    GibbsVar *d_vars = nullptr;
+    int32_t *d_i32 = nullptr;
+    unsigned long long *d_counts = nullptr;
+    std::vector<int32_t> pack;
+    auto put = [&](const std::vector<int32_t> &a) { size_t o = pack.size(); pack.insert(pack.end(), a.begin(), a.end()); return o; };
+    const size_t o_sv = put(scope_var), o_ss = put(scope_stride), o_ch = put(children), o_cy = put(cycle);
+    const size_t o_q = put(std::vector<int32_t>(q_vars, q_vars + n_q)), o_qs = put(qstride);
+    auto fail = [&](hipError_t e) { err = std::string("gibbs: ") + hipGetErrorString(e); hipFree(d_vars); hipFree(d_i32); hipFree(d_counts); return MIBN_E_HIP; };
+    hipError_t e;
+    if ((e = hipMalloc(&d_vars, sizeof(GibbsVar) * n)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_i32, 4 * std::max<size_t>(1, pack.size()))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_counts, 8 * (size_t)cells)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(d_vars, vars.data(), sizeof(GibbsVar) * n, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(d_i32, pack.data(), 4 * pack.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemsetAsync(d_counts, 0, 8 * (size_t)cells, stream)) != hipSuccess) return fail(e);
+    GibbsArgs A;
+    A.pool = d_pool;
+    A.vars = d_vars;
+    A.scope_var = d_i32 + o_sv;
+    A.scope_stride = d_i32 + o_ss;
+    A.children = d_i32 + o_ch;
+    A.cycle = d_i32 + o_cy;
+    A.qvars = d_i32 + o_q;
+    A.qstride = d_i32 + o_qs;
+    A.counts = d_counts;
+    A.n_vars = n;
+    A.n_cycle = (int32_t)cycle.size();
+    A.n_q = n_q;
+    A.hist_cells = (int32_t)cells;
+    A.n_chains = n_chains;
+    A.n_iterations = n_iterations;
+    A.seed = seed;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const unsigned blocks = (unsigned)((n_chains + 63) / 64);
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void *)gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEventRecord(e0, stream);
+    hipLaunchKernelGGL(gibbs_kernel, dim3(blocks), dim3(64 * kGibbsWaves), lds, stream, A);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+    hipEventRecord(e1, stream);
+    std::vector<unsigned long long> hc((size_t)cells);
+    if ((e = hipMemcpyAsync(hc.data(), d_counts, 8 * (size_t)cells, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    kernel_ms = ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    for (int64_t i = 0; i < cells; ++i) counts[i] = (int64_t)hc[(size_t)i];
+    hipFree(d_vars);
+    hipFree(d_i32);
+    hipFree(d_counts);
+    return MIBN_OK;
+}
+
+}  // namespace mibn

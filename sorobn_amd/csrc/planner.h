@@ -1,0 +1,96 @@
+// Host-side planner for the variable-elimination hot path (pure C++17, no HIP dependency).
+//
+// Replaces the bookkeeping half of BayesNet._variable_elimination (sorobn/bayes_net.py:763-789):
+// relevance pruning to ancestors (763-765, `ancestors` 373-378), the hidden set (766), evidence
+// slicing of the CPTs (768-776) and the elimination loop's factor selection (779-786) - but instead
+// of executing pandas joins it emits a *step program* for the HIP interpreter (ve_kernel.hip):
+// every step is one fused  psi[out] = sum_x prod_j phi_j[idx_j(out, x)]  over dense strided tables.
+//
+// Where the reference's elimination order is the iteration order of a Python set (766, 779), the
+// planner evaluates several candidate orders with the SURVEY section 8(d) byte model and executes
+// the cheapest.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mibn {
+
+constexpr int kMaxVars = 1024;            // bitset capacity
+constexpr int kWords = kMaxVars / 64;
+constexpr int kMaxIn = 6;                 // input factors per step (larger products are pre-multiplied)
+constexpr int kMaxAxes = 32;              // output axes per step after merging
+constexpr int kLoTarget = 256;            // lane-varying block: first axes whose product reaches this
+constexpr int kLoMax = 1024;              // ... but never more than this many cells (4 per lane)
+constexpr uint64_t kConstFlag = 1ull << 63;  // in_off bit: table lives in the constants pool
+
+struct Bits {
+    std::array<uint64_t, kWords> w{};
+    int nw = kWords;
+    void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
+    void clr(int i) { w[i >> 6] &= ~(1ull << (i & 63)); }
+    bool test(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
+    bool any() const { for (int k = 0; k < nw; ++k) if (w[k]) return true; return false; }
+    void or_(const Bits &o) { for (int k = 0; k < nw; ++k) w[k] |= o.w[k]; }
+    void andnot(const Bits &o) { for (int k = 0; k < nw; ++k) w[k] &= ~o.w[k]; }
+    bool intersects(const Bits &o) const { for (int k = 0; k < nw; ++k) if (w[k] & o.w[k]) return true; return false; }
+    int count() const { int c = 0; for (int k = 0; k < nw; ++k) c += __builtin_popcountll(w[k]); return c; }
+    template <class F> void for_each(F f) const {
+        for (int k = 0; k < nw; ++k) { uint64_t m = w[k]; while (m) { int b = __builtin_ctzll(m); f(k * 64 + b); m &= m - 1; } }
+    }
+};
+
+struct Network {
+    int n_vars = 0;
+    std::vector<int32_t> card;
+    std::vector<double> log2card;
+    std::vector<std::vector<int32_t>> scope;     // [*parents, v]
+    std::vector<std::vector<int64_t>> cstride;   // dense C-order stride of each scope entry
+    std::vector<int64_t> pool_off;               // offset (doubles) of table v in the constants pool
+    std::vector<int64_t> cells;
+    std::vector<double> pool;
+    std::vector<Bits> anc;                       // ancestors (bayes_net.py:373-378), memoised
+    std::vector<int32_t> depth;                  // longest path from a root
+    std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier)
+    int nw = 1;
+
+    // returns "" or an error message
+    std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
+                    const int64_t *value_off, const double *values);
+};
+
+struct Request {
+    int32_t nq = 0, ne = 0;
+    const int32_t *qvars = nullptr;
+    const int32_t *evars = nullptr;
+    const int32_t *ecodes = nullptr;  // may be null for plan-only statistics
+    int64_t out_off = 0;              // offset (doubles) into the batch result buffer
+};
+
+struct PlanStats {
+    double alg_bytes = 0, alg_flops = 0, n_steps = 0, max_step_cells = 0;
+    int64_t arena_cells = 0;  // scratch cells this request needs in its arena slot
+    int64_t out_cells = 0;
+};
+
+// Step program encoding (uint32 words), consumed by ve_kernel.hip and oracle/plan_sim.cpp:
+//   program := n_steps, step*
+//   step    := w0 = n_in | n_axes<<8 | nlo<<16 | flags<<24
+//              w1 = cx        (cardinality of the eliminated axis; 1 = product only)
+//              w2 = lo_cells  w3 = hi_cells
+//              w4,w5 = out_off (u64, doubles; arena-relative, or result-buffer-relative if FINAL)
+//              w6 = step_words (total words of this step)   w7 = reserved
+//              per input j<n_in:  in_off lo, in_off hi (bit 63 = constants pool), xs_j
+//              card[a]            a < n_axes
+//              stride[j][a]       j < n_in, a < n_axes   (int32, in doubles)
+constexpr uint32_t kFlagFinal = 1;
+constexpr int kHdrWords = 8;
+
+// Plan one request; appends the program to `prog`.  Returns "" or an error message.
+std::string plan_request(const Network &net, const Request &rq, std::vector<uint32_t> &prog, PlanStats &st);
+
+// Validate a request (unknown ids, duplicates, overlap) - bayes_net.py:840-845 and the KeyError of 770.
+std::string validate_request(const Network &net, const Request &rq);
+
+}  // namespace mibn

@@ -1,0 +1,86 @@
+"""TEST DOUBLE: runs the product planner's step programs on the CPU (oracle/libplan_sim.so).
+
+Lets `pytest -m "not gpu"` exercise the real host logic - flatten.py, Backend.encode /
+posterior_series, BayesNet.query / impute post-processing and the C++ planner - in the GPU-less
+build container.  Never imported by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from sorobn_amd.bayes_net import Backend
+from sorobn_amd.flatten import flatten
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libplan_sim.so"])
+        L = C.CDLL(os.path.join(ROOT, "oracle", "libplan_sim.so"))
+        i32p, i64p, f64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        L.plan_sim_query.argtypes = [C.c_int32, i32p, i64p, i32p, i64p, f64p, C.c_int32, i32p,
+                                     C.c_int32, i32p, C.c_int32, i32p, i32p, f64p, f64p]
+        L.plan_sim_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+class SimEngine:
+    """Same surface as sorobn_amd._capi.Engine for the exact path, executed by plan_sim."""
+
+    def __init__(self, flat):
+        self.f = flat
+        self.card = flat.card
+        self.last_stats = None
+        self.hints = np.stack(flat.hints).astype(np.int32) if flat.hints else np.zeros((0, len(flat.card)), np.int32)
+
+    def _one(self, q, ev, codes):
+        f = self.f
+        L = lib()
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        q = np.ascontiguousarray(q, np.int32)
+        ev_ = np.ascontiguousarray(ev if len(ev) else [0], np.int32)
+        co_ = np.ascontiguousarray(codes if len(codes) else [0], np.int32)
+        cells = int(np.prod(f.card[q].astype(np.int64)))
+        out = np.zeros(cells, np.float64)
+        stats = np.zeros(5, np.float64)
+        hints = np.ascontiguousarray(self.hints.reshape(-1) if self.hints.size else [0], np.int32)
+        rc = L.plan_sim_query(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64),
+                              p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
+                              p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
+                              len(q), p(q, C.c_int32), len(ev), p(ev_, C.c_int32),
+                              p(co_, C.c_int32), p(out, C.c_double), p(stats, C.c_double))
+        if rc != 0:
+            raise RuntimeError(f"plan_sim_query rc={rc}: {L.plan_sim_error().decode()}")
+        self.last_stats = stats
+        return out
+
+    def query_fixed(self, qvars, evars, ecodes):
+        return np.stack([self._one(q, e, c) for q, e, c in zip(qvars, evars, ecodes)])
+
+    def query_batch(self, q_off, q_vars, e_off, e_vars, e_codes, out_off=None):
+        outs = [self._one(q_vars[a:b], e_vars[c:d], e_codes[c:d])
+                for a, b, c, d in zip(q_off[:-1], q_off[1:], e_off[:-1], e_off[1:])]
+        off = np.concatenate([[0], np.cumsum([len(o) for o in outs])]).astype(np.int64)
+        return (np.concatenate(outs) if outs else np.zeros(0)), off
+
+
+def sim_backend(bn):
+    """A Backend whose engine is the CPU plan simulator (bypasses Backend.__init__)."""
+    b = Backend.__new__(Backend)
+    b.flat = flatten(bn)
+    b.fingerprint = Backend.fingerprint_of(bn)
+    b.engine = SimEngine(b.flat)
+    b._anc = {}
+    return b
+
+
+def attach(bn):
+    """Make a sorobn_amd.BayesNet answer through the simulator (tests only)."""
+    bn._backend = sim_backend(bn)
+    return bn

@@ -1,0 +1,103 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the C-ABI
+(libmibn.so via sorobn_amd._capi); the oracle / golden vectors are only the checker."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import golden_util as gu
+import netspec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import sorobn_amd
+    from sorobn_amd import _capi
+    assert _capi.device_count() > 0, "no HIP device visible"
+    return sorobn_amd
+
+
+def _check_requests(bn, requests, ctx):
+    # one batched launch for the whole network, then compare request by request
+    answers = bn.query_many([(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in requests])
+    worst = 0.0
+    for r, ans in zip(requests, answers):
+        name, inames, rows, vals, multi = gu.expected(r)
+        c = f"{ctx} {r['query']} {r['event']}"
+        assert ans.name == name, c
+        assert list(ans.index.names) == inames, c
+        assert isinstance(ans.index, pd.MultiIndex) == multi, c
+        assert ans.dtype == np.float64
+        gu.assert_rows_equal(ans.index.tolist(), rows, ctx=c)
+        if len(vals):
+            worst = max(worst, float(np.max(np.abs(ans.to_numpy() - vals))))
+    assert worst <= gu.TOL, (ctx, worst)
+    return worst
+
+
+@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
+def test_golden_networks(amd, fname):
+    for net in gu.load(fname):
+        bn = netspec.build(net["spec"], amd.BayesNet)
+        _check_requests(bn, net["requests"], net["spec"]["name"])
+
+
+def test_golden_small_grids(amd):
+    for entry in gu.load("grids_small.json"):
+        spec = gu.grid_spec_from_recipe(entry)
+        bn = netspec.build(spec, amd.BayesNet)
+        _check_requests(bn, entry["requests"], spec["name"])
+
+
+def test_golden_grid10x10(amd):
+    path = os.path.join(gu.GOLDEN, "grid10x10.json")
+    if not os.path.exists(path):
+        pytest.skip("grid10x10.json not generated")
+    entry = gu.load("grid10x10.json")
+    spec = gu.grid_spec_from_recipe(entry)
+    bn = netspec.build(spec, amd.BayesNet)
+    _check_requests(bn, entry["requests"], spec["name"])
+
+
+def test_single_query_api_alarm(amd):
+    """README.md:225-229 (config C1): 0.715828 / 0.284172."""
+    spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "alarm")["spec"]
+    bn = netspec.build(spec, amd.BayesNet)
+    ans = bn.query("Burglary", event={"Mary calls": True, "John calls": True})
+    expect = pd.Series([0.7158281646356071, 0.28417183536439294], name="P(Burglary)",
+                       index=pd.Index([False, True], name="Burglary"))
+    pd.testing.assert_series_equal(ans, expect, rtol=0, atol=1e-12)
+
+
+def test_c3_stream_vs_oracle(amd):
+    """First requests of the BASELINE C3 stream on the 10x10 grid, HIP vs the C oracle (the oracle
+    is pinned to the reference by tests/test_oracle.py).  Cheap requests only: the sparse CPU oracle
+    needs seconds to minutes for the wide ones."""
+    from oracle.oracle import OracleNet
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 2048, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    post = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert post.shape == (2048, 4)
+    assert np.allclose(post.sum(1), 1.0, atol=1e-12)
+    on = OracleNet(spec)
+    oid = np.array([on.id[f"{i:03d}"] for i in range(100)], np.int32)
+    checked, worst = 0, 0.0
+    for i in range(2048):
+        cost = be.engine.plan_stats([to_var[q[i]]], to_var[ev[i]])["alg_bytes"]
+        if cost > 3e6:
+            continue
+        codes, vals = on.query_codes([int(oid[q[i]])], oid[ev[i]].tolist(), ec[i].tolist())
+        dense = np.zeros(4)
+        dense[codes[:, 0]] = vals
+        worst = max(worst, float(np.max(np.abs(dense - post[i]))))
+        checked += 1
+        if checked >= 200:
+            break
+    assert checked >= 50
+    assert worst <= gu.TOL, worst
