@@ -1,0 +1,141 @@
+"""The oracle (oracle/ve_oracle.c) is pinned to the reference: every golden vector generated from the
+unmodified reference (tests/golden/make_golden.py) and the factor-algebra doctest vectors of
+sorobn/bayes_net.py:62-97,114-229 must be reproduced - index exactly, values within 1e-9."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import oracle as orc
+
+
+def _raw_mul(card, L, R):
+    lib = orc.lib()
+    (lv, lc, lx), (rv, rc, rx) = L, R
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    card, lv, rv = i32(card), i32(lv), i32(rv)
+    lc, rc = i32(lc).reshape(-1), i32(rc).reshape(-1)
+    lx, rx = np.ascontiguousarray(lx, np.float64), np.ascontiguousarray(rx, np.float64)
+    cap = 4096
+    onv = C.c_int32()
+    ovars = np.zeros(16, np.int32)
+    ocodes = np.zeros(cap * 16, np.int32)
+    ovals = np.zeros(cap)
+    n = lib.ve_pointwise_mul_two(p(card, C.c_int32), len(lv), p(lv, C.c_int32), len(lx), p(lc, C.c_int32),
+                                 p(lx, C.c_double), len(rv), p(rv, C.c_int32), len(rx), p(rc, C.c_int32),
+                                 p(rx, C.c_double), cap, C.byref(onv), p(ovars, C.c_int32),
+                                 p(ocodes, C.c_int32), p(ovals, C.c_double))
+    assert n >= 0
+    nv = onv.value
+    return ovars[:nv].tolist(), ocodes[:n * nv].reshape(n, nv).tolist(), ovals[:n].tolist()
+
+
+def _raw_sum_out(card, F, x):
+    lib = orc.lib()
+    fv, fc, fx = F
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    card, fv, fc = i32(card), i32(fv), i32(fc).reshape(-1)
+    fx = np.ascontiguousarray(fx, np.float64)
+    cap = 4096
+    onv = C.c_int32()
+    ovars = np.zeros(16, np.int32)
+    ocodes = np.zeros(cap * 16, np.int32)
+    ovals = np.zeros(cap)
+    n = lib.ve_sum_out(p(card, C.c_int32), len(fv), p(fv, C.c_int32), len(fx), p(fc, C.c_int32),
+                       p(fx, C.c_double), x, cap, C.byref(onv), p(ovars, C.c_int32), p(ocodes, C.c_int32),
+                       p(ovals, C.c_double))
+    assert n >= 0
+    nv = onv.value
+    return ovars[:nv].tolist(), ocodes[:n * nv].reshape(n, nv).tolist(), ovals[:n].tolist()
+
+
+# AIMA fig. 14.10 tables used by the reference's doctests; label codes: 'F' = 0, 'T' = 1 (sorted)
+T, F = 1, 0
+A_ROWS = ([[T, T], [T, F], [F, T], [F, F]], [.3, .7, .9, .1])
+B_ROWS = ([[T, T], [T, F], [F, T], [F, F]], [.2, .8, .6, .4])
+
+
+def test_pointwise_mul_two_shared_level():
+    """bayes_net.py:114-140: a[A,B] * b[B,C]."""
+    vars_, codes, vals = _raw_mul([2, 2, 2], ([0, 1], *A_ROWS), ([1, 2], *B_ROWS))
+    assert vars_ == [0, 1, 2]
+    got = {tuple(c): v for c, v in zip(codes, vals)}
+    expect = {(T, T, T): .06, (T, T, F): .24, (T, F, T): .42, (T, F, F): .28,
+              (F, T, T): .18, (F, T, F): .72, (F, F, T): .06, (F, F, F): .04}
+    assert got.keys() == expect.keys()
+    for k in expect:
+        assert abs(got[k] - expect[k]) < 1e-15
+
+
+def test_pointwise_mul_two_cartesian():
+    """bayes_net.py:145-179: disjoint scopes -> cartesian product, 16 rows, left-major order."""
+    vars_, codes, vals = _raw_mul([2, 2, 2, 2], ([0, 1], *A_ROWS), ([2, 3], *B_ROWS))
+    assert vars_ == [0, 1, 2, 3] and len(vals) == 16
+    assert codes[0] == [T, T, T, T] and abs(vals[0] - .06) < 1e-15
+    assert codes[5] == [T, F, T, F] and abs(vals[5] - .56) < 1e-15
+    assert codes[15] == [F, F, F, F] and abs(vals[15] - .04) < 1e-15
+
+
+def test_pointwise_mul_two_one_dimensional():
+    """bayes_net.py:183-229."""
+    a = ([[T], [F]], [.3, .7])
+    b = ([[T], [F]], [.2, .8])
+    vars_, codes, vals = _raw_mul([2, 2], ([0], *a), ([1], *b))
+    assert dict(zip(map(tuple, codes), vals)) == pytest.approx({(T, T): .06, (T, F): .24, (F, T): .14, (F, F): .56})
+    vars_, codes, vals = _raw_mul([2, 2, 2], ([0], *a), ([1, 2], *B_ROWS))
+    assert vars_ == [0, 1, 2]
+    assert dict(zip(map(tuple, codes), vals)) == pytest.approx(
+        {(T, T, T): .06, (T, T, F): .24, (T, F, T): .18, (T, F, F): .12,
+         (F, T, T): .14, (F, T, F): .56, (F, F, T): .42, (F, F, F): .28})
+
+
+def test_sum_out():
+    """bayes_net.py:62-97: (a*b).sum_out('B') -> sorted by (A, C)."""
+    vars_, codes, vals = _raw_mul([2, 2, 2], ([0, 1], *A_ROWS), ([1, 2], *B_ROWS))
+    v2, c2, x2 = _raw_sum_out([2, 2, 2], (vars_, codes, vals), 1)
+    assert v2 == [0, 2]
+    assert c2 == [[F, F], [F, T], [T, F], [T, T]]
+    assert x2 == pytest.approx([.76, .24, .52, .48], abs=1e-15)
+
+
+def _check_net(spec, requests, max_ref_seconds=None):
+    on = orc.OracleNet(spec)
+    worst, n = 0.0, 0
+    for req in requests:
+        if max_ref_seconds is not None and req.get("ref_seconds", 0) > max_ref_seconds:
+            continue
+        name, inames, rows, vals, multi = gu.expected(req)
+        qs, labels, got = on.query(req["query"], [tuple(e) for e in req["event"]])
+        ctx = f"{spec['name']} {req['query']} {req['event']}"
+        assert qs == inames, ctx
+        gu.assert_rows_equal(labels, rows, ctx=ctx)
+        if len(vals):
+            worst = max(worst, float(np.max(np.abs(got - vals))))
+        n += 1
+    assert worst <= gu.TOL, (spec["name"], worst)
+    return n
+
+
+@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
+def test_oracle_reproduces_reference_networks(fname):
+    total = sum(_check_net(net["spec"], net["requests"]) for net in gu.load(fname))
+    assert total > 500
+
+
+def test_oracle_reproduces_reference_small_grids():
+    for entry in gu.load("grids_small.json"):
+        _check_net(gu.grid_spec_from_recipe(entry), entry["requests"])
+
+
+def test_oracle_reproduces_reference_grid10x10():
+    path = os.path.join(gu.GOLDEN, "grid10x10.json")
+    if not os.path.exists(path):
+        pytest.skip("grid10x10.json not generated")
+    entry = gu.load("grid10x10.json")
+    # the sparse CPU oracle is as slow as the reference on wide requests: keep the suite in minutes
+    n = _check_net(gu.grid_spec_from_recipe(entry), entry["requests"], max_ref_seconds=1.0)
+    assert n >= 10
