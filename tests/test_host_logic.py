@@ -155,6 +155,18 @@ def test_planner_programs_reproduce_reference_grids():
         _check_requests(bn, entry["requests"], spec["name"])
 
 
+def test_planner_programs_reproduce_reference_grid10x10():
+    """The BASELINE C3 network, incl. the reference's 403 s worst case P(099 | 000=0) (SURVEY.md
+    Appendix A: 0.28215567090257165, ...)."""
+    entry = gu.load("grid10x10.json")
+    spec = gu.grid_spec_from_recipe(entry)
+    bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
+    _check_requests(bn, entry["requests"], spec["name"])
+    worst = next(r for r in entry["requests"] if r["query"] == ["099"] and r["event"] == [["000", 0]])
+    assert gu.expected(worst)[3].tolist() == [0.28215567090257165, 0.26459023658731734, 0.2448596401736336,
+                                              0.20839445233647746]
+
+
 def test_query_many_matches_query():
     net = next(n for n in _nets("examples.json") if n["spec"]["name"] == "grades")
     bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet))
