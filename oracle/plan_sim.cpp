@@ -20,6 +20,8 @@
 using namespace mibn;
 
 static std::string g_err;
+static int g_small_cells = 1024;
+extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
 
@@ -30,6 +32,7 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     Network net;
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
+    net.small_cells = g_small_cells;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
     Request rq;
@@ -51,41 +54,107 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     int n_steps = (int)*p++;
     for (int s = 0; s < n_steps; ++s) {
         const uint32_t w0 = p[0];
-        const int n_in = w0 & 0xff, na = (w0 >> 8) & 0xff;
-        const bool fin = (w0 >> 24) & 1;
-        const int cx = (int)p[1];
-        const int64_t cells = (int64_t)p[2] * (int64_t)p[3];
+        const uint32_t kind = w0 & 0xff;
+        const int n_in = (w0 >> 8) & 0xff, na = (w0 >> 16) & 0xff;
+        const int cx = (int)(p[1] & 0xffff);
+        const bool fin = (p[1] >> 16) & 1;
+        const int64_t iters = (int64_t)p[2] * (int64_t)p[3];
         const uint64_t out_off = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
         const int words = (int)p[6];
         double *outp = fin ? out + out_off : arena.data() + out_off;
-        if (!fin && (int64_t)out_off + cells > st.arena_cells) { g_err = "step writes outside its arena"; return -7; }
-        const double *inp[kMaxIn];
-        int xs[kMaxIn];
-        for (int j = 0; j < n_in; ++j) {
-            const uint64_t o = (uint64_t)p[kHdrWords + 3 * j] | ((uint64_t)p[kHdrWords + 3 * j + 1] << 32);
-            inp[j] = (o & kConstFlag) ? net.pool.data() + (o & ~kConstFlag) : arena.data() + o;
-            xs[j] = (int)p[kHdrWords + 3 * j + 2];
-        }
-        const uint32_t *cd = p + kHdrWords + 3 * n_in;
-        const int32_t *strd = (const int32_t *)(cd + na);
-        std::vector<double> tmp((size_t)cells);
-        for (int64_t o = 0; o < cells; ++o) {
-            int64_t r = o;
-            int64_t off[kMaxIn] = {0};
-            for (int a = 0; a < na; ++a) {
-                const int64_t d = r % cd[a];
-                r /= cd[a];
-                for (int j = 0; j < n_in; ++j) off[j] += d * strd[j * na + a];
+        auto table = [&](uint64_t o) { return (o & kConstFlag) ? net.pool.data() + (o & ~kConstFlag) : arena.data() + o; };
+        int64_t cells = iters;
+        if (kind == kKindGeneric) {
+            if (!fin && (int64_t)out_off + cells > st.arena_cells) { g_err = "step writes outside its arena"; return -7; }
+            const double *inp[kMaxIn];
+            int xs[kMaxIn];
+            for (int j = 0; j < n_in; ++j) {
+                inp[j] = table((uint64_t)p[kHdrWords + 3 * j] | ((uint64_t)p[kHdrWords + 3 * j + 1] << 32));
+                xs[j] = (int)p[kHdrWords + 3 * j + 2];
             }
-            double acc = 0.0;
-            for (int x = 0; x < cx; ++x) {
+            const uint32_t *cd = p + kHdrWords + 3 * n_in;
+            const int32_t *strd = (const int32_t *)(cd + na);
+            std::vector<double> tmp((size_t)cells);
+            for (int64_t o = 0; o < cells; ++o) {
+                int64_t r = o;
+                int64_t off[kMaxIn] = {0};
+                for (int a = 0; a < na; ++a) {
+                    const int64_t d = r % cd[a];
+                    r /= cd[a];
+                    for (int j = 0; j < n_in; ++j) off[j] += d * strd[j * na + a];
+                }
+                double acc = 0.0;
+                for (int x = 0; x < cx; ++x) {
+                    double v = 1.0;
+                    for (int j = 0; j < n_in; ++j) v *= inp[j][off[j] + (int64_t)x * xs[j]];
+                    acc += v;
+                }
+                tmp[(size_t)o] = acc;
+            }
+            std::memcpy(outp, tmp.data(), sizeof(double) * (size_t)cells);
+        } else {  // FIBER
+            const int nb = p[7] & 0xf, ns = (p[7] >> 4) & 0xf, nN = (p[7] >> 8) & 0xf, nctrl = (p[7] >> 12) & 0xf;
+            const int NC = (int)(p[7] >> 16);
+            const int T = (int)p[8];
+            const int nT = nN + nctrl;
+            const uint32_t *q = p + kHdrWords;
+            const double *big[2];
+            int bxs[2];
+            for (int b = 0; b < nb; ++b) { big[b] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32)); bxs[b] = (int)q[2]; q += 3; }
+            const double *sm[kMaxSmall];
+            int sxs[kMaxSmall];
+            const int32_t *sts[kMaxSmall];
+            for (int j = 0; j < ns; ++j) {
+                sm[j] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32));
+                sxs[j] = (int)q[2];
+                sts[j] = (const int32_t *)(q + 3);
+                q += 3 + nT;
+            }
+            const uint32_t *tcard = q; q += nT;
+            const uint32_t *nout = q; q += NC;
+            const uint32_t *rax = q; q += 3 * na;   // card, ostride, tstride per R axis
+            const int32_t *bst = (const int32_t *)q;  // [b][a]
+            std::vector<double> Tt((size_t)T);
+            for (int t = 0; t < T; ++t) {
+                int r = t;
+                const int n = r % NC; r /= NC;
+                const int x = r % cx; r /= cx;
+                int64_t off[kMaxSmall] = {0};
+                int rn = n;
+                for (int k = 0; k < nN; ++k) { int d = rn % tcard[k]; rn /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
+                for (int k = nN; k < nT; ++k) { int d = r % tcard[k]; r /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
                 double v = 1.0;
-                for (int j = 0; j < n_in; ++j) v *= inp[j][off[j] + (int64_t)x * xs[j]];
-                acc += v;
+                for (int j = 0; j < ns; ++j) v *= sm[j][off[j] + (int64_t)x * sxs[j]];
+                Tt[(size_t)t] = v;
             }
-            tmp[(size_t)o] = acc;
+            cells = iters * NC;
+            if ((int64_t)out_off + cells > st.arena_cells) { g_err = "fiber step writes outside its arena"; return -7; }
+            std::vector<double> tmp((size_t)cells, -7e300);
+            for (int64_t rr = 0; rr < iters; ++rr) {
+                int64_t r = rr, oo = 0, to = 0, bo[2] = {0, 0};
+                for (int a = 0; a < na; ++a) {
+                    const int64_t d = r % rax[3 * a];
+                    r /= rax[3 * a];
+                    oo += d * rax[3 * a + 1];
+                    to += d * rax[3 * a + 2];
+                    for (int b = 0; b < nb; ++b) bo[b] += d * bst[b * na + a];
+                }
+                for (int n = 0; n < NC; ++n) {
+                    double acc = 0.0;
+                    for (int x = 0; x < cx; ++x) {
+                        double f = 1.0;
+                        for (int b = 0; b < nb; ++b) f *= big[b][bo[b] + (int64_t)x * bxs[b]];
+                        acc += f * Tt[(size_t)(to + (int64_t)x * NC + n)];
+                    }
+                    const int64_t o = oo + nout[n];
+                    if (o < 0 || o >= cells) { g_err = "fiber output offset out of range"; return -8; }
+                    tmp[(size_t)o] = acc;
+                }
+            }
+            for (int64_t i = 0; i < cells; ++i)
+                if (tmp[(size_t)i] == -7e300) { g_err = "fiber step left an output cell unwritten"; return -9; }
+            std::memcpy(outp, tmp.data(), sizeof(double) * (size_t)cells);
         }
-        std::memcpy(outp, tmp.data(), sizeof(double) * (size_t)cells);
         if (fin) {
             double total = 0;
             for (int64_t i = 0; i < cells; ++i) total += outp[i];
@@ -95,4 +164,26 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
         p += words;
     }
     return 0;
+}
+
+// debugging aid: return the raw step program of one request (words copied into `out`, count returned)
+extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                                    const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
+                                    int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars, const int32_t *ecodes,
+                                    uint32_t *out, int64_t cap) {
+    Network net;
+    g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
+    if (!g_err.empty()) return -1;
+    net.small_cells = g_small_cells;
+    for (int i = 0; i < n_hints; ++i)
+        net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
+    Request rq;
+    rq.nq = nq; rq.qvars = qvars; rq.ne = ne; rq.evars = evars; rq.ecodes = ecodes; rq.out_off = 0;
+    std::vector<uint32_t> prog;
+    PlanStats st;
+    g_err = plan_request(net, rq, prog, st);
+    if (!g_err.empty()) return -6;
+    if ((int64_t)prog.size() > cap) return -2;
+    std::memcpy(out, prog.data(), prog.size() * 4);
+    return (int64_t)prog.size();
 }

@@ -133,6 +133,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "threads") h->threads = (int)value;
     else if (n == "wg_per_cu") h->wg_per_cu = std::max(1, std::min(8, (int)value));
     else if (n == "chunk") h->chunk = std::max<int64_t>(1, (int64_t)value);
+    else if (n == "small_cells") h->net.small_cells = std::max(1, std::min(kMaxT, (int)value));  // test hook: forces FIBER steps on small networks
     else { h->err = "unknown option " + n; return MIBN_E_ARG; }
     return MIBN_OK;
 }

@@ -249,6 +249,162 @@ struct Emitter {
     std::vector<double> key;  // layout key per variable: larger = lives longer = faster axis
     std::string err;
 
+    void header(uint32_t *w, uint32_t kind, int n_in, int ma, int mlo, int cx, bool final_, int64_t lo, int64_t hi,
+                uint64_t out_off, int words) {
+        w[0] = kind | ((uint32_t)n_in << 8) | ((uint32_t)ma << 16) | ((uint32_t)mlo << 24);
+        w[1] = (uint32_t)cx | ((final_ ? kFlagFinal : 0u) << 16);
+        w[2] = (uint32_t)lo;
+        w[3] = (uint32_t)hi;
+        w[4] = (uint32_t)(out_off & 0xffffffffu);
+        w[5] = (uint32_t)(out_off >> 32);
+        w[6] = (uint32_t)words;
+        w[7] = w[8] = w[9] = 0;
+    }
+
+    // GENERIC encoding: iteration space = output cells
+    void emit_generic(const std::vector<PF> &ins, const std::vector<std::vector<int64_t>> &s, const std::vector<int64_t> &xs,
+                      const PF &out, int na, int64_t cells, int cx, bool final_) {
+        const int n_in = (int)ins.size();
+        int nlo = 0;
+        int64_t lo = 1;
+        const int64_t lomax = n_in <= 3 ? kLoMax : kLoTarget;  // kernel: 2 cells per lane up to 3 inputs, else 1
+        while (nlo < na && lo < kLoTarget && lo * net.card[out.vars[nlo]] <= lomax) lo *= net.card[out.vars[nlo++]];
+        // merge adjacent axes that are contiguous in every input (the output is dense by construction)
+        std::vector<uint32_t> mcard;
+        std::vector<std::vector<int64_t>> ms(n_in);
+        int mlo = 0;
+        for (int a = 0; a < na; ++a) {
+            bool merge = !mcard.empty() && a != nlo;
+            if (merge)
+                for (int j = 0; j < n_in && merge; ++j) merge = s[j][a] == ms[j].back() * (int64_t)mcard.back();
+            uint32_t c = (uint32_t)net.card[out.vars[a]];
+            if (merge && (uint64_t)mcard.back() * c < (1u << 30)) {
+                mcard.back() *= c;
+            } else {
+                mcard.push_back(c);
+                for (int j = 0; j < n_in; ++j) ms[j].push_back(s[j][a]);
+                if (a < nlo) ++mlo;
+            }
+        }
+        const int ma = (int)mcard.size();
+        if (ma > kMaxAxes) { err = "a step has more than " + std::to_string(kMaxAxes) + " axes"; return; }
+        const size_t base = prog.size();
+        const int words = kHdrWords + 3 * n_in + ma + n_in * ma;
+        prog.resize(base + words);
+        uint32_t *w = prog.data() + base;
+        header(w, kKindGeneric, n_in, ma, mlo, cx, final_, lo, cells / lo, out.off, words);
+        uint32_t *p = w + kHdrWords;
+        for (int j = 0; j < n_in; ++j) {
+            *p++ = (uint32_t)(ins[j].off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j].off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[j];
+        }
+        for (int a = 0; a < ma; ++a) *p++ = mcard[a];
+        for (int j = 0; j < n_in; ++j)
+            for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)ms[j][a];
+    }
+
+    // FIBER encoding (see planner.h); returns false when the step does not fit the form
+    bool emit_fiber(const std::vector<PF> &ins, const std::vector<std::vector<int64_t>> &s, const std::vector<int64_t> &xs,
+                    const PF &out, int na, int64_t cells, int cx) {
+        std::vector<int> big, small;
+        for (int j = 0; j < (int)ins.size(); ++j) (ins[j].cells > net.small_cells ? big : small).push_back(j);
+        if (big.empty() || big.size() > 2 || (int)small.size() > kMaxSmall || cx > 16) return false;
+        // N axes: no big input depends on them; keep at most kMaxNC combinations (fastest axes first)
+        std::vector<int> naxes, raxes;
+        int64_t NC = 1;
+        for (int a = 0; a < na; ++a) {
+            bool free_ = true;
+            for (int b : big) free_ = free_ && s[b][a] == 0;
+            const int c = net.card[out.vars[a]];
+            if (free_ && NC * c <= kMaxNC) { naxes.push_back(a); NC *= c; }
+            else raxes.push_back(a);
+        }
+        // ctrl axes: R axes a small input depends on
+        std::vector<int> ctrl;
+        int64_t T = NC * cx;
+        for (int a : raxes) {
+            bool dep = false;
+            for (int j : small) dep = dep || s[j][a] != 0;
+            if (dep) { ctrl.push_back(a); T *= net.card[out.vars[a]]; if (T > kMaxT) return false; }
+        }
+        const int nT = (int)naxes.size() + (int)ctrl.size();
+        if (naxes.size() > 15 || ctrl.size() > 15) return false;
+        // R-axis tables (unmerged)
+        const int nr = (int)raxes.size();
+        std::vector<int64_t> rcard(nr), rost(nr), rtst(nr, 0);
+        std::vector<std::vector<int64_t>> rb(big.size(), std::vector<int64_t>(nr));
+        {
+            int64_t tmul = NC * cx;
+            for (int i = 0; i < nr; ++i) {
+                const int a = raxes[i];
+                rcard[i] = net.card[out.vars[a]];
+                rost[i] = out.strides[a];
+                for (size_t b = 0; b < big.size(); ++b) rb[b][i] = s[big[b]][a];
+                if (std::find(ctrl.begin(), ctrl.end(), a) != ctrl.end()) { rtst[i] = tmul; tmul *= rcard[i]; }
+            }
+        }
+        int nlo = 0;
+        int64_t lo = 1;
+        while (nlo < nr && lo < kLoTarget && lo * rcard[nlo] <= kFiberLoMax) lo *= rcard[nlo++];
+        int64_t rcells = 1;
+        for (int i = 0; i < nr; ++i) rcells *= rcard[i];
+        // merge adjacent R axes contiguous in the output, in T and in every big input
+        std::vector<int64_t> mc, mo, mt;
+        std::vector<std::vector<int64_t>> mb(big.size());
+        int mlo = 0;
+        for (int i = 0; i < nr; ++i) {
+            bool merge = !mc.empty() && i != nlo && mo.back() * mc.back() == rost[i] && mt.back() * mc.back() == rtst[i] &&
+                         mc.back() * rcard[i] < (1 << 30);
+            for (size_t b = 0; b < big.size() && merge; ++b) merge = mb[b].back() * mc.back() == rb[b][i];
+            if (merge) {
+                mc.back() *= rcard[i];
+            } else {
+                mc.push_back(rcard[i]);
+                mo.push_back(rost[i]);
+                mt.push_back(rtst[i]);
+                for (size_t b = 0; b < big.size(); ++b) mb[b].push_back(rb[b][i]);
+                if (i < nlo) ++mlo;
+            }
+        }
+        const int ma = (int)mc.size();
+        if (ma > kMaxAxes) return false;
+        const int nb = (int)big.size(), ns = (int)small.size();
+        const int words = kHdrWords + 3 * nb + ns * (3 + nT) + nT + (int)NC + 3 * ma + nb * ma;
+        if (words > kMaxStepWords) return false;
+        const size_t base = prog.size();
+        prog.resize(base + words);
+        uint32_t *w = prog.data() + base;
+        header(w, kKindFiber, nb + ns, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
+        w[7] = (uint32_t)nb | ((uint32_t)ns << 4) | ((uint32_t)naxes.size() << 8) | ((uint32_t)ctrl.size() << 12) | ((uint32_t)NC << 16);
+        w[8] = (uint32_t)T;
+        uint32_t *p = w + kHdrWords;
+        for (int b : big) {
+            *p++ = (uint32_t)(ins[b].off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[b].off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[b];
+        }
+        for (int j : small) {
+            *p++ = (uint32_t)(ins[j].off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j].off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[j];
+            for (int a : naxes) *p++ = (uint32_t)(int32_t)s[j][a];
+            for (int a : ctrl) *p++ = (uint32_t)(int32_t)s[j][a];
+        }
+        for (int a : naxes) *p++ = (uint32_t)net.card[out.vars[a]];
+        for (int a : ctrl) *p++ = (uint32_t)net.card[out.vars[a]];
+        for (int64_t n = 0; n < NC; ++n) {
+            int64_t r = n, off = 0;
+            for (int a : naxes) { off += (r % net.card[out.vars[a]]) * out.strides[a]; r /= net.card[out.vars[a]]; }
+            *p++ = (uint32_t)off;
+        }
+        for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = (uint32_t)mt[a]; }
+        for (int b = 0; b < nb; ++b)
+            for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)mb[b][a];
+        (void)cells;
+        return true;
+    }
+
     // Emit one step: multiply `ins`, sum out x (x < 0: product only).  Returns the new factor.
     PF emit(const std::vector<PF> &ins, int x, bool final_, int64_t final_off) {
         PF out;
@@ -278,31 +434,6 @@ struct Emitter {
                 int a = (int)(std::find(out.vars.begin(), out.vars.end(), v) - out.vars.begin());
                 s[j][a] = ins[j].strides[k];
             }
-        // lane-varying block: leading axes until the product reaches kLoTarget (never above kLoMax)
-        int nlo = 0;
-        int64_t lo = 1;
-        while (nlo < na && lo < kLoTarget && lo * net.card[out.vars[nlo]] <= kLoMax) lo *= net.card[out.vars[nlo++]];
-        // merge adjacent axes that are contiguous in every input (the output is dense by construction)
-        std::vector<uint32_t> mcard;
-        std::vector<std::vector<int64_t>> ms(n_in);
-        int mlo = 0;
-        for (int a = 0; a < na; ++a) {
-            bool merge = !mcard.empty() && a != nlo;
-            if (merge)
-                for (int j = 0; j < n_in && merge; ++j)
-                    merge = s[j][a] == ms[j].back() * (int64_t)mcard.back();
-            uint32_t c = (uint32_t)net.card[out.vars[a]];
-            if (merge && (uint64_t)mcard.back() * c < (1u << 30)) {
-                mcard.back() *= c;
-            } else {
-                mcard.push_back(c);
-                for (int j = 0; j < n_in; ++j) ms[j].push_back(s[j][a]);
-                if (a < nlo) ++mlo;
-            }
-        }
-        int ma = (int)mcard.size();
-        if (ma > kMaxAxes) { err = "a step has more than " + std::to_string(kMaxAxes) + " axes"; return out; }
-        int64_t hi = cells / lo;
         int cx = x >= 0 ? net.card[x] : 1;
         if (final_) {
             out.off = (uint64_t)final_off;
@@ -311,29 +442,11 @@ struct Emitter {
             out.off = (uint64_t)arena.alloc(cells);
             out.alloc = cells;
         }
-        size_t base = prog.size();
-        int words = kHdrWords + 3 * n_in + ma + n_in * ma;
-        prog.resize(base + words);
-        uint32_t *w = prog.data() + base;
-        w[0] = (uint32_t)n_in | ((uint32_t)ma << 8) | ((uint32_t)mlo << 16) | ((final_ ? kFlagFinal : 0u) << 24);
-        w[1] = (uint32_t)cx;
-        w[2] = (uint32_t)lo;
-        w[3] = (uint32_t)hi;
-        w[4] = (uint32_t)(out.off & 0xffffffffu);
-        w[5] = (uint32_t)(out.off >> 32);
-        w[6] = (uint32_t)words;
-        w[7] = 0;
-        uint32_t *p = w + kHdrWords;
         double in_cells = 0;
-        for (int j = 0; j < n_in; ++j) {
-            *p++ = (uint32_t)(ins[j].off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j].off >> 32);
-            *p++ = (uint32_t)(int32_t)xs[j];
-            in_cells += (double)ins[j].cells;
-        }
-        for (int a = 0; a < ma; ++a) *p++ = mcard[a];
-        for (int j = 0; j < n_in; ++j)
-            for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)ms[j][a];
+        for (int j = 0; j < n_in; ++j) in_cells += (double)ins[j].cells;
+        if (!(!final_ && emit_fiber(ins, s, xs, out, na, cells, cx)))
+            emit_generic(ins, s, xs, out, na, cells, cx, final_);
+        if (!err.empty()) return out;
         st.alg_bytes += 8.0 * (in_cells + (double)cells);
         double pc = std::exp2(prod_log2);
         st.alg_flops += n_in * pc;

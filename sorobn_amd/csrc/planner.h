@@ -22,7 +22,7 @@ constexpr int kWords = kMaxVars / 64;
 constexpr int kMaxIn = 6;                 // input factors per step (larger products are pre-multiplied)
 constexpr int kMaxAxes = 32;              // output axes per step after merging
 constexpr int kLoTarget = 256;            // lane-varying block: first axes whose product reaches this
-constexpr int kLoMax = 1024;              // ... but never more than this many cells (4 per lane)
+constexpr int kLoMax = 512;               // ... but never more than this many cells (2 per lane)
 constexpr uint64_t kConstFlag = 1ull << 63;  // in_off bit: table lives in the constants pool
 
 struct Bits {
@@ -54,6 +54,7 @@ struct Network {
     std::vector<int32_t> depth;                  // longest path from a root
     std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier)
     int nw = 1;
+    int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table (kSmallCells)
 
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
@@ -74,18 +75,42 @@ struct PlanStats {
     int64_t out_cells = 0;
 };
 
-// Step program encoding (uint32 words), consumed by ve_kernel.hip and oracle/plan_sim.cpp:
+// Step program encoding (uint32 words), consumed by ve_kernel.hip.h and oracle/plan_sim.cpp:
 //   program := n_steps, step*
-//   step    := w0 = n_in | n_axes<<8 | nlo<<16 | flags<<24
-//              w1 = cx        (cardinality of the eliminated axis; 1 = product only)
-//              w2 = lo_cells  w3 = hi_cells
-//              w4,w5 = out_off (u64, doubles; arena-relative, or result-buffer-relative if FINAL)
-//              w6 = step_words (total words of this step)   w7 = reserved
-//              per input j<n_in:  in_off lo, in_off hi (bit 63 = constants pool), xs_j
-//              card[a]            a < n_axes
-//              stride[j][a]       j < n_in, a < n_axes   (int32, in doubles)
+//   every step starts with a 10-word header
+//      w0 = kind | n_in<<8 | n_axes<<16 | nlo<<24      kind: 0 = GENERIC, 1 = FIBER
+//      w1 = cx | flags<<16      cx = cardinality of the eliminated axis (1 = product only)
+//      w2 = lo_cells   w3 = hi_cells     lane-varying / wave-uniform blocks of the iteration space
+//      w4,w5 = out_off (u64, doubles; arena-relative, or result-buffer-relative if FINAL)
+//      w6 = step_words (total words of this step)
+//      w7 = FIBER: n_big | n_small<<4 | n_N<<8 | n_ctrl<<12 | NC<<16        w8 = FIBER: T_cells   w9 = 0
+//
+//   GENERIC  psi[o] = sum_x prod_j phi_j[off_j(o) + x*xs_j], iteration space = output cells:
+//      per input j<n_in:  in_off lo, in_off hi (bit 63 = constants pool), xs_j
+//      card[a]            a < n_axes          (output axes, fastest first, merged)
+//      stride[j][a]       j < n_in, a < n_axes (int32, doubles)
+//
+//   FIBER    the inputs are split into big tables (<= 2, streamed from HBM) and small ones (CPT
+//      slices, <= Network::small_cells cells each).  Output axes no big input depends on are the N axes
+//      (NC = prod of their cards <= kMaxNC): one lane owns one cell r of the remaining R axes, loads
+//      the cx values of each big input once and produces the whole N-fiber in registers:
+//           out[r, n] = sum_x (prod_b F_b[r, x]) * T[n, x, ctrl(r)]
+//      where T = product of the small inputs, tabulated once per step in LDS over
+//      (n fastest, x, ctrl axes = the R axes a small input depends on).  Iteration space = R cells.
+//      per big input b<n_big:     off lo, off hi, xs_b
+//      per small input s<n_small: off lo, off hi, xs_s, tstride[s][k] k < n_N + n_ctrl
+//      tcard[k]                   k < n_N + n_ctrl     (N axes, then ctrl axes)
+//      nout[n]                    n < NC               (output offset of N-combination n)
+//      card[a], ostride[a], tstride[a]    a < n_axes   (R axes, merged; tstride in T cells)
+//      bstride[b][a]              b < n_big, a < n_axes
 constexpr uint32_t kFlagFinal = 1;
-constexpr int kHdrWords = 8;
+constexpr int kHdrWords = 10;
+constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;
+constexpr int kMaxNC = 16;         // N-fiber length held in registers
+constexpr int kMaxT = 2048;        // T cells (16 KiB of LDS)
+constexpr int kMaxSmall = 4;
+constexpr int kFiberLoMax = 512;    // R cells in the lane-varying block of a FIBER step (2 per lane)
+constexpr int kMaxStepWords = 384;  // LDS copy of one step descriptor
 
 // Plan one request; appends the program to `prog`.  Returns "" or an error message.
 std::string plan_request(const Network &net, const Request &rq, std::vector<uint32_t> &prog, PlanStats &st);

@@ -12,12 +12,22 @@
 // one request only need a workgroup barrier between them (same CU, same L1) - no grid-wide sync, no
 // cross-workgroup visibility protocol.
 //
-// Index math: the planner lays every table out with the longest-living variable fastest, splits the
-// output axes into a lane-varying block (lo, 256..1024 cells: consecutive lanes = consecutive cells
-// of the output and, by construction of the layouts, near-consecutive cells of the big input -> coalesced
-// 512-B wave stores, wide loads) and a wave-uniform block (hi).  Lane offsets are decoded once per
-// step, hi offsets are decoded 256 at a time by all lanes in parallel into LDS and then broadcast
-// from LDS in the streaming loop, so the inner loop is loads + fp64 multiplies/adds only.
+// Two step forms (encoding: planner.h):
+//  * FIBER - the streaming form, >95 % of the bytes on the 10x10 grid.  The inputs are one or two
+//    big tables (the elimination frontier, MBs, streamed from HBM) and a few CPT slices (<= 8 KiB).
+//    The product of the CPT slices is tabulated once per step in LDS (T, <= 16 KiB).  A lane owns one
+//    cell r of the big tables' shared axes: it loads the cx values F[r, x] once - consecutive lanes
+//    read consecutive addresses, 512 B per wave instruction - and produces the whole fiber over the
+//    new (CPT-only) axes in registers,  out[r, n] = sum_x F[r, x] * T[n, x, ctrl(r)],  written as one
+//    contiguous NC*8-byte vector store per lane.  Several (r, iteration) pairs are in flight per lane
+//    to cover HBM latency (Little: ~48 KiB per CU needed at 6 TB/s).
+//  * GENERIC - any number of inputs / any shape, one output cell per lane-iteration; used for the
+//    small steps at the start and end of a program and for the final normalised product.
+//
+// Index math: every table is laid out with the longest-living variable fastest, the iteration space
+// is split into a lane-varying block (lo) and a wave-uniform block (hi).  Lane offsets are decoded
+// once per step; hi offsets are decoded 256 at a time by all lanes in parallel into LDS and broadcast
+// from LDS in the streaming loop, which therefore contains only loads, fp64 FMAs and stores.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,8 +36,7 @@
 namespace mibn {
 
 constexpr int kWG = 256;
-constexpr int kMaxC = kLoMax / kWG;  // output cells per lane in the lane-varying block
-constexpr int kStepWordsMax = kHdrWords + 3 * kMaxIn + kMaxAxes + kMaxIn * kMaxAxes;
+constexpr int kFiberC = kFiberLoMax / kWG;  // R cells per lane in the lane-varying block
 
 struct KernelArgs {
     const uint32_t *prog;       // step programs of the batch
@@ -41,14 +50,20 @@ struct KernelArgs {
     int32_t n_requests;
 };
 
-template <int NIN, int CX>
-__device__ __forceinline__ void step_body(const uint32_t *sw, int (*sh_hoff)[kWG], const double *__restrict__ pool,
-                                          double *__restrict__ slot, double *__restrict__ results, const int tid) {
+__device__ __forceinline__ const double *table_ptr(uint32_t lo, uint32_t hi, const double *pool, const double *slot) {
+    const uint64_t o = (uint64_t)lo | ((uint64_t)hi << 32);
+    return (o & kConstFlag) ? pool + (o & ~kConstFlag) : slot + o;
+}
+
+// ---------------------------------------------------------------------------------------- GENERIC
+template <int NIN, int MAXC, int CX>
+__device__ __forceinline__ void generic_body(const uint32_t *sw, int (*sh_hoff)[kWG], const double *__restrict__ pool,
+                                             double *__restrict__ slot, double *__restrict__ results, const int tid) {
     const uint32_t w0 = sw[0];
-    const int na = (w0 >> 8) & 0xff;
-    const int nlo = (w0 >> 16) & 0xff;
-    const bool fin = (w0 >> 24) & 1;
-    const int cx = CX ? CX : (int)sw[1];
+    const int na = (w0 >> 16) & 0xff;
+    const int nlo = (w0 >> 24) & 0xff;
+    const bool fin = (sw[1] >> 16) & 1;
+    const int cx = CX ? CX : (int)(sw[1] & 0xffff);
     const int lo_cells = (int)sw[2];
     const int hi_cells = (int)sw[3];
     const uint64_t out_off = (uint64_t)sw[4] | ((uint64_t)sw[5] << 32);
@@ -58,17 +73,15 @@ __device__ __forceinline__ void step_body(const uint32_t *sw, int (*sh_hoff)[kWG
     int xs[NIN];
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
-        const uint64_t o = (uint64_t)sw[kHdrWords + 3 * j] | ((uint64_t)sw[kHdrWords + 3 * j + 1] << 32);
-        inp[j] = (o & kConstFlag) ? pool + (o & ~kConstFlag) : slot + o;
+        inp[j] = table_ptr(sw[kHdrWords + 3 * j], sw[kHdrWords + 3 * j + 1], pool, slot);
         xs[j] = (int)sw[kHdrWords + 3 * j + 2];
     }
     const uint32_t *card = sw + kHdrWords + 3 * NIN;
     const int *strd = (const int *)(card + na);  // strd[j * na + a]
 
-    // lane-varying offsets, decoded once per step
-    int lo_off[NIN][kMaxC];
+    int lo_off[NIN][MAXC];
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
 #pragma unroll
         for (int j = 0; j < NIN; ++j) lo_off[j][c] = 0;
         const int l = tid + c * kWG;
@@ -86,7 +99,7 @@ __device__ __forceinline__ void step_body(const uint32_t *sw, int (*sh_hoff)[kWG
     }
 
     for (int h0 = 0; h0 < hi_cells; h0 += kWG) {
-        {  // decode 256 wave-uniform offsets in parallel
+        {
             const int h = h0 + tid;
             if (h < hi_cells) {
                 int acc[NIN];
@@ -113,7 +126,7 @@ __device__ __forceinline__ void step_body(const uint32_t *sw, int (*sh_hoff)[kWG
             for (int j = 0; j < NIN; ++j) ho[j] = sh_hoff[j][hh];
             const size_t orow = (size_t)(h0 + hh) * (size_t)lo_cells;
 #pragma unroll
-            for (int c = 0; c < kMaxC; ++c) {
+            for (int c = 0; c < MAXC; ++c) {
                 const int l = tid + c * kWG;
                 if (l < lo_cells) {
                     double acc = 0.0;
@@ -141,14 +154,216 @@ __device__ __forceinline__ void step_body(const uint32_t *sw, int (*sh_hoff)[kWG
     }
 }
 
-template <int NIN>
-__device__ __forceinline__ void step_cx(const uint32_t *sw, int (*sh_hoff)[kWG], const double *pool, double *slot,
-                                        double *results, int tid) {
-    const int cx = (int)sw[1];
-    if (cx == 4) step_body<NIN, 4>(sw, sh_hoff, pool, slot, results, tid);
-    else if (cx == 2) step_body<NIN, 2>(sw, sh_hoff, pool, slot, results, tid);
-    else if (cx == 1) step_body<NIN, 1>(sw, sh_hoff, pool, slot, results, tid);
-    else step_body<NIN, 0>(sw, sh_hoff, pool, slot, results, tid);
+template <int NIN, int MAXC>
+__device__ __forceinline__ void generic_cx(const uint32_t *sw, int (*sh_hoff)[kWG], const double *pool, double *slot,
+                                           double *results, int tid) {
+    const int cx = (int)(sw[1] & 0xffff);
+    if (cx == 4) generic_body<NIN, MAXC, 4>(sw, sh_hoff, pool, slot, results, tid);
+    else if (cx == 2) generic_body<NIN, MAXC, 2>(sw, sh_hoff, pool, slot, results, tid);
+    else generic_body<NIN, MAXC, 0>(sw, sh_hoff, pool, slot, results, tid);
+}
+
+// ------------------------------------------------------------------------------------------ FIBER
+// NBIG big inputs, CX compile-time x-cardinality (0 = runtime), NCT = register capacity of the N-fiber.
+template <int NBIG, int CX, int NCT>
+__device__ __forceinline__ void fiber_body(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kWG],
+                                           const double *__restrict__ pool, double *__restrict__ slot, const int tid) {
+    const uint32_t w0 = sw[0];
+    const int na = (w0 >> 16) & 0xff;
+    const int nlo = (w0 >> 24) & 0xff;
+    const int cx = CX ? CX : (int)(sw[1] & 0xffff);
+    const int lo_cells = (int)sw[2];
+    const int hi_cells = (int)sw[3];
+    double *__restrict__ outp = slot + ((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+    const int ns = (sw[7] >> 4) & 0xf, nN = (sw[7] >> 8) & 0xf, nctrl = (sw[7] >> 12) & 0xf;
+    const int NC = (int)(sw[7] >> 16);
+    const int T = (int)sw[8];
+    const int nT = nN + nctrl;
+
+    const uint32_t *q = sw + kHdrWords;
+    const double *__restrict__ big[NBIG];
+    int bxs[NBIG];
+#pragma unroll
+    for (int b = 0; b < NBIG; ++b) {
+        big[b] = table_ptr(q[0], q[1], pool, slot);
+        bxs[b] = (int)q[2];
+        q += 3;
+    }
+    const uint32_t *smalls = q;  // ns records of (3 + nT) words
+    q += ns * (3 + nT);
+    const uint32_t *tcard = q;
+    q += nT;
+    const uint32_t *nout = q;
+    q += NC;
+    const uint32_t *rax = q;  // (card, ostride, tstride) per R axis
+    q += 3 * na;
+    const int *bst = (const int *)q;  // bst[b * na + a]
+
+    // T[n + NC*(x + cx*ctrl)] = product of the small inputs (the CPT slices), once per step
+    for (int t = tid; t < T; t += kWG) {
+        int r = t;
+        int qn = r / NC;
+        int rn = r - qn * NC;
+        r = qn;
+        const int qx = r / cx;
+        const int x = r - qx * cx;
+        r = qx;
+        double v = 1.0;
+        for (int j = 0; j < ns; ++j) {
+            const uint32_t *rec = smalls + j * (3 + nT);
+            const int *sts = (const int *)(rec + 3);
+            int off = x * (int)rec[2];
+            int a = rn, c = r;
+            for (int k = 0; k < nN; ++k) { const int cd = (int)tcard[k]; const int qq = a / cd; off += (a - qq * cd) * sts[k]; a = qq; }
+            for (int k = nN; k < nT; ++k) { const int cd = (int)tcard[k]; const int qq = c / cd; off += (c - qq * cd) * sts[k]; c = qq; }
+            v *= table_ptr(rec[0], rec[1], pool, slot)[off];
+        }
+        shT[t] = v;
+    }
+    // are the N-fiber's output cells contiguous (n fastest)?  then it is one vector store per lane
+    bool contig = true;
+    for (int n = 0; n < NC; ++n) contig = contig && (nout[n] == (uint32_t)n);
+
+    int lo_o[kFiberC], lo_t[kFiberC], lo_b[NBIG][kFiberC];
+#pragma unroll
+    for (int c = 0; c < kFiberC; ++c) {
+        lo_o[c] = 0;
+        lo_t[c] = 0;
+#pragma unroll
+        for (int b = 0; b < NBIG; ++b) lo_b[b][c] = 0;
+        const int l = tid + c * kWG;
+        if (l < lo_cells) {
+            int r = l;
+            for (int a = 0; a < nlo; ++a) {
+                const int cd = (int)rax[3 * a];
+                const int qq = r / cd;
+                const int d = r - qq * cd;
+                r = qq;
+                lo_o[c] += d * (int)rax[3 * a + 1];
+                lo_t[c] += d * (int)rax[3 * a + 2];
+#pragma unroll
+                for (int b = 0; b < NBIG; ++b) lo_b[b][c] += d * bst[b * na + a];
+            }
+        }
+    }
+
+    for (int h0 = 0; h0 < hi_cells; h0 += kWG) {
+        {
+            const int h = h0 + tid;
+            if (h < hi_cells) {
+                int ao = 0, at = 0, ab[NBIG];
+#pragma unroll
+                for (int b = 0; b < NBIG; ++b) ab[b] = 0;
+                int r = h;
+                for (int a = nlo; a < na; ++a) {
+                    const int cd = (int)rax[3 * a];
+                    const int qq = r / cd;
+                    const int d = r - qq * cd;
+                    r = qq;
+                    ao += d * (int)rax[3 * a + 1];
+                    at += d * (int)rax[3 * a + 2];
+#pragma unroll
+                    for (int b = 0; b < NBIG; ++b) ab[b] += d * bst[b * na + a];
+                }
+                sh_hoff[0][tid] = ao;
+                sh_hoff[1][tid] = at;
+#pragma unroll
+                for (int b = 0; b < NBIG; ++b) sh_hoff[2 + b][tid] = ab[b];
+            }
+        }
+        __syncthreads();  // also orders the T build before its first use
+        const int nh = min(kWG, hi_cells - h0);
+        for (int hh = 0; hh < nh; ++hh) {
+            const int ho = sh_hoff[0][hh], ht = sh_hoff[1][hh];
+            int hb[NBIG];
+#pragma unroll
+            for (int b = 0; b < NBIG; ++b) hb[b] = sh_hoff[2 + b][hh];
+            if (CX) {
+                // all loads of this iteration (kFiberC cells x NBIG tables x CX values) are issued first
+                double f[kFiberC][CX ? CX : 1];
+#pragma unroll
+                for (int c = 0; c < kFiberC; ++c) {
+                    const bool ok = tid + c * kWG < lo_cells;
+#pragma unroll
+                    for (int x = 0; x < (CX ? CX : 1); ++x) {
+                        double p = ok ? big[0][hb[0] + lo_b[0][c] + x * bxs[0]] : 0.0;
+#pragma unroll
+                        for (int b = 1; b < NBIG; ++b) p *= ok ? big[b][hb[b] + lo_b[b][c] + x * bxs[b]] : 0.0;
+                        f[c][x] = p;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < kFiberC; ++c) {
+                    if (tid + c * kWG < lo_cells) {
+                        const double *__restrict__ Tp = shT + (ht + lo_t[c]);
+                        double acc[NCT];
+#pragma unroll
+                        for (int n = 0; n < NCT; ++n) {
+                            double s = 0.0;
+                            if (n < NC) {
+#pragma unroll
+                                for (int x = 0; x < (CX ? CX : 1); ++x) s += f[c][x] * Tp[x * NC + n];
+                            }
+                            acc[n] = s;
+                        }
+                        double *__restrict__ o = outp + (ho + lo_o[c]);
+                        if (contig && NCT == 4 && NC == 4) {
+                            *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[NCT >= 2 ? 1 : 0]);
+                            *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[NCT >= 4 ? 2 : 0], acc[NCT >= 4 ? 3 : 0]);
+                        } else if (contig && NCT == 2 && NC == 2) {
+                            *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[NCT > 1 ? 1 : 0]);
+                        } else {
+#pragma unroll
+                            for (int n = 0; n < NCT; ++n)
+                                if (n < NC) o[nout[n]] = acc[n];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < kFiberC; ++c) {
+                    if (tid + c * kWG < lo_cells) {
+                        const double *__restrict__ Tp = shT + (ht + lo_t[c]);
+                        double acc[NCT];
+#pragma unroll
+                        for (int n = 0; n < NCT; ++n) acc[n] = 0.0;
+                        for (int x = 0; x < cx; ++x) {
+                            double p = big[0][hb[0] + lo_b[0][c] + x * bxs[0]];
+#pragma unroll
+                            for (int b = 1; b < NBIG; ++b) p *= big[b][hb[b] + lo_b[b][c] + x * bxs[b]];
+#pragma unroll
+                            for (int n = 0; n < NCT; ++n)
+                                if (n < NC) acc[n] += p * Tp[x * NC + n];
+                        }
+                        double *__restrict__ o = outp + (ho + lo_o[c]);
+#pragma unroll
+                        for (int n = 0; n < NCT; ++n)
+                            if (n < NC) o[nout[n]] = acc[n];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NBIG, int CX>
+__device__ __forceinline__ void fiber_nc(const uint32_t *sw, double *shT, int (*sh_hoff)[kWG], const double *pool,
+                                         double *slot, int tid) {
+    const int NC = (int)(sw[7] >> 16);
+    if (NC <= 1) fiber_body<NBIG, CX, 1>(sw, shT, sh_hoff, pool, slot, tid);
+    else if (NC <= 2) fiber_body<NBIG, CX, 2>(sw, shT, sh_hoff, pool, slot, tid);
+    else if (NC <= 4) fiber_body<NBIG, CX, 4>(sw, shT, sh_hoff, pool, slot, tid);
+    else fiber_body<NBIG, CX, kMaxNC>(sw, shT, sh_hoff, pool, slot, tid);
+}
+
+template <int NBIG>
+__device__ __forceinline__ void fiber_cx(const uint32_t *sw, double *shT, int (*sh_hoff)[kWG], const double *pool,
+                                         double *slot, int tid) {
+    const int cx = (int)(sw[1] & 0xffff);
+    if (cx == 4) fiber_nc<NBIG, 4>(sw, shT, sh_hoff, pool, slot, tid);
+    else if (cx == 2) fiber_nc<NBIG, 2>(sw, shT, sh_hoff, pool, slot, tid);
+    else fiber_nc<NBIG, 0>(sw, shT, sh_hoff, pool, slot, tid);
 }
 
 // posterior / posterior.sum()  (bayes_net.py:790); an all-zero table (zero-probability evidence) stays zero
@@ -166,7 +381,8 @@ __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double 
 }
 
 __global__ __launch_bounds__(kWG) void ve_kernel(const KernelArgs A) {
-    __shared__ uint32_t sh_step[kStepWordsMax + 6];
+    __shared__ __attribute__((aligned(16))) double shT[kMaxT];
+    __shared__ uint32_t sh_step[kMaxStepWords];
     __shared__ int sh_hoff[kMaxIn][kWG];
     __shared__ double sh_red[kWG / 64];
     __shared__ int sh_ticket;
@@ -185,21 +401,27 @@ __global__ __launch_bounds__(kWG) void ve_kernel(const KernelArgs A) {
         for (int s = 0; s < n_steps; ++s) {
             const int words = (int)p[6];
             __syncthreads();  // previous step's stores are done and visible to the workgroup; sh_step reusable
-            if (tid < words) sh_step[tid] = p[tid];
+            for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
             __syncthreads();
-            const int n_in = sh_step[0] & 0xff;
-            switch (n_in) {
-                case 1: step_cx<1>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-                case 2: step_cx<2>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-                case 3: step_cx<3>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-                case 4: step_cx<4>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-                case 5: step_cx<5>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-                default: step_cx<6>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-            }
-            if ((sh_step[0] >> 24) & 1) {
-                const uint64_t out_off = (uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32);
-                const int n = (int)(sh_step[2] * sh_step[3]);
-                normalise(A.results + out_off, n, sh_red, tid);
+            const uint32_t kind = sh_step[0] & 0xff;
+            const int n_in = (sh_step[0] >> 8) & 0xff;
+            if (kind == kKindFiber) {
+                if ((sh_step[7] & 0xf) == 1) fiber_cx<1>(sh_step, shT, sh_hoff, A.pool, slot, tid);
+                else fiber_cx<2>(sh_step, shT, sh_hoff, A.pool, slot, tid);
+            } else {
+                switch (n_in) {
+                    case 1: generic_cx<1, 2>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
+                    case 2: generic_cx<2, 2>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
+                    case 3: generic_cx<3, 2>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
+                    case 4: generic_cx<4, 1>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
+                    case 5: generic_cx<5, 1>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
+                    default: generic_cx<6, 1>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
+                }
+                if ((sh_step[1] >> 16) & 1) {
+                    const uint64_t out_off = (uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32);
+                    const int n = (int)(sh_step[2] * sh_step[3]);
+                    normalise(A.results + out_off, n, sh_red, tid);
+                }
             }
             p += words;
         }

@@ -26,6 +26,7 @@ def lib():
         L.plan_sim_query.argtypes = [C.c_int32, i32p, i64p, i32p, i64p, f64p, C.c_int32, i32p,
                                      C.c_int32, i32p, C.c_int32, i32p, i32p, f64p, f64p]
         L.plan_sim_error.restype = C.c_char_p
+        L.plan_sim_set_small_cells.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -33,7 +34,8 @@ def lib():
 class SimEngine:
     """Same surface as sorobn_amd._capi.Engine for the exact path, executed by plan_sim."""
 
-    def __init__(self, flat):
+    def __init__(self, flat, small_cells=1024):
+        self.small_cells = small_cells  # lower it to force FIBER steps on small networks
         self.f = flat
         self.card = flat.card
         self.last_stats = None
@@ -50,6 +52,7 @@ class SimEngine:
         out = np.zeros(cells, np.float64)
         stats = np.zeros(5, np.float64)
         hints = np.ascontiguousarray(self.hints.reshape(-1) if self.hints.size else [0], np.int32)
+        L.plan_sim_set_small_cells(int(self.small_cells))
         rc = L.plan_sim_query(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64),
                               p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
                               p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
@@ -70,17 +73,17 @@ class SimEngine:
         return (np.concatenate(outs) if outs else np.zeros(0)), off
 
 
-def sim_backend(bn):
+def sim_backend(bn, small_cells=1024):
     """A Backend whose engine is the CPU plan simulator (bypasses Backend.__init__)."""
     b = Backend.__new__(Backend)
     b.flat = flatten(bn)
     b.fingerprint = Backend.fingerprint_of(bn)
-    b.engine = SimEngine(b.flat)
+    b.engine = SimEngine(b.flat, small_cells)
     b._anc = {}
     return b
 
 
-def attach(bn):
+def attach(bn, small_cells=1024):
     """Make a sorobn_amd.BayesNet answer through the simulator (tests only)."""
-    bn._backend = sim_backend(bn)
+    bn._backend = sim_backend(bn, small_cells)
     return bn

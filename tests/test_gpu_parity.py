@@ -38,17 +38,23 @@ def _check_requests(bn, requests, ctx):
     return worst
 
 
+# small_cells < 1024 forces the FIBER (streaming) step form, normally reserved for > 8 KiB tables, onto the
+# small golden networks: mixed cardinalities, sparse CPTs, every (n_big, cx, NC) kernel specialisation
+@pytest.mark.parametrize("small_cells", [1024, 1, 6])
 @pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
-def test_golden_networks(amd, fname):
+def test_golden_networks(amd, fname, small_cells):
     for net in gu.load(fname):
         bn = netspec.build(net["spec"], amd.BayesNet)
+        bn.backend.engine.set_option("small_cells", small_cells)
         _check_requests(bn, net["requests"], net["spec"]["name"])
 
 
-def test_golden_small_grids(amd):
+@pytest.mark.parametrize("small_cells", [1024, 3, 20])
+def test_golden_small_grids(amd, small_cells):
     for entry in gu.load("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
         bn = netspec.build(spec, amd.BayesNet)
+        bn.backend.engine.set_option("small_cells", small_cells)
         _check_requests(bn, entry["requests"], spec["name"])
 
 

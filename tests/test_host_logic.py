@@ -141,17 +141,21 @@ def _check_requests(bn, requests, ctx, limit=None):
     assert worst <= gu.TOL, (ctx, worst)
 
 
+# small_cells: inputs above this size are "big" -> lowering it forces the FIBER step form (normally only
+# used for > 8 KiB tables) onto the small golden networks, mixed cardinalities and sparse CPTs included
+@pytest.mark.parametrize("small_cells", [1024, 1, 6])
 @pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
-def test_planner_programs_reproduce_reference(fname):
+def test_planner_programs_reproduce_reference(fname, small_cells):
     for net in _nets(fname):
-        bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet))
-        _check_requests(bn, net["requests"], net["spec"]["name"])
+        bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet), small_cells)
+        _check_requests(bn, net["requests"], net["spec"]["name"], limit=None if small_cells == 1024 else 60)
 
 
-def test_planner_programs_reproduce_reference_grids():
+@pytest.mark.parametrize("small_cells", [1024, 3, 20])
+def test_planner_programs_reproduce_reference_grids(small_cells):
     for entry in _nets("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
-        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
+        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), small_cells)
         _check_requests(bn, entry["requests"], spec["name"])
 
 
