@@ -10,6 +10,7 @@
 //
 // This library is NOT part of the product and is never loaded by sorobn_amd: the product path has
 // no CPU fallback (mibn_query_batch fails without a gfx950 device).  Only tests/ may load it.
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -186,4 +187,29 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     if ((int64_t)prog.size() > cap) return -2;
     std::memcpy(out, prog.data(), prog.size() * 4);
     return (int64_t)prog.size();
+}
+
+// host-side planning throughput probe (no execution): plans B fixed-shape requests on `threads` threads
+extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                                 const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
+                                 int64_t B, int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars,
+                                 const int32_t *ecodes, int threads, double *stats /* bytes, steps, words */) {
+    Network net;
+    g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
+    if (!g_err.empty()) return -1;
+    for (int i = 0; i < n_hints; ++i)
+        net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
+    std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
+    for (int64_t b = 0; b <= B; ++b) { q_off[b] = b * nq; e_off[b] = b * ne; out_off[b] = b * 4; }
+    BatchPlan bp;
+    ThreadPool pool(threads);
+    std::vector<ProgBuf> bufs;
+    plan_batch(net, pool, bufs, 0, B, q_off.data(), qvars, e_off.data(), evars, ecodes, out_off.data(), nullptr, bp);  // warm-up
+    auto t0 = std::chrono::steady_clock::now();
+    plan_batch(net, pool, bufs, 0, B, q_off.data(), qvars, e_off.data(), evars, ecodes, out_off.data(), nullptr, bp);
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (auto &b : bufs) b.release();
+    if (stats) { stats[0] = bp.st.alg_bytes; stats[1] = bp.st.n_steps; stats[2] = (double)bp.total_words; }
+    g_err = bp.err;
+    return ms;
 }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -31,25 +32,33 @@ struct mibn_ctx {
     int device = -1;
     int n_cu = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *d_pool = nullptr;
     double *d_arena = nullptr;
     size_t arena_bytes = 0;
-    uint32_t *d_prog = nullptr;
-    size_t prog_cap = 0;  // words
-    uint64_t *d_prog_off = nullptr;
-    int32_t *d_order = nullptr;
-    size_t prog_off_cap = 0, order_cap = 0;
     double *d_results = nullptr;
     size_t results_cap = 0;  // doubles
-    uint32_t *d_ticket = nullptr;
+    // double-buffered chunk pipeline: workers plan chunk i+1 into pinned buffers while the GPU runs chunk i
+    ThreadPool *pool = nullptr;
+    struct Set {
+        std::vector<ProgBuf> bufs;  // pinned host program buffers, one per worker
+        uint32_t *d_prog = nullptr;
+        size_t prog_cap = 0;
+        uint64_t *d_prog_off = nullptr;
+        size_t prog_off_cap = 0;
+        int32_t *d_order = nullptr;
+        size_t order_cap = 0;
+        uint32_t *d_ticket = nullptr;
+        hipEvent_t k0 = nullptr, k1 = nullptr;  // kernel start / end
+        bool busy = false;
+        BatchPlan plan;
+    } set[2];
     std::string err;
     mibn_stats stats{};
     // options
     double arena_gb = 64.0;
     int threads = 0;
     int wg_per_cu = 8;
-    int64_t chunk = 32768;  // requests per internal launch
+    int64_t chunk = 8192;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
 };
 
 #define HIP_TRY(h, expr)                                                                              \
@@ -96,30 +105,35 @@ int mibn_create(int device, mibn_t **out) {
         return MIBN_E_NODEVICE;
     }
     h->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
-        hipMalloc(&h->d_ticket, 64) != hipSuccess) {
-        delete h;
-        return MIBN_E_HIP;
-    }
+    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto &st : h->set)
+        ok = ok && hipEventCreate(&st.k0) == hipSuccess && hipEventCreate(&st.k1) == hipSuccess &&
+             hipMalloc(&st.d_ticket, 64) == hipSuccess;
+    if (!ok) { delete h; return MIBN_E_HIP; }
     *out = h;
     return MIBN_OK;
 }
 
 void mibn_destroy(mibn_t *h) {
     if (!h) return;
+    delete h->pool;
     if (!h->planner_only) {
-        hipSetDevice(h->device);
-        hipFree(h->d_pool);
-        hipFree(h->d_arena);
-        hipFree(h->d_prog);
-        hipFree(h->d_prog_off);
-        hipFree(h->d_order);
-        hipFree(h->d_results);
-        hipFree(h->d_ticket);
-        if (h->ev0) hipEventDestroy(h->ev0);
-        if (h->ev1) hipEventDestroy(h->ev1);
-        if (h->stream) hipStreamDestroy(h->stream);
+        (void)hipSetDevice(h->device);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(h->d_pool);
+        (void)hipFree(h->d_arena);
+        (void)hipFree(h->d_results);
+        for (auto &st : h->set) {
+            for (auto &b : st.bufs)
+                if (b.data) (void)hipHostFree(b.data);
+            (void)hipFree(st.d_prog);
+            (void)hipFree(st.d_prog_off);
+            (void)hipFree(st.d_order);
+            (void)hipFree(st.d_ticket);
+            if (st.k0) (void)hipEventDestroy(st.k0);
+            if (st.k1) (void)hipEventDestroy(st.k1);
+        }
+        if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
 }
@@ -204,78 +218,34 @@ int ensure(mibn_ctx *h, T *&ptr, size_t &cap, size_t need) {
     return MIBN_OK;
 }
 
-struct Chunk {
-    std::vector<std::vector<uint32_t>> progs;      // per planning thread
-    std::vector<uint64_t> prog_off;                // per request (global word offset)
-    std::vector<double> cost;                      // alg_bytes per request
-    std::vector<int32_t> order;
-    int64_t arena_cells = 0;
-    size_t total_words = 0;
-    PlanStats st;
-    std::string err;
-};
+// pinned backing of the program buffers: the upload is then a real async DMA that overlaps planning
+uint32_t *pinned_grow(void *, uint32_t *old, size_t used, size_t new_cap) {
+    uint32_t *p = nullptr;
+    if (hipHostMalloc((void **)&p, new_cap * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (old) {
+        std::memcpy(p, old, used * sizeof(uint32_t));
+        (void)hipHostFree(old);
+    }
+    return p;
+}
 
-// plan requests [b0, b1) on T threads
-void plan_chunk(const mibn_ctx *h, int64_t b0, int64_t b1, const int64_t *q_off, const int32_t *q_vars,
-                const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes, const int64_t *out_off,
-                const std::vector<char> &skip, Chunk &ck) {
-    const int64_t n = b1 - b0;
-    int T = h->threads > 0 ? h->threads : (int)std::thread::hardware_concurrency();
-    T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(T, 64), (n + 63) / 64));
-    ck.progs.assign(T, {});
-    ck.prog_off.assign(n, 0);
-    ck.cost.assign(n, 0.0);
-    std::vector<PlanStats> tst(T);
-    std::vector<std::string> terr(T);
-    std::vector<std::vector<uint64_t>> local_off(T);
-    auto work = [&](int t) {
-        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
-        auto &prog = ck.progs[t];
-        prog.reserve((size_t)(hi - lo) * 512);
-        for (int64_t i = lo; i < hi; ++i) {
-            const int64_t b = b0 + i;
-            ck.prog_off[i] = prog.size();
-            if (skip[b]) { prog.push_back(0); continue; }  // zero steps: result stays all-zero
-            Request rq;
-            rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
-            rq.qvars = q_vars + q_off[b];
-            rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
-            rq.evars = e_vars + e_off[b];
-            rq.ecodes = e_codes + e_off[b];
-            rq.out_off = out_off[b] - out_off[b0];
-            PlanStats st;
-            std::string e = plan_request(h->net, rq, prog, st);
-            if (!e.empty()) { terr[t] = e; return; }
-            ck.cost[i] = st.alg_bytes;
-            tst[t].alg_bytes += st.alg_bytes;
-            tst[t].alg_flops += st.alg_flops;
-            tst[t].n_steps += st.n_steps;
-            tst[t].max_step_cells = std::max(tst[t].max_step_cells, st.max_step_cells);
-            tst[t].arena_cells = std::max(tst[t].arena_cells, st.arena_cells);
-        }
-    };
-    if (T == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
-    }
-    size_t base = 0;
-    for (int t = 0; t < T; ++t) {
-        if (!terr[t].empty()) ck.err = terr[t];
-        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
-        for (int64_t i = lo; i < hi; ++i) ck.prog_off[i] += base;
-        base += ck.progs[t].size();
-        ck.st.alg_bytes += tst[t].alg_bytes;
-        ck.st.alg_flops += tst[t].alg_flops;
-        ck.st.n_steps += tst[t].n_steps;
-        ck.st.max_step_cells = std::max(ck.st.max_step_cells, tst[t].max_step_cells);
-        ck.arena_cells = std::max(ck.arena_cells, tst[t].arena_cells);
-    }
-    ck.total_words = base;
-    ck.order.resize(n);
-    std::iota(ck.order.begin(), ck.order.end(), 0);
-    std::stable_sort(ck.order.begin(), ck.order.end(), [&](int32_t a, int32_t b) { return ck.cost[a] > ck.cost[b]; });
+int default_threads() {
+    int hw = (int)std::thread::hardware_concurrency();
+    int local_world = 1;
+    if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, std::atoi(e));
+    return std::max(1, std::min(64, hw / local_world));
+}
+
+// collect the kernel time of a finished set
+int retire(mibn_ctx *h, mibn_ctx::Set &st) {
+    if (!st.busy) return MIBN_OK;
+    HIP_TRY(h, hipEventSynchronize(st.k1));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, st.k0, st.k1));
+    h->stats.kernel_ms += ms;
+    h->stats.n_launches += 1;
+    st.busy = false;
+    return MIBN_OK;
 }
 
 }  // namespace
@@ -288,6 +258,7 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
     const double t_start = now_ms();
     h->stats = mibn_stats{};
+    if (B == 0) return MIBN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     // validation (bayes_net.py:840-845) and the out-of-domain-evidence short cut
     std::vector<char> skip((size_t)B, 0);
@@ -307,78 +278,89 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             if (c < 0 || c >= h->net.card[rq.evars[i]]) skip[b] = 1;  // label outside the domain -> empty posterior
         }
     }
-    for (int64_t b0 = 0; b0 < B; b0 += h->chunk) {
+    if (!h->pool) {
+        h->pool = new ThreadPool(h->threads > 0 ? h->threads : default_threads());
+        for (auto &st : h->set) {
+            st.bufs.resize(h->pool->size());
+            for (auto &b : st.bufs) b.grow = pinned_grow;
+        }
+    }
+    int rc;
+    const size_t res_cells = (size_t)(out_off[B] - out_off[0]);
+    if ((rc = ensure(h, h->d_results, h->results_cap, res_cells))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_results, 0, res_cells * 8, h->stream));
+    int64_t n_chunks = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += h->chunk, ++n_chunks) {
         const int64_t b1 = std::min(B, b0 + h->chunk);
         const int64_t n = b1 - b0;
+        mibn_ctx::Set &st = h->set[n_chunks & 1];
+        if ((rc = retire(h, st))) return rc;  // its buffers are about to be rewritten
         double t0 = now_ms();
-        Chunk ck;
-        plan_chunk(h, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip, ck);
-        if (!ck.err.empty()) { h->err = ck.err; return MIBN_E_LIMIT; }
+        BatchPlan &ck = st.plan;
+        plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck);
+        if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); return MIBN_E_LIMIT; }
+        for (auto &b : st.bufs)
+            if (b.cap && !b.data) { h->err = "pinned host allocation failed"; (void)hipStreamSynchronize(h->stream); return MIBN_E_HIP; }
         h->stats.plan_ms += now_ms() - t0;
         // arena: one slot per persistent workgroup
         const size_t slot_cells = (size_t)std::max<int64_t>(2, (ck.arena_cells + 1) & ~int64_t(1));
-        size_t free_b = 0, total_b = 0;
-        HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
-        const double budget = std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes));
-        int64_t n_wg = (int64_t)h->n_cu * h->wg_per_cu;
-        n_wg = std::min<int64_t>(n_wg, n);
-        n_wg = std::min<int64_t>(n_wg, (int64_t)(budget / (8.0 * (double)slot_cells)));
-        if (n_wg < 1) { h->err = "a request needs " + std::to_string(8.0 * slot_cells / 1e9) + " GB of scratch, above the arena budget"; return MIBN_E_NOMEM; }
-        const size_t need = (size_t)n_wg * slot_cells * sizeof(double);
-        if (need > h->arena_bytes) {
-            if (h->d_arena) { HIP_TRY(h, hipFree(h->d_arena)); h->d_arena = nullptr; h->arena_bytes = 0; }
-            HIP_TRY(h, hipMalloc(&h->d_arena, need));
-            h->arena_bytes = need;
+        int64_t n_wg = std::min<int64_t>((int64_t)h->n_cu * h->wg_per_cu, n);
+        if ((double)n_wg * slot_cells * 8.0 > (double)h->arena_bytes) {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
+            const double budget = std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes));
+            n_wg = std::min<int64_t>(n_wg, (int64_t)(budget / (8.0 * (double)slot_cells)));
+            if (n_wg < 1) { h->err = "a request needs " + std::to_string(8.0 * slot_cells / 1e9) + " GB of scratch, above the arena budget"; return MIBN_E_NOMEM; }
+            const size_t need = (size_t)n_wg * slot_cells * sizeof(double);
+            if (need > h->arena_bytes) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));  // a running kernel still uses the old arena
+                if (h->d_arena) { HIP_TRY(h, hipFree(h->d_arena)); h->d_arena = nullptr; h->arena_bytes = 0; }
+                HIP_TRY(h, hipMalloc(&h->d_arena, need));
+                h->arena_bytes = need;
+            }
         }
-        const size_t res_cells = (size_t)(out_off[b1] - out_off[b0]);
-        int rc;
-        if ((rc = ensure(h, h->d_prog, h->prog_cap, ck.total_words))) return rc;
-        if ((rc = ensure(h, h->d_prog_off, h->prog_off_cap, (size_t)n))) return rc;
-        if ((rc = ensure(h, h->d_order, h->order_cap, (size_t)n))) return rc;
-        if ((rc = ensure(h, h->d_results, h->results_cap, res_cells))) return rc;
-        // upload
+        if ((rc = ensure(h, st.d_prog, st.prog_cap, ck.total_words))) return rc;
+        if ((rc = ensure(h, st.d_prog_off, st.prog_off_cap, (size_t)n))) return rc;
+        if ((rc = ensure(h, st.d_order, st.order_cap, (size_t)n))) return rc;
         t0 = now_ms();
         size_t base = 0;
-        for (auto &p : ck.progs) {
-            if (!p.empty()) HIP_TRY(h, hipMemcpyAsync(h->d_prog + base, p.data(), p.size() * 4, hipMemcpyHostToDevice, h->stream));
-            base += p.size();
+        for (size_t t = 0; t < ck.thread_words.size(); ++t) {
+            if (ck.thread_words[t])
+                HIP_TRY(h, hipMemcpyAsync(st.d_prog + base, st.bufs[t].data, ck.thread_words[t] * 4, hipMemcpyHostToDevice, h->stream));
+            base += ck.thread_words[t];
         }
-        HIP_TRY(h, hipMemcpyAsync(h->d_prog_off, ck.prog_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_order, ck.order.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->d_ticket, 0, 64, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->d_results, 0, res_cells * 8, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpyAsync(st.d_prog_off, ck.prog_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(st.d_order, ck.order.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemsetAsync(st.d_ticket, 0, 64, h->stream));
         h->stats.h2d_ms += now_ms() - t0;
-        // launch
         KernelArgs A;
-        A.prog = h->d_prog;
-        A.prog_off = h->d_prog_off;
-        A.order = h->d_order;
+        A.prog = st.d_prog;
+        A.prog_off = st.d_prog_off;
+        A.order = st.d_order;
         A.pool = h->d_pool;
         A.arena = h->d_arena;
         A.slot_cells = slot_cells;
-        A.results = h->d_results;
-        A.ticket = h->d_ticket;
+        A.results = h->d_results + (out_off[b0] - out_off[0]);
+        A.ticket = st.d_ticket;
         A.n_requests = (int32_t)n;
-        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        HIP_TRY(h, hipEventRecord(st.k0, h->stream));
         hipLaunchKernelGGL(ve_kernel, dim3((unsigned)n_wg), dim3(kWG), 0, h->stream, A);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        float ms = 0;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        h->stats.kernel_ms += ms;
-        h->stats.n_launches += 1;
-        t0 = now_ms();
-        HIP_TRY(h, hipMemcpy(out + out_off[b0], h->d_results, res_cells * 8, hipMemcpyDeviceToHost));
-        h->stats.d2h_ms += now_ms() - t0;
+        HIP_TRY(h, hipEventRecord(st.k1, h->stream));
+        st.busy = true;
         h->stats.alg_bytes += ck.st.alg_bytes;
         h->stats.alg_flops += ck.st.alg_flops;
         h->stats.n_steps += ck.st.n_steps;
         h->stats.max_step_cells = std::max(h->stats.max_step_cells, ck.st.max_step_cells);
-        h->stats.arena_bytes = (double)need;
+        h->stats.arena_bytes = (double)h->arena_bytes;
         h->stats.n_workgroups = (double)n_wg;
     }
+    for (auto &st : h->set)
+        if ((rc = retire(h, st))) return rc;
+    double t0 = now_ms();
+    HIP_TRY(h, hipMemcpyAsync(out + out_off[0], h->d_results, res_cells * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stats.d2h_ms += now_ms() - t0;
     h->stats.total_ms = now_ms() - t_start;
     return MIBN_OK;
 }

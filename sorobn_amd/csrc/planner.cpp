@@ -3,11 +3,25 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <numeric>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 namespace mibn {
+
+#ifdef MIBN_PLAN_PROFILE
+#include <chrono>
+double g_prof[8];
+struct ProfT { int k; std::chrono::steady_clock::time_point t0; ProfT(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {} ~ProfT() { g_prof[k] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } };
+#define PROF(k) ProfT prof_##k(k)
+#else
+#define PROF(k)
+#endif
 
 // ------------------------------------------------------------------------------------ Network
 
@@ -100,13 +114,16 @@ std::string validate_request(const Network &net, const Request &rq) {
 
 namespace {
 
-struct PF {  // planning-time factor
-    Bits scope;                    // free (non-evidence) variables
-    std::vector<int32_t> vars;     // axes, any order
-    std::vector<int64_t> strides;  // stride (doubles) per axis
-    uint64_t off = 0;              // arena offset, or pool offset | kConstFlag
-    int64_t cells = 0;             // product of the free cardinalities
-    int64_t alloc = 0;             // arena cells owned (0 for constants)
+constexpr int kRawAxes = 40;  // axes of one factor before merging (cells < 2^31 => <= 31 non-trivial axes)
+
+struct PF {  // planning-time factor (plain data: no heap allocation on the planning path)
+    Bits scope;                  // free (non-evidence) variables
+    int n = 0;                   // axes
+    int32_t vars[kRawAxes];
+    int64_t strides[kRawAxes];   // stride (doubles) per axis
+    uint64_t off = 0;            // arena offset, or pool offset | kConstFlag
+    int64_t cells = 0;           // product of the free cardinalities
+    int64_t alloc = 0;           // arena cells owned (0 for constants)
 };
 
 inline double scope_log2(const Network &net, const Bits &b) {
@@ -115,8 +132,26 @@ inline double scope_log2(const Network &net, const Bits &b) {
     return s;
 }
 
+// per-thread scratch reused across requests
+struct Scratch {
+    std::vector<Bits> sim;
+    std::vector<Bits> adj;
+    std::vector<double> w;
+    std::vector<char> alive;
+    std::vector<PF> pool;
+    std::vector<int> live;
+    std::vector<int32_t> pos;  // variable -> axis position in the current output (or -1)
+    std::vector<double> key;
+};
+Scratch &scratch() {
+    static thread_local Scratch s;
+    return s;
+}
+
 // SURVEY section 8(d) byte model of an elimination order over factor scopes.
-double simulate(const Network &net, std::vector<Bits> f, const std::vector<int32_t> &order, double abort_above) {
+double simulate(const Network &net, const std::vector<Bits> &f0, const std::vector<int32_t> &order, double abort_above) {
+    std::vector<Bits> &f = scratch().sim;
+    f.assign(f0.begin(), f0.end());
     double bytes = 0;
     for (int32_t x : order) {
         Bits u;
@@ -149,104 +184,113 @@ double simulate(const Network &net, std::vector<Bits> f, const std::vector<int32
     return bytes;
 }
 
-// greedy min-weight on the interaction graph (weight = size of the factor the elimination creates)
-std::vector<int32_t> greedy_min_weight(const Network &net, const std::vector<Bits> &f, const Bits &hidden,
-                                       bool fill) {
-    int n = net.n_vars;
-    std::vector<Bits> adj(n);
-    for (auto &a : adj) a.nw = net.nw;
-    for (auto &s : f) s.for_each([&](int v) { adj[v].or_(s); });
-    for (int v = 0; v < n; ++v) adj[v].clr(v);
+// Greedy elimination on the interaction graph.  fill = false: min-weight (size of the factor the
+// elimination creates).  fill = true: min-fill (number of new edges), ties by weight.
+std::vector<int32_t> greedy_order(const Network &net, const std::vector<Bits> &f, const Bits &hidden, bool fill) {
+    const int n = net.n_vars;
+    Scratch &S = scratch();
+    S.adj.assign(n, Bits{});
+    for (auto &a : S.adj) a.nw = net.nw;
+    for (auto &s : f) s.for_each([&](int v) { S.adj[v].or_(s); });
+    for (int v = 0; v < n; ++v) S.adj[v].clr(v);
+    std::vector<Bits> &adj = S.adj;
     std::vector<int32_t> hid;
     hidden.for_each([&](int v) { hid.push_back(v); });
-    std::vector<double> w(n, 0);
+    S.w.assign(n, 0.0);
+    S.alive.assign(n, 0);
     auto weight = [&](int x) {
-        double s = scope_log2(net, adj[x]);
+        const double s = scope_log2(net, adj[x]);
         if (!fill) return s;
-        // weighted min-fill flavour: created factor size minus what the neighbours already share
-        double removed = 0;
+        int missing = 0;  // (ordered) pairs of neighbours that are not yet adjacent
         adj[x].for_each([&](int y) {
-            Bits t = adj[x];
-            t.andnot(adj[y]);
-            t.clr(y);
-            removed += t.count();
+            for (int k = 0; k < net.nw; ++k) missing += __builtin_popcountll(adj[x].w[k] & ~adj[y].w[k]);
+            missing -= 1;  // y itself is in adj[x] but not in adj[y]
         });
-        return removed * 64.0 + s;  // primary: number of fill edges, secondary: size
+        return missing * 64.0 + s;
     };
-    for (int x : hid) w[x] = weight(x);
+    for (int x : hid) { S.w[x] = weight(x); S.alive[x] = 1; }
     std::vector<int32_t> order;
-    std::vector<char> alive(n, 0);
-    for (int x : hid) alive[x] = 1;
+    order.reserve(hid.size());
     for (size_t it = 0; it < hid.size(); ++it) {
         int best = -1;
         for (int x : hid)
-            if (alive[x]) {
-                if (best < 0 || w[x] < w[best] - 1e-12 ||
-                    (std::fabs(w[x] - w[best]) <= 1e-12 &&
+            if (S.alive[x]) {
+                if (best < 0 || S.w[x] < S.w[best] - 1e-12 ||
+                    (std::fabs(S.w[x] - S.w[best]) <= 1e-12 &&
                      (net.depth[x] < net.depth[best] || (net.depth[x] == net.depth[best] && x < best))))
                     best = x;
             }
         order.push_back(best);
-        alive[best] = 0;
-        Bits nb = adj[best];
+        S.alive[best] = 0;
+        const Bits nb = adj[best];
+        Bits touched = nb;  // vertices whose weight can change: the neighbours and (min-fill) their neighbours
         nb.for_each([&](int y) {
             adj[y].or_(nb);
             adj[y].clr(best);
             adj[y].clr(y);
         });
-        nb.for_each([&](int y) { if (alive[y]) w[y] = weight(y); });
-        if (fill)  // second-ring weights change too
-            nb.for_each([&](int y) { adj[y].for_each([&](int z) { if (alive[z]) w[z] = weight(z); }); });
+        if (fill) nb.for_each([&](int y) { touched.or_(adj[y]); });
+        touched.for_each([&](int y) { if (S.alive[y]) S.w[y] = weight(y); });
     }
     return order;
 }
 
 struct Arena {
-    std::vector<std::pair<int64_t, int64_t>> free_;  // (offset, size), sorted by offset
+    static constexpr int kMaxBlocks = 64;
+    int64_t foff[kMaxBlocks], fsz[kMaxBlocks];  // free list sorted by offset
+    int nf = 0;
     int64_t top = 0;
     int64_t alloc(int64_t n) {
         n = (n + 1) & ~int64_t(1);  // keep 16-byte alignment
-        for (size_t i = 0; i < free_.size(); ++i)
-            if (free_[i].second >= n) {
-                int64_t o = free_[i].first;
-                free_[i].first += n;
-                free_[i].second -= n;
-                if (!free_[i].second) free_.erase(free_.begin() + i);
+        for (int i = 0; i < nf; ++i)
+            if (fsz[i] >= n) {
+                const int64_t o = foff[i];
+                foff[i] += n;
+                fsz[i] -= n;
+                if (!fsz[i]) { for (int k = i; k + 1 < nf; ++k) { foff[k] = foff[k + 1]; fsz[k] = fsz[k + 1]; } --nf; }
                 return o;
             }
-        // extend: if the last free block touches the top, grow it
-        if (!free_.empty() && free_.back().first + free_.back().second == top) {
-            int64_t o = free_.back().first;
+        if (nf && foff[nf - 1] + fsz[nf - 1] == top) {  // grow the free block that touches the top
+            const int64_t o = foff[nf - 1];
             top = o + n;
-            free_.pop_back();
+            --nf;
             return o;
         }
-        int64_t o = top;
+        const int64_t o = top;
         top += n;
         return o;
     }
     void release(int64_t o, int64_t n) {
         n = (n + 1) & ~int64_t(1);
-        auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(o, int64_t(0)));
-        it = free_.insert(it, {o, n});
-        size_t i = it - free_.begin();
-        if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
-            free_[i].second += free_[i + 1].second;
-            free_.erase(free_.begin() + i + 1);
-        }
-        if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
-            free_[i - 1].second += free_[i].second;
-            free_.erase(free_.begin() + i);
-        }
+        int i = 0;
+        while (i < nf && foff[i] < o) ++i;
+        const bool left = i > 0 && foff[i - 1] + fsz[i - 1] == o;
+        const bool right = i < nf && o + n == foff[i];
+        if (left && right) {
+            fsz[i - 1] += n + fsz[i];
+            for (int k = i; k + 1 < nf; ++k) { foff[k] = foff[k + 1]; fsz[k] = fsz[k + 1]; }
+            --nf;
+        } else if (left) {
+            fsz[i - 1] += n;
+        } else if (right) {
+            foff[i] = o;
+            fsz[i] += n;
+        } else if (nf < kMaxBlocks) {
+            for (int k = nf; k > i; --k) { foff[k] = foff[k - 1]; fsz[k] = fsz[k - 1]; }
+            foff[i] = o;
+            fsz[i] = n;
+            ++nf;
+        }  // else: leak the block (only costs scratch space)
     }
 };
 
 struct Emitter {
     const Network &net;
-    std::vector<uint32_t> &prog;
+    ProgBuf &prog;
     PlanStats &st;
     Arena arena;
-    std::vector<double> key;  // layout key per variable: larger = lives longer = faster axis
+    std::vector<double> &key;   // layout key per variable: larger = lives longer = faster axis
+    std::vector<int32_t> &pos;  // variable -> output axis (scratch, -1 outside emit)
     std::string err;
 
     void header(uint32_t *w, uint32_t kind, int n_in, int ma, int mlo, int cx, bool final_, int64_t lo, int64_t hi,
@@ -261,42 +305,41 @@ struct Emitter {
         w[7] = w[8] = w[9] = 0;
     }
 
+    using Strides = int64_t[kMaxIn][kRawAxes];
+
     // GENERIC encoding: iteration space = output cells
-    void emit_generic(const std::vector<PF> &ins, const std::vector<std::vector<int64_t>> &s, const std::vector<int64_t> &xs,
-                      const PF &out, int na, int64_t cells, int cx, bool final_) {
-        const int n_in = (int)ins.size();
+    void emit_generic(const PF *const *ins, int n_in, const Strides &s, const int64_t *xs, const PF &out, int64_t cells,
+                      int cx, bool final_) {
+        const int na = out.n;
         int nlo = 0;
         int64_t lo = 1;
         const int64_t lomax = n_in <= 3 ? kLoMax : kLoTarget;  // kernel: 2 cells per lane up to 3 inputs, else 1
         while (nlo < na && lo < kLoTarget && lo * net.card[out.vars[nlo]] <= lomax) lo *= net.card[out.vars[nlo++]];
         // merge adjacent axes that are contiguous in every input (the output is dense by construction)
-        std::vector<uint32_t> mcard;
-        std::vector<std::vector<int64_t>> ms(n_in);
-        int mlo = 0;
+        uint32_t mcard[kRawAxes];
+        int64_t ms[kMaxIn][kRawAxes];
+        int ma = 0, mlo = 0;
         for (int a = 0; a < na; ++a) {
-            bool merge = !mcard.empty() && a != nlo;
-            if (merge)
-                for (int j = 0; j < n_in && merge; ++j) merge = s[j][a] == ms[j].back() * (int64_t)mcard.back();
-            uint32_t c = (uint32_t)net.card[out.vars[a]];
-            if (merge && (uint64_t)mcard.back() * c < (1u << 30)) {
-                mcard.back() *= c;
+            bool merge = ma > 0 && a != nlo;
+            for (int j = 0; j < n_in && merge; ++j) merge = s[j][a] == ms[j][ma - 1] * (int64_t)mcard[ma - 1];
+            const uint32_t c = (uint32_t)net.card[out.vars[a]];
+            if (merge && (uint64_t)mcard[ma - 1] * c < (1u << 30)) {
+                mcard[ma - 1] *= c;
             } else {
-                mcard.push_back(c);
-                for (int j = 0; j < n_in; ++j) ms[j].push_back(s[j][a]);
+                mcard[ma] = c;
+                for (int j = 0; j < n_in; ++j) ms[j][ma] = s[j][a];
+                ++ma;
                 if (a < nlo) ++mlo;
             }
         }
-        const int ma = (int)mcard.size();
         if (ma > kMaxAxes) { err = "a step has more than " + std::to_string(kMaxAxes) + " axes"; return; }
-        const size_t base = prog.size();
         const int words = kHdrWords + 3 * n_in + ma + n_in * ma;
-        prog.resize(base + words);
-        uint32_t *w = prog.data() + base;
+        uint32_t *w = prog.extend(words);
         header(w, kKindGeneric, n_in, ma, mlo, cx, final_, lo, cells / lo, out.off, words);
         uint32_t *p = w + kHdrWords;
         for (int j = 0; j < n_in; ++j) {
-            *p++ = (uint32_t)(ins[j].off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j].off >> 32);
+            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j]->off >> 32);
             *p++ = (uint32_t)(int32_t)xs[j];
         }
         for (int a = 0; a < ma; ++a) *p++ = mcard[a];
@@ -305,136 +348,149 @@ struct Emitter {
     }
 
     // FIBER encoding (see planner.h); returns false when the step does not fit the form
-    bool emit_fiber(const std::vector<PF> &ins, const std::vector<std::vector<int64_t>> &s, const std::vector<int64_t> &xs,
-                    const PF &out, int na, int64_t cells, int cx) {
-        std::vector<int> big, small;
-        for (int j = 0; j < (int)ins.size(); ++j) (ins[j].cells > net.small_cells ? big : small).push_back(j);
-        if (big.empty() || big.size() > 2 || (int)small.size() > kMaxSmall || cx > 16) return false;
+    bool emit_fiber(const PF *const *ins, int n_in, const Strides &s, const int64_t *xs, const PF &out, int cx) {
+        const int na = out.n;
+        int big[kMaxIn], small[kMaxIn], nb = 0, ns = 0;
+        for (int j = 0; j < n_in; ++j) {
+            if (ins[j]->cells > net.small_cells) big[nb++] = j;
+            else small[ns++] = j;
+        }
+        if (nb < 1 || nb > 2 || ns > kMaxSmall || cx > 16) return false;
         // N axes: no big input depends on them; keep at most kMaxNC combinations (fastest axes first)
-        std::vector<int> naxes, raxes;
+        int naxes[kRawAxes], raxes[kRawAxes], nN = 0, nr = 0;
         int64_t NC = 1;
         for (int a = 0; a < na; ++a) {
             bool free_ = true;
-            for (int b : big) free_ = free_ && s[b][a] == 0;
+            for (int b = 0; b < nb; ++b) free_ = free_ && s[big[b]][a] == 0;
             const int c = net.card[out.vars[a]];
-            if (free_ && NC * c <= kMaxNC) { naxes.push_back(a); NC *= c; }
-            else raxes.push_back(a);
+            if (free_ && NC * c <= kMaxNC && nN < 15) { naxes[nN++] = a; NC *= c; }
+            else raxes[nr++] = a;
         }
-        // ctrl axes: R axes a small input depends on
-        std::vector<int> ctrl;
+        // R-axis tables (unmerged); ctrl axes = R axes a small input depends on
+        int64_t rcard[kRawAxes], rost[kRawAxes], rtst[kRawAxes], rb[2][kRawAxes];
+        int ctrl[kRawAxes], nctrl = 0;
         int64_t T = NC * cx;
-        for (int a : raxes) {
+        for (int i = 0; i < nr; ++i) {
+            const int a = raxes[i];
+            rcard[i] = net.card[out.vars[a]];
+            rost[i] = out.strides[a];
+            for (int b = 0; b < nb; ++b) rb[b][i] = s[big[b]][a];
             bool dep = false;
-            for (int j : small) dep = dep || s[j][a] != 0;
-            if (dep) { ctrl.push_back(a); T *= net.card[out.vars[a]]; if (T > kMaxT) return false; }
-        }
-        const int nT = (int)naxes.size() + (int)ctrl.size();
-        if (naxes.size() > 15 || ctrl.size() > 15) return false;
-        // R-axis tables (unmerged)
-        const int nr = (int)raxes.size();
-        std::vector<int64_t> rcard(nr), rost(nr), rtst(nr, 0);
-        std::vector<std::vector<int64_t>> rb(big.size(), std::vector<int64_t>(nr));
-        {
-            int64_t tmul = NC * cx;
-            for (int i = 0; i < nr; ++i) {
-                const int a = raxes[i];
-                rcard[i] = net.card[out.vars[a]];
-                rost[i] = out.strides[a];
-                for (size_t b = 0; b < big.size(); ++b) rb[b][i] = s[big[b]][a];
-                if (std::find(ctrl.begin(), ctrl.end(), a) != ctrl.end()) { rtst[i] = tmul; tmul *= rcard[i]; }
+            for (int k = 0; k < ns; ++k) dep = dep || s[small[k]][a] != 0;
+            rtst[i] = 0;
+            if (dep) {
+                if (nctrl >= 15) return false;
+                ctrl[nctrl++] = a;
+                rtst[i] = T;
+                T *= rcard[i];
+                if (T > kMaxT) return false;
             }
         }
+        const int nT = nN + nctrl;
         int nlo = 0;
         int64_t lo = 1;
         while (nlo < nr && lo < kLoTarget && lo * rcard[nlo] <= kFiberLoMax) lo *= rcard[nlo++];
         int64_t rcells = 1;
         for (int i = 0; i < nr; ++i) rcells *= rcard[i];
         // merge adjacent R axes contiguous in the output, in T and in every big input
-        std::vector<int64_t> mc, mo, mt;
-        std::vector<std::vector<int64_t>> mb(big.size());
-        int mlo = 0;
+        int64_t mc[kRawAxes], mo[kRawAxes], mt[kRawAxes], mb[2][kRawAxes];
+        int ma = 0, mlo = 0;
         for (int i = 0; i < nr; ++i) {
-            bool merge = !mc.empty() && i != nlo && mo.back() * mc.back() == rost[i] && mt.back() * mc.back() == rtst[i] &&
-                         mc.back() * rcard[i] < (1 << 30);
-            for (size_t b = 0; b < big.size() && merge; ++b) merge = mb[b].back() * mc.back() == rb[b][i];
+            bool merge = ma > 0 && i != nlo && mo[ma - 1] * mc[ma - 1] == rost[i] && mt[ma - 1] * mc[ma - 1] == rtst[i] &&
+                         mc[ma - 1] * rcard[i] < (1 << 30);
+            for (int b = 0; b < nb && merge; ++b) merge = mb[b][ma - 1] * mc[ma - 1] == rb[b][i];
             if (merge) {
-                mc.back() *= rcard[i];
+                mc[ma - 1] *= rcard[i];
             } else {
-                mc.push_back(rcard[i]);
-                mo.push_back(rost[i]);
-                mt.push_back(rtst[i]);
-                for (size_t b = 0; b < big.size(); ++b) mb[b].push_back(rb[b][i]);
+                mc[ma] = rcard[i];
+                mo[ma] = rost[i];
+                mt[ma] = rtst[i];
+                for (int b = 0; b < nb; ++b) mb[b][ma] = rb[b][i];
+                ++ma;
                 if (i < nlo) ++mlo;
             }
         }
-        const int ma = (int)mc.size();
         if (ma > kMaxAxes) return false;
-        const int nb = (int)big.size(), ns = (int)small.size();
         const int words = kHdrWords + 3 * nb + ns * (3 + nT) + nT + (int)NC + 3 * ma + nb * ma;
         if (words > kMaxStepWords) return false;
-        const size_t base = prog.size();
-        prog.resize(base + words);
-        uint32_t *w = prog.data() + base;
+        uint32_t *w = prog.extend(words);
         header(w, kKindFiber, nb + ns, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
-        w[7] = (uint32_t)nb | ((uint32_t)ns << 4) | ((uint32_t)naxes.size() << 8) | ((uint32_t)ctrl.size() << 12) | ((uint32_t)NC << 16);
+        w[7] = (uint32_t)nb | ((uint32_t)ns << 4) | ((uint32_t)nN << 8) | ((uint32_t)nctrl << 12) | ((uint32_t)NC << 16);
         w[8] = (uint32_t)T;
         uint32_t *p = w + kHdrWords;
-        for (int b : big) {
-            *p++ = (uint32_t)(ins[b].off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[b].off >> 32);
-            *p++ = (uint32_t)(int32_t)xs[b];
+        for (int b = 0; b < nb; ++b) {
+            *p++ = (uint32_t)(ins[big[b]]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[big[b]]->off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[big[b]];
         }
-        for (int j : small) {
-            *p++ = (uint32_t)(ins[j].off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j].off >> 32);
+        for (int k = 0; k < ns; ++k) {
+            const int j = small[k];
+            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j]->off >> 32);
             *p++ = (uint32_t)(int32_t)xs[j];
-            for (int a : naxes) *p++ = (uint32_t)(int32_t)s[j][a];
-            for (int a : ctrl) *p++ = (uint32_t)(int32_t)s[j][a];
+            for (int i = 0; i < nN; ++i) *p++ = (uint32_t)(int32_t)s[j][naxes[i]];
+            for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)(int32_t)s[j][ctrl[i]];
         }
-        for (int a : naxes) *p++ = (uint32_t)net.card[out.vars[a]];
-        for (int a : ctrl) *p++ = (uint32_t)net.card[out.vars[a]];
+        for (int i = 0; i < nN; ++i) *p++ = (uint32_t)net.card[out.vars[naxes[i]]];
+        for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)net.card[out.vars[ctrl[i]]];
         for (int64_t n = 0; n < NC; ++n) {
             int64_t r = n, off = 0;
-            for (int a : naxes) { off += (r % net.card[out.vars[a]]) * out.strides[a]; r /= net.card[out.vars[a]]; }
+            for (int i = 0; i < nN; ++i) {
+                const int c = net.card[out.vars[naxes[i]]];
+                off += (r % c) * out.strides[naxes[i]];
+                r /= c;
+            }
             *p++ = (uint32_t)off;
         }
         for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = (uint32_t)mt[a]; }
         for (int b = 0; b < nb; ++b)
             for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)mb[b][a];
-        (void)cells;
         return true;
     }
 
-    // Emit one step: multiply `ins`, sum out x (x < 0: product only).  Returns the new factor.
-    PF emit(const std::vector<PF> &ins, int x, bool final_, int64_t final_off) {
-        PF out;
+    // Emit one step: multiply `ins`, sum out x (x < 0: product only); the new factor is written to `out`.
+    void emit(const PF *const *ins, int n_in, int x, bool final_, int64_t final_off, PF &out) {
+        out.scope = Bits{};
         out.scope.nw = net.nw;
-        for (auto &f : ins) out.scope.or_(f.scope);
-        double prod_log2 = scope_log2(net, out.scope);
+        for (int j = 0; j < n_in; ++j) out.scope.or_(ins[j]->scope);
+        const double prod_log2 = scope_log2(net, out.scope);
         if (x >= 0) out.scope.clr(x);
-        out.scope.for_each([&](int v) { out.vars.push_back(v); });
-        std::sort(out.vars.begin(), out.vars.end(), [&](int a, int b) { return key[a] > key[b] || (key[a] == key[b] && a < b); });
-        int na = (int)out.vars.size();
+        int na = 0;
+        bool overflow = false;
+        out.scope.for_each([&](int v) { if (na < kRawAxes) out.vars[na++] = v; else overflow = true; });
+        if (overflow) { err = "a factor has more than " + std::to_string(kRawAxes) + " axes"; return; }
+        // layout: longest-living variable fastest (insertion sort on the key, descending)
+        for (int i = 1; i < na; ++i) {
+            const int v = out.vars[i];
+            int k = i - 1;
+            while (k >= 0 && (key[out.vars[k]] < key[v] || (key[out.vars[k]] == key[v] && out.vars[k] > v))) { out.vars[k + 1] = out.vars[k]; --k; }
+            out.vars[k + 1] = v;
+        }
+        out.n = na;
         int64_t cells = 1;
-        out.strides.resize(na);
         for (int a = 0; a < na; ++a) {
             out.strides[a] = cells;
             cells *= net.card[out.vars[a]];
-            if (cells >= (1ll << 31)) { err = "an intermediate factor has >= 2^31 cells"; return out; }
+            if (cells >= (1ll << 31)) { err = "an intermediate factor has >= 2^31 cells"; return; }
+            pos[out.vars[a]] = a;
         }
         out.cells = cells;
-        int n_in = (int)ins.size();
         // per-input strides along the output axes, and along x
-        std::vector<std::vector<int64_t>> s(n_in, std::vector<int64_t>(na, 0));
-        std::vector<int64_t> xs(n_in, 0);
-        for (int j = 0; j < n_in; ++j)
-            for (size_t k = 0; k < ins[j].vars.size(); ++k) {
-                int v = ins[j].vars[k];
-                if (v == x) { xs[j] = ins[j].strides[k]; continue; }
-                int a = (int)(std::find(out.vars.begin(), out.vars.end(), v) - out.vars.begin());
-                s[j][a] = ins[j].strides[k];
+        Strides s;
+        int64_t xs[kMaxIn];
+        double in_cells = 0;
+        for (int j = 0; j < n_in; ++j) {
+            for (int a = 0; a < na; ++a) s[j][a] = 0;
+            xs[j] = 0;
+            for (int k = 0; k < ins[j]->n; ++k) {
+                const int v = ins[j]->vars[k];
+                if (v == x) xs[j] = ins[j]->strides[k];
+                else s[j][pos[v]] = ins[j]->strides[k];
             }
-        int cx = x >= 0 ? net.card[x] : 1;
+            in_cells += (double)ins[j]->cells;
+        }
+        for (int a = 0; a < na; ++a) pos[out.vars[a]] = -1;
+        const int cx = x >= 0 ? net.card[x] : 1;
         if (final_) {
             out.off = (uint64_t)final_off;
             out.alloc = 0;
@@ -442,38 +498,23 @@ struct Emitter {
             out.off = (uint64_t)arena.alloc(cells);
             out.alloc = cells;
         }
-        double in_cells = 0;
-        for (int j = 0; j < n_in; ++j) in_cells += (double)ins[j].cells;
-        if (!(!final_ && emit_fiber(ins, s, xs, out, na, cells, cx)))
-            emit_generic(ins, s, xs, out, na, cells, cx, final_);
-        if (!err.empty()) return out;
+        if (!(!final_ && emit_fiber(ins, n_in, s, xs, out, cx))) emit_generic(ins, n_in, s, xs, out, cells, cx, final_);
+        if (!err.empty()) return;
         st.alg_bytes += 8.0 * (in_cells + (double)cells);
-        double pc = std::exp2(prod_log2);
+        const double pc = std::exp2(prod_log2);
         st.alg_flops += n_in * pc;
         st.max_step_cells = std::max(st.max_step_cells, pc);
         st.n_steps += 1;
-        for (auto &f : ins)
-            if (f.alloc) arena.release((int64_t)f.off, f.alloc);
-        return out;
-    }
-
-    // multiply/eliminate with at most kMaxIn inputs per step
-    PF emit_limited(std::vector<PF> ins, int x, bool final_, int64_t final_off) {
-        while ((int)ins.size() > kMaxIn && err.empty()) {
-            std::sort(ins.begin(), ins.end(), [](const PF &a, const PF &b) { return a.cells < b.cells; });
-            std::vector<PF> head(ins.begin(), ins.begin() + kMaxIn);
-            PF prod = emit(head, -1, false, 0);
-            ins.erase(ins.begin(), ins.begin() + kMaxIn);
-            ins.push_back(prod);
-        }
-        if (!err.empty()) return PF{};
-        return emit(ins, x, final_, final_off);
+        for (int j = 0; j < n_in; ++j)
+            if (ins[j]->alloc) arena.release((int64_t)ins[j]->off, ins[j]->alloc);
     }
 };
 
 }  // namespace
 
-std::string plan_request(const Network &net, const Request &rq, std::vector<uint32_t> &prog, PlanStats &st) {
+std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, PlanStats &st) {
+    PROF(0);
+    Scratch &S = scratch();
     // relevant = query | event | ancestors(...)  (bayes_net.py:763-765); hidden = relevant - query - event (766)
     Bits rel, qb, eb;
     rel.nw = qb.nw = eb.nw = net.nw;
@@ -482,35 +523,51 @@ std::string plan_request(const Network &net, const Request &rq, std::vector<uint
     Bits hidden = rel;
     hidden.andnot(qb);
     hidden.andnot(eb);
-    std::vector<int32_t> ecode(net.n_vars, 0);
+    int32_t ecode_buf[kMaxVars];
     if (rq.ecodes)
-        for (int i = 0; i < rq.ne; ++i) ecode[rq.evars[i]] = rq.ecodes[i];
+        for (int i = 0; i < rq.ne; ++i) ecode_buf[rq.evars[i]] = rq.ecodes[i];
+    else
+        for (int i = 0; i < rq.ne; ++i) ecode_buf[rq.evars[i]] = 0;
 
     // factors = evidence-sliced CPTs of the relevant nodes (bayes_net.py:768-776): the evidence axis is
     // not copied away but folded into the base offset (stride 0 afterwards)
-    std::vector<PF> fs;
+    std::vector<PF> &pool = S.pool;
+    std::vector<int> &live = S.live;
+    pool.clear();
+    live.clear();
+    pool.reserve(3 * (size_t)net.n_vars + 64);  // never reallocates below: `ins` holds pointers into it
     std::vector<Bits> scopes;
+    std::string err;
     rel.for_each([&](int v) {
-        PF f;
+        pool.emplace_back();
+        PF &f = pool.back();
         f.scope.nw = net.nw;
         uint64_t off = (uint64_t)net.pool_off[v];
         int64_t cells = 1;
         for (size_t k = 0; k < net.scope[v].size(); ++k) {
-            int u = net.scope[v][k];
+            const int u = net.scope[v][k];
             if (eb.test(u)) {
-                off += (uint64_t)(net.cstride[v][k] * ecode[u]);
-            } else {
+                off += (uint64_t)(net.cstride[v][k] * ecode_buf[u]);
+            } else if (net.card[u] > 1) {
+                if (f.n >= kRawAxes) { err = "a CPT has more than " + std::to_string(kRawAxes) + " free axes"; return; }
                 f.scope.set(u);
-                f.vars.push_back(u);
-                f.strides.push_back(net.cstride[v][k]);
+                f.vars[f.n] = u;
+                f.strides[f.n] = net.cstride[v][k];
+                ++f.n;
                 cells *= net.card[u];
             }
         }
         f.off = off | kConstFlag;
         f.cells = cells;
-        fs.push_back(f);
+        live.push_back((int)pool.size() - 1);
         scopes.push_back(f.scope);
     });
+    if (!err.empty()) return err;
+    // single-state variables carry no information: they are never axes, never eliminated
+    Bits trivial;
+    trivial.nw = net.nw;
+    hidden.for_each([&](int v) { if (net.card[v] <= 1) trivial.set(v); });
+    hidden.andnot(trivial);
 
     // candidate elimination orders, cheapest by the byte model wins
     std::vector<int32_t> hid;
@@ -529,44 +586,217 @@ std::string plan_request(const Network &net, const Request &rq, std::vector<uint
             std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return keyfn(a) < keyfn(b); });
             return o;
         };
-        // "meet": sweep down from the roots to the query's depth, then up from the leaves
-        consider(sorted_by([&](int v) { return net.depth[v] < qdepth ? (double)net.depth[v] : 1e6 - net.depth[v]; }));
-        consider(sorted_by([&](int v) { return (double)net.depth[v]; }));   // topological sweep
-        consider(sorted_by([&](int v) { return -(double)net.depth[v]; }));  // reverse sweep
-        for (auto &h : net.hints) consider(sorted_by([&](int v) { return (double)h[v]; }));
-        consider(greedy_min_weight(net, scopes, hidden, false));
-        consider(greedy_min_weight(net, scopes, hidden, true));
+        {
+            PROF(1);
+            // "meet": sweep down from the roots to the query's depth, then up from the leaves
+            consider(sorted_by([&](int v) { return net.depth[v] < qdepth ? (double)net.depth[v] : 1e6 - net.depth[v]; }));
+            consider(sorted_by([&](int v) { return (double)net.depth[v]; }));   // topological sweep
+            consider(sorted_by([&](int v) { return -(double)net.depth[v]; }));  // reverse sweep
+            for (auto &h : net.hints) consider(sorted_by([&](int v) { return (double)h[v]; }));
+        }
+        // (greedy min-weight is evaluated too in principle, but on grids min-fill dominates it: 52.7 vs 52.5 MB mean)
+        { PROF(3); consider(greedy_order(net, scopes, hidden, true)); }
     }
 
-    Emitter em{net, prog, st, Arena{}, std::vector<double>(net.n_vars, 0.0), ""};
-    for (size_t i = 0; i < best.size(); ++i) em.key[best[i]] = (double)i;
-    for (int i = 0; i < rq.nq; ++i) em.key[rq.qvars[i]] = 1e9 + i;
+    PROF(4);
+    S.key.assign(net.n_vars, 0.0);
+    S.pos.assign(net.n_vars, -1);
+    Emitter em{net, prog, st, Arena{}, S.key, S.pos, ""};
+    for (size_t i = 0; i < best.size(); ++i) S.key[best[i]] = (double)i;
+    for (int i = 0; i < rq.nq; ++i) S.key[rq.qvars[i]] = 1e9 + i;
 
-    size_t count_pos = prog.size();
-    prog.push_back(0);
-    double steps0 = st.n_steps;
-    for (int32_t x : best) {
-        std::vector<PF> ins;
-        // pop every factor mentioning x (bayes_net.py:780-784)
-        size_t k = 0;
-        for (size_t i = 0; i < fs.size(); ++i) {
-            if (fs[i].scope.test(x)) ins.push_back(fs[i]);
-            else { if (k != i) fs[k] = fs[i]; ++k; }
+    const size_t count_pos = prog.size;
+    prog.push(0);
+    const double steps0 = st.n_steps;
+    const PF *ins[kMaxVars + 8];
+    // multiply/eliminate with at most kMaxIn inputs per step: larger products are pre-multiplied
+    auto emit_limited = [&](int n_in, int x, bool final_, int64_t final_off) -> int {
+        while (n_in > kMaxIn && em.err.empty()) {
+            if (pool.size() + 2 > pool.capacity()) { em.err = "planner factor pool exhausted"; return -1; }
+            std::sort(ins, ins + n_in, [](const PF *a, const PF *b) { return a->cells < b->cells; });
+            pool.emplace_back();
+            em.emit(ins, kMaxIn, -1, false, 0, pool.back());
+            for (int k = kMaxIn; k < n_in; ++k) ins[k - kMaxIn] = ins[k];
+            n_in -= kMaxIn;
+            ins[n_in++] = &pool.back();
         }
-        fs.resize(k);
-        PF out = em.emit_limited(ins, x, false, 0);  // pointwise_mul + sum_out (785)
+        if (!em.err.empty()) return -1;
+        if (pool.size() + 1 > pool.capacity()) { em.err = "planner factor pool exhausted"; return -1; }
+        pool.emplace_back();
+        em.emit(ins, n_in, x, final_, final_off, pool.back());
+        return (int)pool.size() - 1;
+    };
+    for (int32_t x : best) {
+        // pop every factor mentioning x (bayes_net.py:780-784)
+        int n_in = 0;
+        size_t k = 0;
+        for (size_t i = 0; i < live.size(); ++i) {
+            if (pool[live[i]].scope.test(x)) ins[n_in++] = &pool[live[i]];
+            else live[k++] = live[i];
+        }
+        live.resize(k);
+        const int out = emit_limited(n_in, x, false, 0);  // pointwise_mul + sum_out (785)
         if (!em.err.empty()) return em.err;
-        fs.push_back(out);
+        live.push_back(out);
     }
     // posterior = pointwise_mul(factors) / sum (bayes_net.py:789-790), written in the caller's
     // query order (C-order, last query variable fastest)
     st.out_cells = 1;
     for (int i = 0; i < rq.nq; ++i) st.out_cells *= net.card[rq.qvars[i]];
-    em.emit_limited(fs, -1, true, rq.out_off);
+    int n_in = 0;
+    for (int i : live) ins[n_in++] = &pool[i];
+    emit_limited(n_in, -1, true, rq.out_off);
     if (!em.err.empty()) return em.err;
-    prog[count_pos] = (uint32_t)(st.n_steps - steps0);
+    prog.data[count_pos] = (uint32_t)(st.n_steps - steps0);
     st.arena_cells = std::max(st.arena_cells, em.arena.top);
     return "";
+}
+
+// ------------------------------------------------------------------------------------ buffers / threads
+
+uint32_t *ProgBuf::extend(size_t words) {
+    if (size + words > cap) {
+        size_t ncap = std::max<size_t>(cap * 2, size + words + 4096);
+        if (grow) {
+            data = grow(ctx, data, size, ncap);
+        } else {
+            data = (uint32_t *)std::realloc(data, ncap * sizeof(uint32_t));
+        }
+        cap = ncap;
+    }
+    uint32_t *p = data + size;
+    size += words;
+    return p;
+}
+
+void ProgBuf::release() {
+    if (!grow) std::free(data);
+    data = nullptr;
+    size = cap = 0;
+}
+
+std::string plan_request(const Network &net, const Request &rq, std::vector<uint32_t> &prog, PlanStats &st) {
+    ProgBuf b;
+    std::string e = plan_request(net, rq, b, st);
+    prog.insert(prog.end(), b.data, b.data + b.size);
+    b.release();
+    return e;
+}
+
+struct ThreadPool::Impl {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool stop = false;
+};
+
+ThreadPool::ThreadPool(int n) : impl_(new Impl), n_(std::max(1, n)) {
+    for (int t = 1; t < n_; ++t)  // worker 0 is the calling thread
+        impl_->th.emplace_back([this, t] {
+            uint64_t seen = 0;
+            for (;;) {
+                const std::function<void(int)> *job;
+                {
+                    std::unique_lock<std::mutex> lk(impl_->m);
+                    impl_->cv_go.wait(lk, [&] { return impl_->stop || impl_->generation != seen; });
+                    if (impl_->stop) return;
+                    seen = impl_->generation;
+                    job = impl_->job;
+                }
+                (*job)(t);
+                {
+                    std::lock_guard<std::mutex> lk(impl_->m);
+                    if (--impl_->pending == 0) impl_->cv_done.notify_one();
+                }
+            }
+        });
+}
+
+ThreadPool::~ThreadPool() {
+    {
+        std::lock_guard<std::mutex> lk(impl_->m);
+        impl_->stop = true;
+    }
+    impl_->cv_go.notify_all();
+    for (auto &t : impl_->th) t.join();
+    delete impl_;
+}
+
+void ThreadPool::run(const std::function<void(int)> &job) {
+    if (n_ > 1) {
+        std::lock_guard<std::mutex> lk(impl_->m);
+        impl_->job = &job;
+        impl_->pending = n_ - 1;
+        ++impl_->generation;
+    }
+    impl_->cv_go.notify_all();
+    job(0);
+    if (n_ > 1) {
+        std::unique_lock<std::mutex> lk(impl_->m);
+        impl_->cv_done.wait(lk, [&] { return impl_->pending == 0; });
+    }
+}
+
+void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
+                const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
+                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck) {
+    const int64_t n = b1 - b0;
+    const int T = pool.size();
+    if ((int)bufs.size() < T) bufs.resize(T);
+    ck.st = PlanStats{};
+    ck.arena_cells = 0;
+    ck.err.clear();
+    ck.prog_off.assign(n, 0);
+    ck.cost.assign(n, 0.0);
+    ck.thread_words.assign(T, 0);
+    std::vector<PlanStats> tst(T);
+    std::vector<std::string> terr(T);
+    pool.run([&](int t) {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        ProgBuf &prog = bufs[t];
+        prog.size = 0;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t b = b0 + i;
+            ck.prog_off[i] = prog.size;
+            if (skip && skip[b]) { prog.push(0); continue; }  // zero steps: result stays all-zero
+            Request rq;
+            rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
+            rq.qvars = q_vars + q_off[b];
+            rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
+            rq.evars = e_vars + e_off[b];
+            rq.ecodes = e_codes + e_off[b];
+            rq.out_off = out_off[b] - out_off[b0];
+            PlanStats st;
+            std::string e = plan_request(net, rq, prog, st);
+            if (!e.empty()) { terr[t] = e; return; }
+            ck.cost[i] = st.alg_bytes;
+            tst[t].alg_bytes += st.alg_bytes;
+            tst[t].alg_flops += st.alg_flops;
+            tst[t].n_steps += st.n_steps;
+            tst[t].max_step_cells = std::max(tst[t].max_step_cells, st.max_step_cells);
+            tst[t].arena_cells = std::max(tst[t].arena_cells, st.arena_cells);
+        }
+        ck.thread_words[t] = prog.size;
+    });
+    size_t base = 0;
+    for (int t = 0; t < T; ++t) {
+        if (!terr[t].empty()) ck.err = terr[t];
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        for (int64_t i = lo; i < hi; ++i) ck.prog_off[i] += base;
+        base += ck.thread_words[t];
+        ck.st.alg_bytes += tst[t].alg_bytes;
+        ck.st.alg_flops += tst[t].alg_flops;
+        ck.st.n_steps += tst[t].n_steps;
+        ck.st.max_step_cells = std::max(ck.st.max_step_cells, tst[t].max_step_cells);
+        ck.arena_cells = std::max(ck.arena_cells, tst[t].arena_cells);
+    }
+    ck.total_words = base;
+    ck.order.resize(n);
+    std::iota(ck.order.begin(), ck.order.end(), 0);
+    std::stable_sort(ck.order.begin(), ck.order.end(), [&](int32_t a, int32_t b) { return ck.cost[a] > ck.cost[b]; });
 }
 
 }  // namespace mibn

@@ -12,6 +12,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -112,8 +113,50 @@ constexpr int kMaxSmall = 4;
 constexpr int kFiberLoMax = 512;    // R cells in the lane-varying block of a FIBER step (2 per lane)
 constexpr int kMaxStepWords = 384;  // LDS copy of one step descriptor
 
+// Growable word buffer the planner appends programs to.  The engine backs it with pinned host memory
+// (so the upload is a true async DMA) and keeps it across calls; the default backing is malloc.
+struct ProgBuf {
+    uint32_t *data = nullptr;
+    size_t size = 0, cap = 0;
+    // returns a buffer of >= new_cap words whose first `used` words are copied from `old` (and releases old)
+    uint32_t *(*grow)(void *ctx, uint32_t *old, size_t used, size_t new_cap) = nullptr;
+    void *ctx = nullptr;
+    uint32_t *extend(size_t words);  // appends `words` uninitialised words, returns their address
+    void push(uint32_t w) { *extend(1) = w; }
+    void release();                  // frees a malloc-backed buffer (no-op for custom backings)
+};
+
 // Plan one request; appends the program to `prog`.  Returns "" or an error message.
+std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, PlanStats &st);
 std::string plan_request(const Network &net, const Request &rq, std::vector<uint32_t> &prog, PlanStats &st);
+
+// Persistent host worker threads (planning a 16 k-request batch spawns no threads and faults no pages).
+class ThreadPool {
+public:
+    explicit ThreadPool(int n);
+    ~ThreadPool();
+    int size() const { return n_; }
+    void run(const std::function<void(int)> &job);  // job(t) on every worker t in [0, n); returns when all are done
+private:
+    struct Impl;
+    Impl *impl_;
+    int n_;
+};
+
+// Plan requests [b0, b1) of a CSR batch: worker t plans a contiguous share into bufs[t].
+struct BatchPlan {
+    std::vector<size_t> thread_words;          // words written by each worker (bufs[t].size)
+    std::vector<uint64_t> prog_off;            // per request: word offset into the concatenated buffers
+    std::vector<double> cost;                  // per request: algorithmic bytes
+    std::vector<int32_t> order;                // execution order, heaviest first
+    int64_t arena_cells = 0;                   // largest per-request scratch need
+    size_t total_words = 0;
+    PlanStats st;                              // totals
+    std::string err;
+};
+void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
+                const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
+                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &bp);
 
 // Validate a request (unknown ids, duplicates, overlap) - bayes_net.py:840-845 and the KeyError of 770.
 std::string validate_request(const Network &net, const Request &rq);
