@@ -30,39 +30,53 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# HBM bytes per launch from the rocprofv3 PMC passes (profiles/): not measurable inside this process,
+# so the bench reports null; the committed profile summary holds the measured value.
+TRAFFIC_NOTE = None
 
 
-def cpu_baseline(spec, qv, ev, ec, gpu_post, budget_s):
+def cpu_baseline(spec, qv, ev, ec, gpu_post, budget_s, max_rows=3e7):
     """Time the C oracle (oracle/ve_oracle.c, kind="port": sparse-table VE restating
-    bayes_net.py:739-794 with ascending-id elimination, the order the hash-ordered reference uses) on
-    the first requests of the stream until `budget_s` seconds are spent; also returns the max-abs
-    marginal error of the GPU posteriors on that sample."""
+    bayes_net.py:739-794, eliminating in ascending-name = row-major order like the hash-ordered
+    reference) on the first requests of the stream until `budget_s` seconds are spent; also returns the
+    max-abs marginal error of the GPU posteriors on that sample.  Requests whose row-major product
+    would exceed `max_rows` rows (minutes each on the CPU; the reference needs 448 s for the worst
+    one) are skipped and counted - so the CPU figure is optimistic."""
+    import netspec
     from oracle.oracle import OracleNet
 
     on = OracleNet(spec)
     oid = np.array([on.id[f"{i:03d}"] for i in range(len(on.names))], np.int32)  # grid id -> oracle id
-    prio = np.empty(len(on.names), np.int32)  # eliminate in ascending *name* order (row-major), like
-    prio[oid] = np.arange(len(on.names), dtype=np.int32)  # the hash-ordered reference (oracle/refload.py)
+    prio = np.empty(len(on.names), np.int32)
+    prio[oid] = np.arange(len(on.names), dtype=np.int32)
     t0 = time.perf_counter()
-    n, err = 0, 0.0
-    while n < len(qv) and time.perf_counter() - t0 < budget_s:
-        codes, vals = on.query_codes([int(oid[qv[n]])], oid[ev[n]].tolist(), ec[n].tolist(), order=prio)
-        dense = np.zeros(int(on.card[int(oid[qv[n]])]))
+    n = skipped = i = 0
+    err = 0.0
+    while i < len(qv) and time.perf_counter() - t0 < budget_s:
+        if netspec.grid_row_major_cost(qv[i], ev[i], 10, 10, 4)[0] > max_rows:
+            skipped += 1
+            i += 1
+            continue
+        codes, vals = on.query_codes([int(oid[qv[i]])], oid[ev[i]].tolist(), ec[i].tolist(), order=prio)
+        dense = np.zeros(int(on.card[int(oid[qv[i]])]))
         dense[codes[:, 0]] = vals
-        err = max(err, float(np.max(np.abs(dense - gpu_post[n]))))
+        err = max(err, float(np.max(np.abs(dense - gpu_post[i]))))
         n += 1
+        i += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} requests of the C3 stream (rng seed 1), {dt:.1f} s, "
-                      "oracle/ve_oracle.c single thread, row-major (ascending name) elimination order"}, err
+    return {"value": n / dt if n else 0.0, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the first {n + skipped} requests of the C3 stream (rng seed 1) in {dt:.1f} s; the other "
+                      f"{skipped} (> {max_rows:.0e} row-major product rows, minutes each on a CPU core) were not run, so "
+                      "the figure is an upper bound for the whole stream; oracle/ve_oracle.c, single thread, "
+                      "row-major (ascending name) elimination order like the hash-ordered reference"}, err
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16384, help="requests per step per GPU")
+    ap.add_argument("--batch", type=int, default=32768, help="requests per step per GPU")
     ap.add_argument("--n-evidence", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -173,6 +187,7 @@ def main():
             lo = first_lo
             cb, err = cpu_baseline(spec, qv[lo:lo + a.batch], ev[lo:lo + a.batch], ec[lo:lo + a.batch],
                                    first_post, a.cpu_seconds)
+            out["roofline"]["traffic"] = TRAFFIC_NOTE
             out["cpu_baseline"] = cb
             out["max_abs_marginal_err_vs_oracle"] = err
         print(json.dumps(out), flush=True)

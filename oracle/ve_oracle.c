@@ -199,7 +199,7 @@ static int sum_out(const int32_t *card, const factor *in, int32_t x, factor *out
         if (i != px) {
             pos[k++] = i;
             keyspace *= card[in->vars[i]];
-            if (keyspace > ((int64_t)1 << 27)) return VE_ERR_KEYSPACE;
+            if (keyspace > ((int64_t)1 << 29)) return VE_ERR_KEYSPACE;
         }
     double *sum = (double *)calloc((size_t)keyspace, sizeof(double));
     double *comp = (double *)calloc((size_t)keyspace, sizeof(double));

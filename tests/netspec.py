@@ -192,6 +192,30 @@ def c3_requests(n_nodes, K, n, n_evidence=4, seed=1, start=0):
     return q[start:], ev[start:], ec[start:]
 
 
+def grid_row_major_cost(q, evs, R, C, K):
+    """Scope-only cost of eliminating a grid request in ascending-id (row-major) order, the order the
+    hash-ordered reference uses: returns (total product rows, largest product rows)."""
+    par = lambda v: ([v - C] if v >= C else []) + ([v - 1] if v % C else [])
+    evs = set(int(e) for e in evs)
+    rel, stack = set(), [int(q), *evs]
+    while stack:
+        v = stack.pop()
+        if v not in rel:
+            rel.add(v)
+            stack += par(v)
+    fs = [frozenset(u for u in par(v) + [v] if u not in evs) for v in rel]
+    total = biggest = 0
+    for x in sorted(rel - {int(q)} - evs):
+        ins = [s for s in fs if x in s]
+        fs = [s for s in fs if x not in s]
+        u = frozenset().union(*ins)
+        total += K ** len(u)
+        biggest = max(biggest, K ** len(u))
+        fs.append(u - {x})
+    u = frozenset().union(*fs)
+    return total + K ** len(u), max(biggest, K ** len(u))
+
+
 def asia_requests(node_names, n, seed=0):
     """The BASELINE C2 stream: query var uniform over the nodes, n_evidence uniform in {1,2,3} from
     the others, values uniform {False, True}.  Returns a list of (query name, {name: bool})."""
