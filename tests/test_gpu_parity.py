@@ -107,3 +107,53 @@ def test_c3_stream_vs_oracle(amd):
             break
     assert checked >= 50
     assert worst <= gu.TOL, worst
+
+
+def test_gibbs_matches_exact_posterior(amd):
+    """Config-5 style check on strictly positive CPTs (the reference's chain is reducible on
+    deterministic CPTs): pooled chain estimate vs the exact backend.  Parity
+    with the reference's stream is unpinned (vose absent), so the check is statistical."""
+    spec = netspec.grid_spec(4, 5, 3, seed=3)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    ev = {"000": 1, "019": 2, "007": 0}
+    for q in (("012",), ("009", "010")):
+        exact = bn.query(*q, event=ev)
+        n_chains, n_iter = 512, 4000
+        got = be.gibbs_sampling(*q, event=ev, n_iterations=n_iter, n_chains=n_chains, seed=11)
+        got = amd.BayesNet._finish(got, q)
+        assert got.index.equals(exact.index)
+        assert abs(got.sum() - 1.0) < 1e-12
+        # 2M correlated samples: 0.01 absolute is > 6 sigma even with an autocorrelation time of 50
+        assert float(np.max(np.abs(got.to_numpy() - exact.to_numpy()))) < 0.01
+    # different seeds give different streams, same seed the same counts
+    a = be.gibbs_sampling("012", event=ev, n_iterations=500, n_chains=64, seed=1)
+    b = be.gibbs_sampling("012", event=ev, n_iterations=500, n_chains=64, seed=1)
+    c = be.gibbs_sampling("012", event=ev, n_iterations=500, n_chains=64, seed=2)
+    assert a.equals(b) and not a.equals(c)
+
+
+def test_gibbs_through_query_api(amd):
+    """query(..., algorithm='gibbs', n_iterations=N): one chain like the reference (bayes_net.py:850-853),
+    returns value counts / N over the visited joint states."""
+    spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "sprinkler")["spec"]
+    bn = netspec.build(spec, amd.BayesNet)
+    ans = bn.query("Rain", event={"Sprinkler": True}, algorithm="gibbs", n_iterations=20000)
+    assert ans.name == "P(Rain)" and ans.index.name == "Rain" and ans.index.tolist() == [False, True]
+    assert abs(ans.sum() - 1.0) < 1e-12
+    assert abs(ans[False] - 0.7) < 0.03  # bayes_net.py:751-755: exact answer 0.7 / 0.3
+    many = bn.query("Rain", event={"Sprinkler": True}, algorithm="gibbs", n_iterations=2000, n_chains=256)
+    assert abs(many[False] - 0.7) < 0.01
+
+
+def test_config5_gibbs_50_nodes_8_states(amd):
+    """BASELINE config 5 at reduced length: 5x10 grid topology, K=8, query node 25, evidence nodes
+    {0, 9, 40, 49, 22}; 128 chains x 20k single-site updates vs the exact posterior."""
+    spec = netspec.grid_spec(5, 10, 8, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    rng = np.random.default_rng(1)
+    ev = {f"{n:03d}": int(rng.integers(0, 8)) for n in (0, 9, 40, 49, 22)}
+    exact = bn.query("025", event=ev)
+    got = bn.query("025", event=ev, algorithm="gibbs", n_iterations=20000, n_chains=128)
+    assert got.index.equals(exact.index)
+    assert float(np.max(np.abs(got.to_numpy() - exact.to_numpy()))) < 0.01
