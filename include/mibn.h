@@ -93,7 +93,7 @@ typedef struct mibn_stats {
     double alg_bytes;      /* sum over steps of 8*(sum input cells + output cells) */
     double alg_flops;      /* sum over steps of n_inputs * product-scope cells */
     double n_steps;        /* elimination + final product steps executed */
-    double kernel_ms;      /* HIP-event time of the VE kernel launches (sum) */
+    double kernel_ms;      /* HIP-event time of all kernel launches (sum over launches) */
     double plan_ms;        /* host planning wall time */
     double h2d_ms;         /* program upload */
     double d2h_ms;         /* result download */
@@ -101,9 +101,18 @@ typedef struct mibn_stats {
     double n_launches;     /* kernel launches */
     double arena_bytes;    /* device scratch arena in use */
     double max_step_cells; /* largest product scope of any step */
-    double n_workgroups;   /* persistent workgroups launched (last launch) */
+    double n_workgroups;   /* work items (= workgroups) launched */
 } mibn_stats;
 int mibn_last_stats(const mibn_t *h, mibn_stats *out);
+
+/* Per-kernel breakdown of the last mibn_query_batch call: HIP-event time on the library's stream and
+ * the section-8(d) algorithmic bytes of the steps each kernel executed (tiles pro rata).  Fills at most
+ * `cap` entries (one per kernel that ran), *n = number filled. */
+typedef struct mibn_kernel_stat {
+    char name[48];
+    double launches, ms, alg_bytes, items;
+} mibn_kernel_stat;
+int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n);
 
 /* Plan only (no device work): fills alg_bytes / alg_flops / n_steps / max_step_cells for one
  * request.  Also usable without a device through a context created by mibn_create_planner(). */

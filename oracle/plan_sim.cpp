@@ -12,6 +12,7 @@
 // no CPU fallback (mibn_query_batch fails without a gfx950 device).  Only tests/ may load it.
 #include <chrono>
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,10 +22,120 @@
 using namespace mibn;
 
 static std::string g_err;
-static int g_small_cells = 1024;
+static int g_small_cells = 1024, g_big_iters = 16384, g_tile_h = 128;
 extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
+extern "C" void plan_sim_set_tiling(int big_iters, int tile_h) { g_big_iters = big_iters; g_tile_h = tile_h; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
+
+// Execute iterations [h_begin, h_end) x lo_cells of one step (the whole step when the range covers hi_cells).
+// Mirrors generic_body / fiber_body of ve_kernel.hip.h with scalar loops.
+static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int64_t h_end, std::vector<double> &arena,
+                     int64_t arena_base, int64_t arena_cells, double *out) {
+    const uint32_t w0 = p[0];
+    const uint32_t kind = w0 & 0xff;
+    const int n_in = (w0 >> 8) & 0xff, na = (w0 >> 16) & 0xff;
+    const int cx = (int)(p[1] & 0xffff);
+    const bool fin = (p[1] >> 16) & 1;
+    const int64_t lo = p[2];
+    const uint64_t out_off = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
+    double *slot = arena.data() + arena_base;
+    double *outp = fin ? out + out_off : slot + out_off;
+    auto table = [&](uint64_t o) { return (o & kConstFlag) ? net.pool.data() + (o & ~kConstFlag) : slot + o; };
+    const int64_t it0 = h_begin * lo, it1 = h_end * lo;
+    if (kind == kKindGeneric) {
+        if (!fin && (int64_t)out_off + it1 > arena_cells) { g_err = "step writes outside its arena"; return -7; }
+        const double *inp[kMaxIn];
+        int xs[kMaxIn];
+        for (int j = 0; j < n_in; ++j) {
+            inp[j] = table((uint64_t)p[kHdrWords + 3 * j] | ((uint64_t)p[kHdrWords + 3 * j + 1] << 32));
+            xs[j] = (int)p[kHdrWords + 3 * j + 2];
+        }
+        const uint32_t *cd = p + kHdrWords + 3 * n_in;
+        const int32_t *strd = (const int32_t *)(cd + na);
+        std::vector<double> tmp((size_t)(it1 - it0));
+        for (int64_t o = it0; o < it1; ++o) {
+            int64_t r = o;
+            int64_t off[kMaxIn] = {0};
+            for (int a = 0; a < na; ++a) {
+                const int64_t d = r % cd[a];
+                r /= cd[a];
+                for (int j = 0; j < n_in; ++j) off[j] += d * strd[j * na + a];
+            }
+            double acc = 0.0;
+            for (int x = 0; x < cx; ++x) {
+                double v = 1.0;
+                for (int j = 0; j < n_in; ++j) v *= inp[j][off[j] + (int64_t)x * xs[j]];
+                acc += v;
+            }
+            tmp[(size_t)(o - it0)] = acc;
+        }
+        std::memcpy(outp + it0, tmp.data(), sizeof(double) * tmp.size());
+        return 0;
+    }
+    // FIBER
+    const int nb = p[7] & 0xf, ns = (p[7] >> 4) & 0xf, nN = (p[7] >> 8) & 0xf, nctrl = (p[7] >> 12) & 0xf;
+    const int NC = (int)(p[7] >> 16);
+    const int T = (int)p[8];
+    const int nT = nN + nctrl;
+    const uint32_t *q = p + kHdrWords;
+    const double *big[2];
+    int bxs[2];
+    for (int b = 0; b < nb; ++b) { big[b] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32)); bxs[b] = (int)q[2]; q += 3; }
+    const double *sm[kMaxSmall];
+    int sxs[kMaxSmall];
+    const int32_t *sts[kMaxSmall];
+    for (int j = 0; j < ns; ++j) {
+        sm[j] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32));
+        sxs[j] = (int)q[2];
+        sts[j] = (const int32_t *)(q + 3);
+        q += 3 + nT;
+    }
+    const uint32_t *tcard = q; q += nT;
+    const uint32_t *nout = q; q += NC;
+    const uint32_t *rax = q; q += 3 * na;   // card, ostride, tstride per R axis
+    const int32_t *bst = (const int32_t *)q;  // [b][a]
+    std::vector<double> Tt((size_t)T);
+    for (int t = 0; t < T; ++t) {
+        int r = t;
+        const int n = r % NC; r /= NC;
+        const int x = r % cx; r /= cx;
+        int64_t off[kMaxSmall] = {0};
+        int rn = n;
+        for (int k = 0; k < nN; ++k) { int d = rn % tcard[k]; rn /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
+        for (int k = nN; k < nT; ++k) { int d = r % tcard[k]; r /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
+        double v = 1.0;
+        for (int j = 0; j < ns; ++j) v *= sm[j][off[j] + (int64_t)x * sxs[j]];
+        Tt[(size_t)t] = v;
+    }
+    const int64_t total_cells = (int64_t)p[2] * (int64_t)p[3] * NC;
+    if ((int64_t)out_off + total_cells > arena_cells) { g_err = "fiber step writes outside its arena"; return -7; }
+    std::vector<std::pair<int64_t, double>> writes;
+    writes.reserve((size_t)((it1 - it0) * NC));
+    for (int64_t rr = it0; rr < it1; ++rr) {
+        int64_t r = rr, oo = 0, to = 0, bo[2] = {0, 0};
+        for (int a = 0; a < na; ++a) {
+            const int64_t d = r % rax[3 * a];
+            r /= rax[3 * a];
+            oo += d * rax[3 * a + 1];
+            to += d * rax[3 * a + 2];
+            for (int b = 0; b < nb; ++b) bo[b] += d * bst[b * na + a];
+        }
+        for (int n = 0; n < NC; ++n) {
+            double acc = 0.0;
+            for (int x = 0; x < cx; ++x) {
+                double f = 1.0;
+                for (int b = 0; b < nb; ++b) f *= big[b][bo[b] + (int64_t)x * bxs[b]];
+                acc += f * Tt[(size_t)(to + (int64_t)x * NC + n)];
+            }
+            const int64_t o = oo + nout[n];
+            if (o < 0 || o >= total_cells) { g_err = "fiber output offset out of range"; return -8; }
+            writes.emplace_back(o, acc);
+        }
+    }
+    for (auto &w : writes) outp[w.first] = w.second;  // (inputs never alias the output)
+    return 0;
+}
 
 extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
                               const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
@@ -34,137 +145,66 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
     net.small_cells = g_small_cells;
+    net.big_iters = g_big_iters;
+    net.tile_h = g_tile_h;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
+    // one-request batch through the product's batch planner and level-synchronous scheduler
+    int64_t q_off[2] = {0, nq}, e_off[2] = {0, ne}, out_off[2] = {0, 1};
+    for (int i = 0; i < nq; ++i) out_off[1] *= card[qvars[i]];
     Request rq;
-    rq.nq = nq; rq.qvars = qvars; rq.ne = ne; rq.evars = evars; rq.ecodes = ecodes; rq.out_off = 0;
+    rq.nq = nq; rq.qvars = qvars; rq.ne = ne; rq.evars = evars;
     g_err = validate_request(net, rq);
     if (!g_err.empty()) return -1;
-    int64_t out_cells = 1;
-    for (int i = 0; i < nq; ++i) out_cells *= card[qvars[i]];
-    for (int64_t i = 0; i < out_cells; ++i) out[i] = 0.0;
+    for (int64_t i = 0; i < out_off[1]; ++i) out[i] = 0.0;
+    char skip = 0;
     for (int i = 0; i < ne; ++i)
-        if (ecodes[i] < 0 || ecodes[i] >= card[evars[i]]) return 0;  // label outside the domain: empty posterior
-    std::vector<uint32_t> prog;
-    PlanStats st;
-    g_err = plan_request(net, rq, prog, st);
-    if (!g_err.empty()) return -6;
-    if (stats) { stats[0] = st.alg_bytes; stats[1] = st.alg_flops; stats[2] = st.n_steps; stats[3] = st.max_step_cells; stats[4] = (double)st.arena_cells; }
-    std::vector<double> arena((size_t)st.arena_cells + 2, -1e300);  // poison: reading unwritten scratch shows up
-    const uint32_t *p = prog.data();
-    int n_steps = (int)*p++;
-    for (int s = 0; s < n_steps; ++s) {
-        const uint32_t w0 = p[0];
-        const uint32_t kind = w0 & 0xff;
-        const int n_in = (w0 >> 8) & 0xff, na = (w0 >> 16) & 0xff;
-        const int cx = (int)(p[1] & 0xffff);
-        const bool fin = (p[1] >> 16) & 1;
-        const int64_t iters = (int64_t)p[2] * (int64_t)p[3];
-        const uint64_t out_off = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
-        const int words = (int)p[6];
-        double *outp = fin ? out + out_off : arena.data() + out_off;
-        auto table = [&](uint64_t o) { return (o & kConstFlag) ? net.pool.data() + (o & ~kConstFlag) : arena.data() + o; };
-        int64_t cells = iters;
-        if (kind == kKindGeneric) {
-            if (!fin && (int64_t)out_off + cells > st.arena_cells) { g_err = "step writes outside its arena"; return -7; }
-            const double *inp[kMaxIn];
-            int xs[kMaxIn];
-            for (int j = 0; j < n_in; ++j) {
-                inp[j] = table((uint64_t)p[kHdrWords + 3 * j] | ((uint64_t)p[kHdrWords + 3 * j + 1] << 32));
-                xs[j] = (int)p[kHdrWords + 3 * j + 2];
-            }
-            const uint32_t *cd = p + kHdrWords + 3 * n_in;
-            const int32_t *strd = (const int32_t *)(cd + na);
-            std::vector<double> tmp((size_t)cells);
-            for (int64_t o = 0; o < cells; ++o) {
-                int64_t r = o;
-                int64_t off[kMaxIn] = {0};
-                for (int a = 0; a < na; ++a) {
-                    const int64_t d = r % cd[a];
-                    r /= cd[a];
-                    for (int j = 0; j < n_in; ++j) off[j] += d * strd[j * na + a];
-                }
-                double acc = 0.0;
-                for (int x = 0; x < cx; ++x) {
-                    double v = 1.0;
-                    for (int j = 0; j < n_in; ++j) v *= inp[j][off[j] + (int64_t)x * xs[j]];
-                    acc += v;
-                }
-                tmp[(size_t)o] = acc;
-            }
-            std::memcpy(outp, tmp.data(), sizeof(double) * (size_t)cells);
-        } else {  // FIBER
-            const int nb = p[7] & 0xf, ns = (p[7] >> 4) & 0xf, nN = (p[7] >> 8) & 0xf, nctrl = (p[7] >> 12) & 0xf;
-            const int NC = (int)(p[7] >> 16);
-            const int T = (int)p[8];
-            const int nT = nN + nctrl;
-            const uint32_t *q = p + kHdrWords;
-            const double *big[2];
-            int bxs[2];
-            for (int b = 0; b < nb; ++b) { big[b] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32)); bxs[b] = (int)q[2]; q += 3; }
-            const double *sm[kMaxSmall];
-            int sxs[kMaxSmall];
-            const int32_t *sts[kMaxSmall];
-            for (int j = 0; j < ns; ++j) {
-                sm[j] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32));
-                sxs[j] = (int)q[2];
-                sts[j] = (const int32_t *)(q + 3);
-                q += 3 + nT;
-            }
-            const uint32_t *tcard = q; q += nT;
-            const uint32_t *nout = q; q += NC;
-            const uint32_t *rax = q; q += 3 * na;   // card, ostride, tstride per R axis
-            const int32_t *bst = (const int32_t *)q;  // [b][a]
-            std::vector<double> Tt((size_t)T);
-            for (int t = 0; t < T; ++t) {
-                int r = t;
-                const int n = r % NC; r /= NC;
-                const int x = r % cx; r /= cx;
-                int64_t off[kMaxSmall] = {0};
-                int rn = n;
-                for (int k = 0; k < nN; ++k) { int d = rn % tcard[k]; rn /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
-                for (int k = nN; k < nT; ++k) { int d = r % tcard[k]; r /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
-                double v = 1.0;
-                for (int j = 0; j < ns; ++j) v *= sm[j][off[j] + (int64_t)x * sxs[j]];
-                Tt[(size_t)t] = v;
-            }
-            cells = iters * NC;
-            if ((int64_t)out_off + cells > st.arena_cells) { g_err = "fiber step writes outside its arena"; return -7; }
-            std::vector<double> tmp((size_t)cells, -7e300);
-            for (int64_t rr = 0; rr < iters; ++rr) {
-                int64_t r = rr, oo = 0, to = 0, bo[2] = {0, 0};
-                for (int a = 0; a < na; ++a) {
-                    const int64_t d = r % rax[3 * a];
-                    r /= rax[3 * a];
-                    oo += d * rax[3 * a + 1];
-                    to += d * rax[3 * a + 2];
-                    for (int b = 0; b < nb; ++b) bo[b] += d * bst[b * na + a];
-                }
-                for (int n = 0; n < NC; ++n) {
-                    double acc = 0.0;
-                    for (int x = 0; x < cx; ++x) {
-                        double f = 1.0;
-                        for (int b = 0; b < nb; ++b) f *= big[b][bo[b] + (int64_t)x * bxs[b]];
-                        acc += f * Tt[(size_t)(to + (int64_t)x * NC + n)];
+        if (ecodes[i] < 0 || ecodes[i] >= card[evars[i]]) skip = 1;  // label outside the domain: empty posterior
+    ThreadPool pool(1);
+    std::vector<ProgBuf> bufs;
+    BatchPlan bp;
+    const int32_t zero = 0;
+    plan_batch(net, pool, bufs, 0, 1, q_off, qvars, e_off, ne ? evars : &zero, ne ? ecodes : &zero, out_off, &skip, bp);
+    g_err = bp.err;
+    if (!g_err.empty()) { for (auto &b : bufs) b.release(); return -6; }
+    if (stats) { stats[0] = bp.st.alg_bytes; stats[1] = bp.st.alg_flops; stats[2] = bp.st.n_steps; stats[3] = bp.st.max_step_cells; stats[4] = (double)bp.arena_cells; }
+    Schedule sc;
+    build_schedule(net, bp, bufs, 0, 1, sc);
+    std::vector<double> arena((size_t)sc.arena_cells + 16, -1e300);  // poison: reading unwritten scratch shows up
+    const uint32_t *prog = bufs[0].data + bp.local_off[0];
+    int rc = 0;
+    double bytes_check = 0;
+    for (const Launch &L : sc.launches) {
+        bytes_check += L.alg_bytes;
+        for (size_t k = L.first; k < L.first + L.count && rc == 0; ++k) {
+            const Item &it = sc.items[k];
+            const uint32_t *p = prog + it.rel_off;
+            if (L.kid == kKidSeg) {
+                for (uint32_t s = 0; s < it.a && rc == 0; ++s) {
+                    if (kernel_id_of_step(p) < 0) rc = -10;
+                    rc = exec_step(net, p, 0, p[3], arena, (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
+                    if (rc == 0 && ((p[1] >> 16) & 1)) {
+                        const uint64_t oo = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
+                        const int64_t cells = (int64_t)p[2] * (int64_t)p[3];
+                        double total = 0;
+                        for (int64_t i = 0; i < cells; ++i) total += out[oo + i];
+                        if (total > 0)
+                            for (int64_t i = 0; i < cells; ++i) out[oo + i] /= total;
                     }
-                    const int64_t o = oo + nout[n];
-                    if (o < 0 || o >= cells) { g_err = "fiber output offset out of range"; return -8; }
-                    tmp[(size_t)o] = acc;
+                    p += p[6];
                 }
+            } else {
+                if (kernel_id_of_step(p) != L.kid) { g_err = "tile scheduled on the wrong kernel"; rc = -11; }
+                else rc = exec_step(net, p, it.a, it.b, arena, (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
             }
-            for (int64_t i = 0; i < cells; ++i)
-                if (tmp[(size_t)i] == -7e300) { g_err = "fiber step left an output cell unwritten"; return -9; }
-            std::memcpy(outp, tmp.data(), sizeof(double) * (size_t)cells);
         }
-        if (fin) {
-            double total = 0;
-            for (int64_t i = 0; i < cells; ++i) total += outp[i];
-            if (total > 0)
-                for (int64_t i = 0; i < cells; ++i) outp[i] /= total;
-        }
-        p += words;
     }
-    return 0;
+    if (rc == 0 && !skip && std::fabs(bytes_check - bp.st.alg_bytes) > 64.0 * bp.st.n_steps + 1e-9 * bp.st.alg_bytes) {
+        g_err = "schedule bytes do not add up to the plan's algorithmic bytes";
+        rc = -12;
+    }
+    for (auto &b : bufs) b.release();
+    return rc;
 }
 
 // debugging aid: return the raw step program of one request (words copied into `out`, count returned)
@@ -176,6 +216,8 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
     net.small_cells = g_small_cells;
+    net.big_iters = g_big_iters;
+    net.tile_h = g_tile_h;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
     Request rq;

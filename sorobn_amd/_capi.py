@@ -16,6 +16,7 @@ SYMBOLS = [
     "mibn_device_count", "mibn_version", "mibn_create", "mibn_destroy", "mibn_last_error",
     "mibn_set_network", "mibn_set_order_hints", "mibn_query_batch", "mibn_last_stats",
     "mibn_plan_stats", "mibn_create_planner", "mibn_set_option", "mibn_gibbs",
+    "mibn_last_kernel_stats",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
@@ -35,6 +36,11 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_double), ("ms", C.c_double),
+                ("alg_bytes", C.c_double), ("items", C.c_double)]
 
 
 _lib = None
@@ -62,6 +68,7 @@ def lib():
         L.mibn_set_order_hints.argtypes = [vp, C.c_int32, i32p]
         L.mibn_query_batch.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p]
         L.mibn_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mibn_last_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_plan_stats.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, C.POINTER(Stats)]
         L.mibn_set_option.argtypes = [vp, C.c_char_p, C.c_double]
         L.mibn_gibbs.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, i32p, i32p, C.c_int64,
@@ -181,6 +188,14 @@ class Engine:
         s = Stats()
         self._check(self._L.mibn_last_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    def kernel_stats(self):
+        """Per-kernel breakdown of the last query_batch: list of dicts (name, launches, ms, alg_bytes, items)."""
+        arr = (KernelStat * 32)()
+        n = C.c_int32(0)
+        self._check(self._L.mibn_last_kernel_stats(self._h, 32, arr, C.byref(n)))
+        return [{"name": arr[i].name.decode(), "launches": arr[i].launches, "ms": arr[i].ms,
+                 "alg_bytes": arr[i].alg_bytes, "items": arr[i].items} for i in range(n.value)]
 
     def plan_stats(self, qvars, evars):
         q, e = _i32(qvars), _i32(evars)

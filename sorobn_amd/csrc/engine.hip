@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -31,9 +32,9 @@ struct mibn_ctx {
     bool planner_only = false;
     int device = -1;
     int n_cu = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // gibbs + result download
     double *d_pool = nullptr;
-    double *d_arena = nullptr;
+    double *d_arena = nullptr;  // private arenas of the requests of the wave in flight
     size_t arena_bytes = 0;
     double *d_results = nullptr;
     size_t results_cap = 0;  // doubles
@@ -45,20 +46,26 @@ struct mibn_ctx {
         size_t prog_cap = 0;
         uint64_t *d_prog_off = nullptr;
         size_t prog_off_cap = 0;
-        int32_t *d_order = nullptr;
-        size_t order_cap = 0;
-        uint32_t *d_ticket = nullptr;
-        hipEvent_t k0 = nullptr, k1 = nullptr;  // kernel start / end
+        uint64_t *d_arena_off = nullptr;
+        size_t arena_off_cap = 0;
+        Item *d_items = nullptr;
+        size_t items_cap = 0;
+        std::vector<hipEvent_t> ev;          // launch boundaries of the waves in flight
+        struct Timed { int kid; size_t e0, e1; double bytes, items; };
+        std::vector<Timed> timed;
+        size_t ev_used = 0;
         bool busy = false;
         BatchPlan plan;
+        Schedule sched;
     } set[2];
     std::string err;
     mibn_stats stats{};
+    mibn_kernel_stat kstats[kNumKernels];
     // options
-    double arena_gb = 64.0;
+    double arena_gb = 96.0;
     int threads = 0;
     int wg_per_cu = 8;
-    int64_t chunk = 8192;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
+    int64_t chunk = 16384;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
 };
 
 #define HIP_TRY(h, expr)                                                                              \
@@ -106,9 +113,6 @@ int mibn_create(int device, mibn_t **out) {
     }
     h->n_cu = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
-    for (auto &st : h->set)
-        ok = ok && hipEventCreate(&st.k0) == hipSuccess && hipEventCreate(&st.k1) == hipSuccess &&
-             hipMalloc(&st.d_ticket, 64) == hipSuccess;
     if (!ok) { delete h; return MIBN_E_HIP; }
     *out = h;
     return MIBN_OK;
@@ -128,10 +132,9 @@ void mibn_destroy(mibn_t *h) {
                 if (b.data) (void)hipHostFree(b.data);
             (void)hipFree(st.d_prog);
             (void)hipFree(st.d_prog_off);
-            (void)hipFree(st.d_order);
-            (void)hipFree(st.d_ticket);
-            if (st.k0) (void)hipEventDestroy(st.k0);
-            if (st.k1) (void)hipEventDestroy(st.k1);
+            (void)hipFree(st.d_arena_off);
+            (void)hipFree(st.d_items);
+            for (auto e : st.ev) (void)hipEventDestroy(e);
         }
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
@@ -147,6 +150,8 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "threads") h->threads = (int)value;
     else if (n == "wg_per_cu") h->wg_per_cu = std::max(1, std::min(8, (int)value));
     else if (n == "chunk") h->chunk = std::max<int64_t>(1, (int64_t)value);
+    else if (n == "big_iters") h->net.big_iters = std::max<int64_t>(1, (int64_t)value);  // test hooks: force tiling
+    else if (n == "tile_h") h->net.tile_h = std::max(1, std::min(kWG, (int)value));
     else if (n == "small_cells") h->net.small_cells = std::max(1, std::min(kMaxT, (int)value));  // test hook: forces FIBER steps on small networks
     else { h->err = "unknown option " + n; return MIBN_E_ARG; }
     return MIBN_OK;
@@ -236,15 +241,44 @@ int default_threads() {
     return std::max(1, std::min(64, hw / local_world));
 }
 
-// collect the kernel time of a finished set
+using KernelFn = void (*)(LevelArgs);
+const KernelFn kKernels[kNumKernels] = {
+    seg_kernel,
+    fiber_tile_kernel<1, 4, 1>, fiber_tile_kernel<1, 4, 4>, fiber_tile_kernel<1, 2, 1>, fiber_tile_kernel<1, 2, 4>,
+    fiber_tile_kernel<1, 0, 1>, fiber_tile_kernel<1, 0, 4>, fiber_tile_kernel<2, 4, 1>, fiber_tile_kernel<2, 4, 4>,
+    fiber_tile_kernel<2, 2, 1>, fiber_tile_kernel<2, 2, 4>, fiber_tile_kernel<2, 0, 1>, fiber_tile_kernel<2, 0, 4>,
+    generic_tile_kernel<1>, generic_tile_kernel<2>, generic_tile_kernel<3>, generic_tile_kernel<4>,
+    generic_tile_kernel<5>, generic_tile_kernel<6>};
+
+// wait for a set's launches and book their HIP-event durations per kernel
 int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     if (!st.busy) return MIBN_OK;
-    HIP_TRY(h, hipEventSynchronize(st.k1));
-    float ms = 0;
-    HIP_TRY(h, hipEventElapsedTime(&ms, st.k0, st.k1));
-    h->stats.kernel_ms += ms;
-    h->stats.n_launches += 1;
+    HIP_TRY(h, hipEventSynchronize(st.ev[st.ev_used - 1]));
+    for (auto &t : st.timed) {
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));
+        h->stats.kernel_ms += ms;
+        h->stats.n_launches += 1;
+        mibn_kernel_stat &k = h->kstats[t.kid];
+        k.launches += 1;
+        k.ms += ms;
+        k.alg_bytes += t.bytes;
+        k.items += t.items;
+    }
+    st.timed.clear();
+    st.ev_used = 0;
     st.busy = false;
+    return MIBN_OK;
+}
+
+int next_event(mibn_ctx *h, mibn_ctx::Set &st, size_t &idx) {
+    if (st.ev_used == st.ev.size()) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreate(&e));
+        st.ev.push_back(e);
+    }
+    idx = st.ev_used++;
+    HIP_TRY(h, hipEventRecord(st.ev[idx], h->stream));
     return MIBN_OK;
 }
 
@@ -258,6 +292,10 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
     const double t_start = now_ms();
     h->stats = mibn_stats{};
+    for (int k = 0; k < kNumKernels; ++k) {
+        h->kstats[k] = mibn_kernel_stat{};
+        std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", kernel_name(k));
+    }
     if (B == 0) return MIBN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     // validation (bayes_net.py:840-845) and the out-of-domain-evidence short cut
@@ -289,6 +327,9 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
     const size_t res_cells = (size_t)(out_off[B] - out_off[0]);
     if ((rc = ensure(h, h->d_results, h->results_cap, res_cells))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_results, 0, res_cells * 8, h->stream));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
+    const int64_t budget_cells = (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes)) / 8.0);
     int64_t n_chunks = 0;
     for (int64_t b0 = 0; b0 < B; b0 += h->chunk, ++n_chunks) {
         const int64_t b1 = std::min(B, b0 + h->chunk);
@@ -300,28 +341,11 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
         plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck);
         if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); return MIBN_E_LIMIT; }
         for (auto &b : st.bufs)
-            if (b.cap && !b.data) { h->err = "pinned host allocation failed"; (void)hipStreamSynchronize(h->stream); return MIBN_E_HIP; }
+            if (b.cap && !b.data) { h->err = "pinned host allocation failed"; return MIBN_E_HIP; }
         h->stats.plan_ms += now_ms() - t0;
-        // arena: one slot per persistent workgroup
-        const size_t slot_cells = (size_t)std::max<int64_t>(2, (ck.arena_cells + 1) & ~int64_t(1));
-        int64_t n_wg = std::min<int64_t>((int64_t)h->n_cu * h->wg_per_cu, n);
-        if ((double)n_wg * slot_cells * 8.0 > (double)h->arena_bytes) {
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
-            const double budget = std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes));
-            n_wg = std::min<int64_t>(n_wg, (int64_t)(budget / (8.0 * (double)slot_cells)));
-            if (n_wg < 1) { h->err = "a request needs " + std::to_string(8.0 * slot_cells / 1e9) + " GB of scratch, above the arena budget"; return MIBN_E_NOMEM; }
-            const size_t need = (size_t)n_wg * slot_cells * sizeof(double);
-            if (need > h->arena_bytes) {
-                HIP_TRY(h, hipStreamSynchronize(h->stream));  // a running kernel still uses the old arena
-                if (h->d_arena) { HIP_TRY(h, hipFree(h->d_arena)); h->d_arena = nullptr; h->arena_bytes = 0; }
-                HIP_TRY(h, hipMalloc(&h->d_arena, need));
-                h->arena_bytes = need;
-            }
-        }
         if ((rc = ensure(h, st.d_prog, st.prog_cap, ck.total_words))) return rc;
         if ((rc = ensure(h, st.d_prog_off, st.prog_off_cap, (size_t)n))) return rc;
-        if ((rc = ensure(h, st.d_order, st.order_cap, (size_t)n))) return rc;
+        if ((rc = ensure(h, st.d_arena_off, st.arena_off_cap, (size_t)n))) return rc;
         t0 = now_ms();
         size_t base = 0;
         for (size_t t = 0; t < ck.thread_words.size(); ++t) {
@@ -330,30 +354,63 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             base += ck.thread_words[t];
         }
         HIP_TRY(h, hipMemcpyAsync(st.d_prog_off, ck.prog_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(st.d_order, ck.order.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemsetAsync(st.d_ticket, 0, 64, h->stream));
         h->stats.h2d_ms += now_ms() - t0;
-        KernelArgs A;
-        A.prog = st.d_prog;
-        A.prog_off = st.d_prog_off;
-        A.order = st.d_order;
-        A.pool = h->d_pool;
-        A.arena = h->d_arena;
-        A.slot_cells = slot_cells;
-        A.results = h->d_results + (out_off[b0] - out_off[0]);
-        A.ticket = st.d_ticket;
-        A.n_requests = (int32_t)n;
-        HIP_TRY(h, hipEventRecord(st.k0, h->stream));
-        hipLaunchKernelGGL(ve_kernel, dim3((unsigned)n_wg), dim3(kWG), 0, h->stream, A);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(st.k1, h->stream));
-        st.busy = true;
+        // waves: consecutive requests whose private arenas fit the scratch budget together
+        for (int64_t r0 = 0; r0 < n;) {
+            int64_t r1 = r0, cells = 0;
+            while (r1 < n) {
+                const int64_t need = (ck.arena_need[r1] + 15) & ~int64_t(15);
+                if (r1 > r0 && cells + need > budget_cells) break;
+                cells += need;
+                ++r1;
+            }
+            if (cells > budget_cells) { h->err = "a request needs " + std::to_string(8.0 * cells / 1e9) + " GB of scratch, above the arena budget"; return MIBN_E_NOMEM; }
+            t0 = now_ms();
+            Schedule &sc = st.sched;
+            build_schedule(h->net, ck, st.bufs, r0, r1, sc);
+            h->stats.plan_ms += now_ms() - t0;
+            const size_t need_bytes = (size_t)std::max<int64_t>(16, sc.arena_cells) * sizeof(double);
+            if (need_bytes > h->arena_bytes) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));  // earlier launches still use the old arena
+                if (h->d_arena) { HIP_TRY(h, hipFree(h->d_arena)); h->d_arena = nullptr; h->arena_bytes = 0; }
+                HIP_TRY(h, hipMalloc(&h->d_arena, need_bytes));
+                h->arena_bytes = need_bytes;
+            }
+            // items / arena offsets of this wave live until the wave's launches have run: one wave per set at a
+            // time unless the chunk had to be split (then wait for the previous wave first)
+            if (r0 > 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if ((rc = ensure(h, st.d_items, st.items_cap, sc.items.size()))) return rc;
+            t0 = now_ms();
+            HIP_TRY(h, hipMemcpyAsync(st.d_arena_off, sc.arena_off.data(), (size_t)(r1 - r0) * 8, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(st.d_items, sc.items.data(), sc.items.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
+            h->stats.h2d_ms += now_ms() - t0;
+            LevelArgs A;
+            A.prog = st.d_prog;
+            A.prog_off = st.d_prog_off + r0;
+            A.arena_off = st.d_arena_off;
+            A.pool = h->d_pool;
+            A.arena = h->d_arena;
+            A.results = h->d_results + (out_off[b0] - out_off[0]);
+            size_t e_prev = 0;
+            if ((rc = next_event(h, st, e_prev))) return rc;
+            for (const Launch &L : sc.launches) {
+                A.items = st.d_items + L.first;
+                hipLaunchKernelGGL(kKernels[L.kid], dim3((unsigned)L.count), dim3(kWG), 0, h->stream, A);
+                size_t e_next = 0;
+                if ((rc = next_event(h, st, e_next))) return rc;
+                st.timed.push_back({L.kid, e_prev, e_next, L.alg_bytes, (double)L.count});
+                e_prev = e_next;
+            }
+            HIP_TRY(h, hipGetLastError());
+            st.busy = true;
+            h->stats.arena_bytes = std::max(h->stats.arena_bytes, (double)need_bytes);
+            h->stats.n_workgroups += (double)sc.items.size();
+            r0 = r1;
+        }
         h->stats.alg_bytes += ck.st.alg_bytes;
         h->stats.alg_flops += ck.st.alg_flops;
         h->stats.n_steps += ck.st.n_steps;
         h->stats.max_step_cells = std::max(h->stats.max_step_cells, ck.st.max_step_cells);
-        h->stats.arena_bytes = (double)h->arena_bytes;
-        h->stats.n_workgroups = (double)n_wg;
     }
     for (auto &st : h->set)
         if ((rc = retire(h, st))) return rc;
@@ -362,6 +419,15 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stats.d2h_ms += now_ms() - t0;
     h->stats.total_ms = now_ms() - t_start;
+    return MIBN_OK;
+}
+
+extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
+    if (!h || !out || !n) return MIBN_E_ARG;
+    int k = 0;
+    for (int i = 0; i < kNumKernels && k < cap; ++i)
+        if (h->kstats[i].launches > 0) out[k++] = h->kstats[i];
+    *n = k;
     return MIBN_OK;
 }
 

@@ -498,8 +498,10 @@ struct Emitter {
             out.off = (uint64_t)arena.alloc(cells);
             out.alloc = cells;
         }
+        const size_t step_base = prog.size;
         if (!(!final_ && emit_fiber(ins, n_in, s, xs, out, cx))) emit_generic(ins, n_in, s, xs, out, cells, cx, final_);
         if (!err.empty()) return;
+        prog.data[step_base + 9] = (uint32_t)(((int64_t)in_cells + cells + 2) >> 2);  // section-8(d) cells of this step, units of 4
         st.alg_bytes += 8.0 * (in_cells + (double)cells);
         const double pc = std::exp2(prod_log2);
         st.alg_flops += n_in * pc;
@@ -751,6 +753,9 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
     ck.err.clear();
     ck.prog_off.assign(n, 0);
     ck.cost.assign(n, 0.0);
+    ck.arena_need.assign(n, 0);
+    ck.thread_of.assign(n, 0);
+    ck.local_off.assign(n, 0);
     ck.thread_words.assign(T, 0);
     std::vector<PlanStats> tst(T);
     std::vector<std::string> terr(T);
@@ -761,6 +766,8 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
         for (int64_t i = lo; i < hi; ++i) {
             const int64_t b = b0 + i;
             ck.prog_off[i] = prog.size;
+            ck.local_off[i] = prog.size;
+            ck.thread_of[i] = t;
             if (skip && skip[b]) { prog.push(0); continue; }  // zero steps: result stays all-zero
             Request rq;
             rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
@@ -773,6 +780,7 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             std::string e = plan_request(net, rq, prog, st);
             if (!e.empty()) { terr[t] = e; return; }
             ck.cost[i] = st.alg_bytes;
+            ck.arena_need[i] = st.arena_cells;
             tst[t].alg_bytes += st.alg_bytes;
             tst[t].alg_flops += st.alg_flops;
             tst[t].n_steps += st.n_steps;
@@ -797,6 +805,113 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
     ck.order.resize(n);
     std::iota(ck.order.begin(), ck.order.end(), 0);
     std::stable_sort(ck.order.begin(), ck.order.end(), [&](int32_t a, int32_t b) { return ck.cost[a] > ck.cost[b]; });
+}
+
+// ------------------------------------------------------------------------------------ schedule
+
+const char *kernel_name(int kid) {
+    static const char *names[kNumKernels] = {
+        "seg_kernel",
+        "fiber_tile_kernel<1,4,1>", "fiber_tile_kernel<1,4,4>", "fiber_tile_kernel<1,2,1>", "fiber_tile_kernel<1,2,4>",
+        "fiber_tile_kernel<1,0,1>", "fiber_tile_kernel<1,0,4>", "fiber_tile_kernel<2,4,1>", "fiber_tile_kernel<2,4,4>",
+        "fiber_tile_kernel<2,2,1>", "fiber_tile_kernel<2,2,4>", "fiber_tile_kernel<2,0,1>", "fiber_tile_kernel<2,0,4>",
+        "generic_tile_kernel<1>", "generic_tile_kernel<2>", "generic_tile_kernel<3>", "generic_tile_kernel<4>",
+        "generic_tile_kernel<5>", "generic_tile_kernel<6>"};
+    return kid >= 0 && kid < kNumKernels ? names[kid] : "?";
+}
+
+int kernel_id_of_step(const uint32_t *w) {
+    const uint32_t kind = w[0] & 0xff;
+    const int cx = (int)(w[1] & 0xffff);
+    if (kind == kKindFiber) {
+        const int nb = w[7] & 0xf, NC = (int)(w[7] >> 16);
+        const int cxc = cx == 4 ? 0 : (cx == 2 ? 1 : 2);
+        return kKidFiber0 + (nb - 1) * 6 + cxc * 2 + (NC > 1 ? 1 : 0);
+    }
+    const int n_in = (w[0] >> 8) & 0xff;
+    return kKidGeneric0 + std::min(std::max(n_in, 1), kMaxIn) - 1;
+}
+
+// section-8(d) algorithmic bytes of one step (the planner stores (input + output cells) / 4 in w9)
+int64_t step_cost_bytes(const uint32_t *w) { return 32 * (int64_t)w[9]; }
+
+void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<ProgBuf> &bufs, int64_t r0, int64_t r1,
+                    Schedule &out) {
+    const int64_t kBigIters = net.big_iters;
+    const uint32_t kTileH = (uint32_t)std::max(1, net.tile_h);
+    const int64_t n = r1 - r0;
+    out.items.clear();
+    out.launches.clear();
+    out.arena_off.assign(n, 0);
+    int64_t top = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        out.arena_off[i] = (uint64_t)top;
+        top += (bp.arena_need[r0 + i] + 15) & ~int64_t(15);  // 128-byte aligned private arenas
+    }
+    out.arena_cells = top;
+    // pass 1: items tagged with (level, kid); bucket sizes
+    struct Tagged { Item it; int level, kid; double bytes; };
+    std::vector<Tagged> tagged;
+    tagged.reserve((size_t)n * 8);
+    int n_levels = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = r0 + i;
+        const uint32_t *prog = bufs[bp.thread_of[r]].data + bp.local_off[r];
+        const int n_steps = (int)prog[0];
+        uint32_t off = 1;
+        int level = 0;
+        int seg_first = -1, seg_steps = 0;
+        double seg_bytes = 0;
+        auto flush = [&]() {
+            if (seg_steps) {
+                tagged.push_back({{(uint32_t)i, (uint32_t)seg_first, (uint32_t)seg_steps, 0u}, level, kKidSeg, seg_bytes});
+                ++level;
+                seg_steps = 0;
+                seg_bytes = 0;
+            }
+        };
+        for (int s = 0; s < n_steps; ++s) {
+            const uint32_t *w = prog + off;
+            const int64_t iters = (int64_t)w[2] * (int64_t)w[3];
+            const bool fin = (w[1] >> 16) & 1;
+            const double bytes = (double)step_cost_bytes(w);
+            if (!fin && iters >= kBigIters && w[3] > 1) {
+                flush();
+                const int kid = kernel_id_of_step(w);
+                const uint32_t hi = w[3];
+                for (uint32_t h = 0; h < hi; h += kTileH) {
+                    const uint32_t he = std::min(hi, h + kTileH);
+                    tagged.push_back({{(uint32_t)i, off, h, he}, level, kid, bytes * (double)(he - h) / (double)hi});
+                }
+                ++level;
+            } else {
+                if (!seg_steps) seg_first = (int)off;
+                ++seg_steps;
+                seg_bytes += bytes;
+            }
+            off += w[6];
+        }
+        flush();
+        n_levels = std::max(n_levels, level);
+    }
+    out.n_levels = n_levels;
+    // pass 2: counting sort by (level, kid)
+    const size_t nb = (size_t)n_levels * kNumKernels;
+    std::vector<size_t> count(nb + 1, 0);
+    std::vector<double> bytes(nb, 0.0);
+    for (auto &t : tagged) { ++count[(size_t)t.level * kNumKernels + t.kid + 1]; bytes[(size_t)t.level * kNumKernels + t.kid] += t.bytes; }
+    for (size_t k = 0; k < nb; ++k) count[k + 1] += count[k];
+    out.items.resize(tagged.size());
+    std::vector<size_t> cur(count.begin(), count.end() - 1);
+    for (auto &t : tagged) out.items[cur[(size_t)t.level * kNumKernels + t.kid]++] = t.it;
+    for (size_t k = 0; k < nb; ++k)
+        if (count[k + 1] > count[k]) {
+            const int level = (int)(k / kNumKernels), kid = (int)(k % kNumKernels);
+            if (kid == kKidSeg)  // longest segments first: they are the tail of their launch
+                std::stable_sort(out.items.begin() + count[k], out.items.begin() + count[k + 1],
+                                 [](const Item &a, const Item &b) { return a.a > b.a; });
+            out.launches.push_back({level, kid, count[k], count[k + 1] - count[k], bytes[k]});
+        }
 }
 
 }  // namespace mibn

@@ -55,7 +55,9 @@ struct Network {
     std::vector<int32_t> depth;                  // longest path from a root
     std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier)
     int nw = 1;
-    int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table (kSmallCells)
+    int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
+    int64_t big_iters = 16384;  // a step with at least this many lane-iterations is a level of its own (tiled)
+    int tile_h = 128;        // hi iterations per tile
 
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
@@ -84,7 +86,8 @@ struct PlanStats {
 //      w2 = lo_cells   w3 = hi_cells     lane-varying / wave-uniform blocks of the iteration space
 //      w4,w5 = out_off (u64, doubles; arena-relative, or result-buffer-relative if FINAL)
 //      w6 = step_words (total words of this step)
-//      w7 = FIBER: n_big | n_small<<4 | n_N<<8 | n_ctrl<<12 | NC<<16        w8 = FIBER: T_cells   w9 = 0
+//      w7 = FIBER: n_big | n_small<<4 | n_N<<8 | n_ctrl<<12 | NC<<16        w8 = FIBER: T_cells
+//      w9 = (input cells + output cells) / 4  - the step's section-8(d) traffic, for per-kernel rooflines
 //
 //   GENERIC  psi[o] = sum_x prod_j phi_j[off_j(o) + x*xs_j], iteration space = output cells:
 //      per input j<n_in:  in_off lo, in_off hi (bit 63 = constants pool), xs_j
@@ -148,6 +151,9 @@ struct BatchPlan {
     std::vector<size_t> thread_words;          // words written by each worker (bufs[t].size)
     std::vector<uint64_t> prog_off;            // per request: word offset into the concatenated buffers
     std::vector<double> cost;                  // per request: algorithmic bytes
+    std::vector<int64_t> arena_need;           // per request: scratch cells
+    std::vector<int32_t> thread_of;            // per request: worker that planned it
+    std::vector<uint64_t> local_off;           // per request: word offset inside that worker's buffer
     std::vector<int32_t> order;                // execution order, heaviest first
     int64_t arena_cells = 0;                   // largest per-request scratch need
     size_t total_words = 0;
@@ -157,6 +163,43 @@ struct BatchPlan {
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
                 const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &bp);
+
+// ---------------------------------------------------------------------------------------------------
+// Level-synchronous schedule.  A request's program is cut into *items*: a maximal run of small steps
+// is one SEGMENT item (one workgroup runs the steps back to back), every big step is its own level
+// and is split into TILE items over its wave-uniform iteration range, executed by a kernel specialised
+// for the step's shape.  Item k of a request runs at level k; level L of all requests of a wave is one
+// launch per kernel id, launches are stream-ordered, so the only synchronisation is the launch
+// boundary.  Big steps thereby use the whole chip (no single-workgroup tails) and every
+// specialisation gets its own register budget.
+struct Item {
+    uint32_t req;      // request index within the wave
+    uint32_t rel_off;  // word offset of the (first) step inside the request's program
+    uint32_t a, b;     // SEGMENT: a = number of steps.  TILE: [a, b) = range of hi iterations
+};
+struct Launch {
+    int level, kid;
+    size_t first, count;  // range in Schedule::items
+    double alg_bytes;     // algorithmic bytes of the steps (tiles pro rata) in this launch
+};
+constexpr int kKidSeg = 0;         // segment interpreter
+constexpr int kKidFiber0 = 1;      // 12 FIBER tile kernels: 1 + (n_big-1)*6 + cx_class*2 + (NC > 1)
+constexpr int kKidGeneric0 = 13;   // 6 GENERIC tile kernels: 13 + (n_in - 1)
+constexpr int kNumKernels = 19;
+const char *kernel_name(int kid);
+int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
+int64_t step_cost_bytes(const uint32_t *w);
+
+struct Schedule {
+    std::vector<Item> items;
+    std::vector<Launch> launches;
+    std::vector<uint64_t> arena_off;  // per request of the wave: offset (doubles) of its private arena
+    int64_t arena_cells = 0;          // total
+    int n_levels = 0;
+};
+// requests [r0, r1) of the planned chunk (indices into BatchPlan::prog_off); `arena_need[i]` = scratch cells of request i
+void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<ProgBuf> &bufs, int64_t r0, int64_t r1,
+                    Schedule &out);
 
 // Validate a request (unknown ids, duplicates, overlap) - bayes_net.py:840-845 and the KeyError of 770.
 std::string validate_request(const Network &net, const Request &rq);

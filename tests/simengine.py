@@ -27,6 +27,7 @@ def lib():
                                      C.c_int32, i32p, C.c_int32, i32p, i32p, f64p, f64p]
         L.plan_sim_error.restype = C.c_char_p
         L.plan_sim_set_small_cells.argtypes = [C.c_int]
+        L.plan_sim_set_tiling.argtypes = [C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -34,8 +35,9 @@ def lib():
 class SimEngine:
     """Same surface as sorobn_amd._capi.Engine for the exact path, executed by plan_sim."""
 
-    def __init__(self, flat, small_cells=1024):
+    def __init__(self, flat, small_cells=1024, tiling=(16384, 128)):
         self.small_cells = small_cells  # lower it to force FIBER steps on small networks
+        self.tiling = tiling            # (big_iters, tile_h): lower them to force tiled levels on small networks
         self.f = flat
         self.card = flat.card
         self.last_stats = None
@@ -53,6 +55,7 @@ class SimEngine:
         stats = np.zeros(5, np.float64)
         hints = np.ascontiguousarray(self.hints.reshape(-1) if self.hints.size else [0], np.int32)
         L.plan_sim_set_small_cells(int(self.small_cells))
+        L.plan_sim_set_tiling(int(self.tiling[0]), int(self.tiling[1]))
         rc = L.plan_sim_query(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64),
                               p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
                               p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
@@ -73,17 +76,17 @@ class SimEngine:
         return (np.concatenate(outs) if outs else np.zeros(0)), off
 
 
-def sim_backend(bn, small_cells=1024):
+def sim_backend(bn, small_cells=1024, tiling=(16384, 128)):
     """A Backend whose engine is the CPU plan simulator (bypasses Backend.__init__)."""
     b = Backend.__new__(Backend)
     b.flat = flatten(bn)
     b.fingerprint = Backend.fingerprint_of(bn)
-    b.engine = SimEngine(b.flat, small_cells)
+    b.engine = SimEngine(b.flat, small_cells, tiling)
     b._anc = {}
     return b
 
 
-def attach(bn, small_cells=1024):
+def attach(bn, small_cells=1024, tiling=(16384, 128)):
     """Make a sorobn_amd.BayesNet answer through the simulator (tests only)."""
-    bn._backend = sim_backend(bn, small_cells)
+    bn._backend = sim_backend(bn, small_cells, tiling)
     return bn

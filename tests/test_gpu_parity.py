@@ -40,21 +40,27 @@ def _check_requests(bn, requests, ctx):
 
 # small_cells < 1024 forces the FIBER (streaming) step form, normally reserved for > 8 KiB tables, onto the
 # small golden networks: mixed cardinalities, sparse CPTs, every (n_big, cx, NC) kernel specialisation
-@pytest.mark.parametrize("small_cells", [1024, 1, 6])
+# (big_iters, tile_h) below the defaults (16384, 128) turn small steps into tiled levels, so the tile kernels
+# of every shape run on the small golden networks too
+@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (1, (2, 1)), (6, (8, 3))])
 @pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
-def test_golden_networks(amd, fname, small_cells):
+def test_golden_networks(amd, fname, small_cells, tiling):
     for net in gu.load(fname):
         bn = netspec.build(net["spec"], amd.BayesNet)
         bn.backend.engine.set_option("small_cells", small_cells)
+        bn.backend.engine.set_option("big_iters", tiling[0])
+        bn.backend.engine.set_option("tile_h", tiling[1])
         _check_requests(bn, net["requests"], net["spec"]["name"])
 
 
-@pytest.mark.parametrize("small_cells", [1024, 3, 20])
-def test_golden_small_grids(amd, small_cells):
+@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (3, (4, 1)), (20, (64, 2))])
+def test_golden_small_grids(amd, small_cells, tiling):
     for entry in gu.load("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
         bn = netspec.build(spec, amd.BayesNet)
         bn.backend.engine.set_option("small_cells", small_cells)
+        bn.backend.engine.set_option("big_iters", tiling[0])
+        bn.backend.engine.set_option("tile_h", tiling[1])
         _check_requests(bn, entry["requests"], spec["name"])
 
 

@@ -143,19 +143,21 @@ def _check_requests(bn, requests, ctx, limit=None):
 
 # small_cells: inputs above this size are "big" -> lowering it forces the FIBER step form (normally only
 # used for > 8 KiB tables) onto the small golden networks, mixed cardinalities and sparse CPTs included
-@pytest.mark.parametrize("small_cells", [1024, 1, 6])
+# tiling = (big_iters, tile_h): lowering them turns small steps into tiled levels of the level-synchronous
+# schedule (normally only steps with >= 16384 lane-iterations, in tiles of 128 hi iterations)
+@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (1, (2, 1)), (6, (8, 3))])
 @pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
-def test_planner_programs_reproduce_reference(fname, small_cells):
+def test_planner_programs_reproduce_reference(fname, small_cells, tiling):
     for net in _nets(fname):
-        bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet), small_cells)
+        bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet), small_cells, tiling)
         _check_requests(bn, net["requests"], net["spec"]["name"], limit=None if small_cells == 1024 else 60)
 
 
-@pytest.mark.parametrize("small_cells", [1024, 3, 20])
-def test_planner_programs_reproduce_reference_grids(small_cells):
+@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (3, (4, 1)), (20, (64, 2))])
+def test_planner_programs_reproduce_reference_grids(small_cells, tiling):
     for entry in _nets("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
-        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), small_cells)
+        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), small_cells, tiling)
         _check_requests(bn, entry["requests"], spec["name"])
 
 

@@ -34,6 +34,10 @@ def run(Qs, Es, Cs, label, reps=2):
     print(f"{label:34s} B={len(Qs):6d} wall {dt*1e3:8.1f} ms kernel {s['kernel_ms']:8.2f} ms plan {s['plan_ms']:7.1f} ms "
           f"h2d {s['h2d_ms']:6.1f} bytes {s['alg_bytes']/1e9:8.2f} GB -> {s['alg_bytes']/s['kernel_ms']/1e6:8.1f} GB/s "
           f"steps {s['n_steps']:.0f} wgs {s['n_workgroups']:.0f} arena {s['arena_bytes']/1e9:.1f} GB", flush=True)
+    if os.environ.get("PROBE_KSTATS"):
+        for k in sorted(eng.kernel_stats(), key=lambda k: -k["ms"])[:6]:
+            print(f"      {k['name']:28s} launches {k['launches']:5.0f} items {k['items']:9.0f} ms {k['ms']:8.2f} "
+                  f"bytes {k['alg_bytes']/1e9:8.2f} GB -> {k['alg_bytes']/max(k['ms'],1e-9)/1e6:8.1f} GB/s")
     return s
 
 
