@@ -10,6 +10,7 @@
 //
 // This library is NOT part of the product and is never loaded by sorobn_amd: the product path has
 // no CPU fallback (mibn_query_batch fails without a gfx950 device).  Only tests/ may load it.
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cmath>
@@ -22,9 +23,10 @@
 using namespace mibn;
 
 static std::string g_err;
-static int g_small_cells = 1024, g_big_iters = 16384, g_tile_h = 128;
+static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1;
 extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
 extern "C" void plan_sim_set_tiling(int big_iters, int tile_h) { g_big_iters = big_iters; g_tile_h = tile_h; }
+extern "C" void plan_sim_set_fuse(int fuse) { g_fuse = fuse; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
 
@@ -76,25 +78,38 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
     // FIBER
     const int nb = p[7] & 0xf, ns = (p[7] >> 4) & 0xf, nN = (p[7] >> 8) & 0xf, nctrl = (p[7] >> 12) & 0xf;
     const int NC = (int)(p[7] >> 16);
-    const int T = (int)p[8];
+    const int T = (int)(p[8] & 0xffff);
+    const int c1 = (int)(p[8] >> 16);
+    if (c1 < 1 || cx % c1) { g_err = "fiber step: c1 does not divide cx"; return -9; }
     const int nT = nN + nctrl;
     const uint32_t *q = p + kHdrWords;
     const double *big[2];
-    int bxs[2];
-    for (int b = 0; b < nb; ++b) { big[b] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32)); bxs[b] = (int)q[2]; q += 3; }
+    int bxs1[2], bxs2[2];
+    for (int b = 0; b < nb; ++b) { big[b] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32)); bxs1[b] = (int)q[2]; bxs2[b] = (int)q[3]; q += 4; }
     const double *sm[kMaxSmall];
-    int sxs[kMaxSmall];
+    int sxs1[kMaxSmall], sxs2[kMaxSmall];
     const int32_t *sts[kMaxSmall];
     for (int j = 0; j < ns; ++j) {
         sm[j] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32));
-        sxs[j] = (int)q[2];
-        sts[j] = (const int32_t *)(q + 3);
-        q += 3 + nT;
+        sxs1[j] = (int)q[2];
+        sxs2[j] = (int)q[3];
+        sts[j] = (const int32_t *)(q + 4);
+        q += 4 + nT;
     }
     const uint32_t *tcard = q; q += nT;
     const uint32_t *nout = q; q += NC;
     const uint32_t *rax = q; q += 3 * na;   // card, ostride, tstride per R axis
     const int32_t *bst = (const int32_t *)q;  // [b][a]
+    if ((p[1] >> 16) & kFlagContig) {  // the kernel's vector / transposed stores rely on this
+        for (int n = 0; n < NC; ++n)
+            if (nout[n] != (uint32_t)n) { g_err = "CONTIG step with scattered N offsets"; return -9; }
+        const int nlo_m = (p[0] >> 24) & 0xff;
+        int64_t expect = NC;
+        for (int a = 0; a < nlo_m; ++a) {
+            if ((int64_t)rax[3 * a + 1] != expect) { g_err = "CONTIG step whose lane block is not contiguous"; return -9; }
+            expect *= rax[3 * a];
+        }
+    }
     std::vector<double> Tt((size_t)T);
     for (int t = 0; t < T; ++t) {
         int r = t;
@@ -105,7 +120,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
         for (int k = 0; k < nN; ++k) { int d = rn % tcard[k]; rn /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
         for (int k = nN; k < nT; ++k) { int d = r % tcard[k]; r /= tcard[k]; for (int j = 0; j < ns; ++j) off[j] += (int64_t)d * sts[j][k]; }
         double v = 1.0;
-        for (int j = 0; j < ns; ++j) v *= sm[j][off[j] + (int64_t)x * sxs[j]];
+        for (int j = 0; j < ns; ++j) v *= sm[j][off[j] + (int64_t)(x % c1) * sxs1[j] + (int64_t)(x / c1) * sxs2[j]];
         Tt[(size_t)t] = v;
     }
     const int64_t total_cells = (int64_t)p[2] * (int64_t)p[3] * NC;
@@ -125,7 +140,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
             double acc = 0.0;
             for (int x = 0; x < cx; ++x) {
                 double f = 1.0;
-                for (int b = 0; b < nb; ++b) f *= big[b][bo[b] + (int64_t)x * bxs[b]];
+                for (int b = 0; b < nb; ++b) f *= big[b][bo[b] + (int64_t)(x % c1) * bxs1[b] + (int64_t)(x / c1) * bxs2[b]];
                 acc += f * Tt[(size_t)(to + (int64_t)x * NC + n)];
             }
             const int64_t o = oo + nout[n];
@@ -147,6 +162,7 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     net.small_cells = g_small_cells;
     net.big_iters = g_big_iters;
     net.tile_h = g_tile_h;
+    net.fuse = g_fuse;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
     // one-request batch through the product's batch planner and level-synchronous scheduler
@@ -195,7 +211,16 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
                 }
             } else {
                 if (kernel_id_of_step(p) != L.kid) { g_err = "tile scheduled on the wrong kernel"; rc = -11; }
-                else rc = exec_step(net, p, it.a, it.b, arena, (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
+                else if (it.a < 1 || it.a > (uint32_t)kTileMax) { g_err = "tile height out of range"; rc = -11; }
+                else {
+                    // the workgroups [it.b, next item's b) of the launch each run one tile of it.a hi iterations
+                    const uint32_t next_b = k + 1 < L.first + L.count ? sc.items[k + 1].b : (uint32_t)L.grid;
+                    const uint32_t tiles = (p[3] + it.a - 1) / it.a;
+                    if (next_b - it.b != tiles) { g_err = "tile prefix does not match the step's tile count"; rc = -11; }
+                    for (uint32_t t = 0; t < tiles && rc == 0; ++t)
+                        rc = exec_step(net, p, (int64_t)t * it.a, std::min<int64_t>(p[3], (int64_t)(t + 1) * it.a), arena,
+                                       (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
+                }
             }
         }
     }
@@ -218,6 +243,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     net.small_cells = g_small_cells;
     net.big_iters = g_big_iters;
     net.tile_h = g_tile_h;
+    net.fuse = g_fuse;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
     Request rq;

@@ -65,6 +65,7 @@ struct mibn_ctx {
     double arena_gb = 96.0;
     int threads = 0;
     int wg_per_cu = 8;
+    int trace = 0;  // debug: one stderr line per launch
     int64_t chunk = 16384;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
 };
 
@@ -151,7 +152,9 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "wg_per_cu") h->wg_per_cu = std::max(1, std::min(8, (int)value));
     else if (n == "chunk") h->chunk = std::max<int64_t>(1, (int64_t)value);
     else if (n == "big_iters") h->net.big_iters = std::max<int64_t>(1, (int64_t)value);  // test hooks: force tiling
-    else if (n == "tile_h") h->net.tile_h = std::max(1, std::min(kWG, (int)value));
+    else if (n == "tile_h") h->net.tile_h = std::max(0, std::min(kTileMax, (int)value));  // 0 = sized by traffic
+    else if (n == "trace") h->trace = (int)value;
+    else if (n == "fuse") h->net.fuse = value != 0;  // joint elimination of two variables per pass
     else if (n == "small_cells") h->net.small_cells = std::max(1, std::min(kMaxT, (int)value));  // test hook: forces FIBER steps on small networks
     else { h->err = "unknown option " + n; return MIBN_E_ARG; }
     return MIBN_OK;
@@ -242,13 +245,14 @@ int default_threads() {
 }
 
 using KernelFn = void (*)(LevelArgs);
+#define MIBN_FIBER_ROW(NB, C) fiber_tile_kernel<NB, C, 0>, fiber_tile_kernel<NB, C, 1>, fiber_tile_kernel<NB, C, 2>, fiber_tile_kernel<NB, C, 3>
 const KernelFn kKernels[kNumKernels] = {
     seg_kernel,
-    fiber_tile_kernel<1, 4, 1>, fiber_tile_kernel<1, 4, 4>, fiber_tile_kernel<1, 2, 1>, fiber_tile_kernel<1, 2, 4>,
-    fiber_tile_kernel<1, 0, 1>, fiber_tile_kernel<1, 0, 4>, fiber_tile_kernel<2, 4, 1>, fiber_tile_kernel<2, 4, 4>,
-    fiber_tile_kernel<2, 2, 1>, fiber_tile_kernel<2, 2, 4>, fiber_tile_kernel<2, 0, 1>, fiber_tile_kernel<2, 0, 4>,
+    MIBN_FIBER_ROW(1, 0), MIBN_FIBER_ROW(1, 1), MIBN_FIBER_ROW(1, 2),
+    MIBN_FIBER_ROW(2, 0), MIBN_FIBER_ROW(2, 1), MIBN_FIBER_ROW(2, 2),
     generic_tile_kernel<1>, generic_tile_kernel<2>, generic_tile_kernel<3>, generic_tile_kernel<4>,
     generic_tile_kernel<5>, generic_tile_kernel<6>};
+#undef MIBN_FIBER_ROW
 
 // wait for a set's launches and book their HIP-event durations per kernel
 int retire(mibn_ctx *h, mibn_ctx::Set &st) {
@@ -264,6 +268,7 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         k.ms += ms;
         k.alg_bytes += t.bytes;
         k.items += t.items;
+        if (h->trace) std::fprintf(stderr, "[mibn launch] %-32s wgs %8.0f MB %10.2f ms %8.4f -> %7.1f GB/s\n", kernel_name(t.kid), t.items, t.bytes / 1e6, ms, t.bytes / ms / 1e6);
     }
     st.timed.clear();
     st.ev_used = 0;
@@ -392,19 +397,22 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             A.arena = h->d_arena;
             A.results = h->d_results + (out_off[b0] - out_off[0]);
             size_t e_prev = 0;
+            double n_wg = 0;
             if ((rc = next_event(h, st, e_prev))) return rc;
             for (const Launch &L : sc.launches) {
                 A.items = st.d_items + L.first;
-                hipLaunchKernelGGL(kKernels[L.kid], dim3((unsigned)L.count), dim3(kWG), 0, h->stream, A);
+                A.n_items = (int)L.count;
+                hipLaunchKernelGGL(kKernels[L.kid], dim3((unsigned)L.grid), dim3(kWG), 0, h->stream, A);
                 size_t e_next = 0;
                 if ((rc = next_event(h, st, e_next))) return rc;
-                st.timed.push_back({L.kid, e_prev, e_next, L.alg_bytes, (double)L.count});
+                st.timed.push_back({L.kid, e_prev, e_next, L.alg_bytes, (double)L.grid});
+                n_wg += (double)L.grid;
                 e_prev = e_next;
             }
             HIP_TRY(h, hipGetLastError());
             st.busy = true;
             h->stats.arena_bytes = std::max(h->stats.arena_bytes, (double)need_bytes);
-            h->stats.n_workgroups += (double)sc.items.size();
+            h->stats.n_workgroups += n_wg;
             r0 = r1;
         }
         h->stats.alg_bytes += ck.st.alg_bytes;

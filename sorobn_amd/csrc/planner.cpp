@@ -306,6 +306,7 @@ struct Emitter {
     }
 
     using Strides = int64_t[kMaxIn][kRawAxes];
+    using XStrides = int64_t[kMaxIn][2];
 
     // GENERIC encoding: iteration space = output cells
     void emit_generic(const PF *const *ins, int n_in, const Strides &s, const int64_t *xs, const PF &out, int64_t cells,
@@ -348,14 +349,14 @@ struct Emitter {
     }
 
     // FIBER encoding (see planner.h); returns false when the step does not fit the form
-    bool emit_fiber(const PF *const *ins, int n_in, const Strides &s, const int64_t *xs, const PF &out, int cx) {
+    bool emit_fiber(const PF *const *ins, int n_in, const Strides &s, const XStrides &xs, const PF &out, int cx, int c1) {
         const int na = out.n;
         int big[kMaxIn], small[kMaxIn], nb = 0, ns = 0;
         for (int j = 0; j < n_in; ++j) {
             if (ins[j]->cells > net.small_cells) big[nb++] = j;
             else small[ns++] = j;
         }
-        if (nb < 1 || nb > 2 || ns > kMaxSmall || cx > 16) return false;
+        if (nb < 1 || nb > 2 || ns > kMaxSmall || cx > kMaxCx) return false;
         // N axes: no big input depends on them; keep at most kMaxNC combinations (fastest axes first)
         int naxes[kRawAxes], raxes[kRawAxes], nN = 0, nr = 0;
         int64_t NC = 1;
@@ -392,6 +393,13 @@ struct Emitter {
         while (nlo < nr && lo < kLoTarget && lo * rcard[nlo] <= kFiberLoMax) lo *= rcard[nlo++];
         int64_t rcells = 1;
         for (int i = 0; i < nr; ++i) rcells *= rcard[i];
+        if (rcells < net.big_iters) return false;  // small steps run in the segment interpreter (GENERIC form)
+        // contiguous fibers: N-combination n at offset n, lane cell l at l*NC
+        bool contig = true;
+        {
+            int64_t expect = NC;
+            for (int i = 0; i < nlo; ++i) { contig = contig && rost[i] == expect; expect *= rcard[i]; }
+        }
         // merge adjacent R axes contiguous in the output, in T and in every big input
         int64_t mc[kRawAxes], mo[kRawAxes], mt[kRawAxes], mb[2][kRawAxes];
         int ma = 0, mlo = 0;
@@ -411,28 +419,9 @@ struct Emitter {
             }
         }
         if (ma > kMaxAxes) return false;
-        const int words = kHdrWords + 3 * nb + ns * (3 + nT) + nT + (int)NC + 3 * ma + nb * ma;
+        const int words = kHdrWords + 4 * nb + ns * (4 + nT) + nT + (int)NC + 3 * ma + nb * ma;
         if (words > kMaxStepWords) return false;
-        uint32_t *w = prog.extend(words);
-        header(w, kKindFiber, nb + ns, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
-        w[7] = (uint32_t)nb | ((uint32_t)ns << 4) | ((uint32_t)nN << 8) | ((uint32_t)nctrl << 12) | ((uint32_t)NC << 16);
-        w[8] = (uint32_t)T;
-        uint32_t *p = w + kHdrWords;
-        for (int b = 0; b < nb; ++b) {
-            *p++ = (uint32_t)(ins[big[b]]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[big[b]]->off >> 32);
-            *p++ = (uint32_t)(int32_t)xs[big[b]];
-        }
-        for (int k = 0; k < ns; ++k) {
-            const int j = small[k];
-            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j]->off >> 32);
-            *p++ = (uint32_t)(int32_t)xs[j];
-            for (int i = 0; i < nN; ++i) *p++ = (uint32_t)(int32_t)s[j][naxes[i]];
-            for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)(int32_t)s[j][ctrl[i]];
-        }
-        for (int i = 0; i < nN; ++i) *p++ = (uint32_t)net.card[out.vars[naxes[i]]];
-        for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)net.card[out.vars[ctrl[i]]];
+        uint32_t nout[kMaxNC];
         for (int64_t n = 0; n < NC; ++n) {
             int64_t r = n, off = 0;
             for (int i = 0; i < nN; ++i) {
@@ -440,25 +429,52 @@ struct Emitter {
                 off += (r % c) * out.strides[naxes[i]];
                 r /= c;
             }
-            *p++ = (uint32_t)off;
+            nout[n] = (uint32_t)off;
+            contig = contig && off == n;
         }
+        uint32_t *w = prog.extend(words);
+        header(w, kKindFiber, nb + ns, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
+        if (contig) w[1] |= kFlagContig << 16;
+        w[7] = (uint32_t)nb | ((uint32_t)ns << 4) | ((uint32_t)nN << 8) | ((uint32_t)nctrl << 12) | ((uint32_t)NC << 16);
+        w[8] = (uint32_t)T | ((uint32_t)c1 << 16);
+        uint32_t *p = w + kHdrWords;
+        for (int b = 0; b < nb; ++b) {
+            *p++ = (uint32_t)(ins[big[b]]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[big[b]]->off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[big[b]][0];
+            *p++ = (uint32_t)(int32_t)xs[big[b]][1];
+        }
+        for (int k = 0; k < ns; ++k) {
+            const int j = small[k];
+            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j]->off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[j][0];
+            *p++ = (uint32_t)(int32_t)xs[j][1];
+            for (int i = 0; i < nN; ++i) *p++ = (uint32_t)(int32_t)s[j][naxes[i]];
+            for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)(int32_t)s[j][ctrl[i]];
+        }
+        for (int i = 0; i < nN; ++i) *p++ = (uint32_t)net.card[out.vars[naxes[i]]];
+        for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)net.card[out.vars[ctrl[i]]];
+        for (int64_t n = 0; n < NC; ++n) *p++ = nout[n];
         for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = (uint32_t)mt[a]; }
         for (int b = 0; b < nb; ++b)
             for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)mb[b][a];
         return true;
     }
 
-    // Emit one step: multiply `ins`, sum out x (x < 0: product only); the new factor is written to `out`.
-    void emit(const PF *const *ins, int n_in, int x, bool final_, int64_t final_off, PF &out) {
+    // Emit one step: multiply `ins`, sum out the nx (0..2) variables X (nx = 0: product only); the new factor is
+    // written to `out`.  fiber_only: emit nothing and return false unless the step fits the FIBER form (used to try
+    // the joint elimination of two variables).
+    bool emit(const PF *const *ins, int n_in, const int *X, int nx, bool final_, int64_t final_off, PF &out, bool fiber_only) {
         out.scope = Bits{};
         out.scope.nw = net.nw;
         for (int j = 0; j < n_in; ++j) out.scope.or_(ins[j]->scope);
         const double prod_log2 = scope_log2(net, out.scope);
-        if (x >= 0) out.scope.clr(x);
+        for (int k = 0; k < nx; ++k) out.scope.clr(X[k]);
         int na = 0;
         bool overflow = false;
         out.scope.for_each([&](int v) { if (na < kRawAxes) out.vars[na++] = v; else overflow = true; });
-        if (overflow) { err = "a factor has more than " + std::to_string(kRawAxes) + " axes"; return; }
+        if (overflow) { if (!fiber_only) err = "a factor has more than " + std::to_string(kRawAxes) + " axes"; return false; }
         // layout: longest-living variable fastest (insertion sort on the key, descending)
         for (int i = 1; i < na; ++i) {
             const int v = out.vars[i];
@@ -471,26 +487,28 @@ struct Emitter {
         for (int a = 0; a < na; ++a) {
             out.strides[a] = cells;
             cells *= net.card[out.vars[a]];
-            if (cells >= (1ll << 31)) { err = "an intermediate factor has >= 2^31 cells"; return; }
-            pos[out.vars[a]] = a;
+            if (cells >= (1ll << 31)) { if (!fiber_only) err = "an intermediate factor has >= 2^31 cells"; return false; }
         }
+        for (int a = 0; a < na; ++a) pos[out.vars[a]] = a;
         out.cells = cells;
-        // per-input strides along the output axes, and along x
+        // per-input strides along the output axes, and along the eliminated variables
         Strides s;
-        int64_t xs[kMaxIn];
+        XStrides xs;
         double in_cells = 0;
         for (int j = 0; j < n_in; ++j) {
             for (int a = 0; a < na; ++a) s[j][a] = 0;
-            xs[j] = 0;
+            xs[j][0] = xs[j][1] = 0;
             for (int k = 0; k < ins[j]->n; ++k) {
                 const int v = ins[j]->vars[k];
-                if (v == x) xs[j] = ins[j]->strides[k];
+                if (nx > 0 && v == X[0]) xs[j][0] = ins[j]->strides[k];
+                else if (nx > 1 && v == X[1]) xs[j][1] = ins[j]->strides[k];
                 else s[j][pos[v]] = ins[j]->strides[k];
             }
             in_cells += (double)ins[j]->cells;
         }
         for (int a = 0; a < na; ++a) pos[out.vars[a]] = -1;
-        const int cx = x >= 0 ? net.card[x] : 1;
+        const int c1 = nx > 0 ? net.card[X[0]] : 1;
+        const int cx = nx > 1 ? c1 * net.card[X[1]] : c1;
         if (final_) {
             out.off = (uint64_t)final_off;
             out.alloc = 0;
@@ -499,8 +517,17 @@ struct Emitter {
             out.alloc = cells;
         }
         const size_t step_base = prog.size;
-        if (!(!final_ && emit_fiber(ins, n_in, s, xs, out, cx))) emit_generic(ins, n_in, s, xs, out, cells, cx, final_);
-        if (!err.empty()) return;
+        const bool fiber = !final_ && emit_fiber(ins, n_in, s, xs, out, cx, c1);
+        if (!fiber) {
+            if (fiber_only) {
+                if (out.alloc) arena.release((int64_t)out.off, out.alloc);
+                return false;
+            }
+            int64_t xs1[kMaxIn];
+            for (int j = 0; j < n_in; ++j) xs1[j] = xs[j][0];
+            emit_generic(ins, n_in, s, xs1, out, cells, cx, final_);
+        }
+        if (!err.empty()) return false;
         prog.data[step_base + 9] = (uint32_t)(((int64_t)in_cells + cells + 2) >> 2);  // section-8(d) cells of this step, units of 4
         st.alg_bytes += 8.0 * (in_cells + (double)cells);
         const double pc = std::exp2(prod_log2);
@@ -509,6 +536,7 @@ struct Emitter {
         st.n_steps += 1;
         for (int j = 0; j < n_in; ++j)
             if (ins[j]->alloc) arena.release((int64_t)ins[j]->off, ins[j]->alloc);
+        return true;
     }
 };
 
@@ -617,7 +645,7 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
             if (pool.size() + 2 > pool.capacity()) { em.err = "planner factor pool exhausted"; return -1; }
             std::sort(ins, ins + n_in, [](const PF *a, const PF *b) { return a->cells < b->cells; });
             pool.emplace_back();
-            em.emit(ins, kMaxIn, -1, false, 0, pool.back());
+            em.emit(ins, kMaxIn, nullptr, 0, false, 0, pool.back(), false);
             for (int k = kMaxIn; k < n_in; ++k) ins[k - kMaxIn] = ins[k];
             n_in -= kMaxIn;
             ins[n_in++] = &pool.back();
@@ -625,18 +653,53 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
         if (!em.err.empty()) return -1;
         if (pool.size() + 1 > pool.capacity()) { em.err = "planner factor pool exhausted"; return -1; }
         pool.emplace_back();
-        em.emit(ins, n_in, x, final_, final_off, pool.back());
+        em.emit(ins, n_in, &x, x >= 0 ? 1 : 0, final_, final_off, pool.back(), false);
         return (int)pool.size() - 1;
     };
-    for (int32_t x : best) {
+    for (size_t i = 0; i < best.size(); ++i) {
+        const int32_t x = best[i];
         // pop every factor mentioning x (bayes_net.py:780-784)
         int n_in = 0;
         size_t k = 0;
-        for (size_t i = 0; i < live.size(); ++i) {
-            if (pool[live[i]].scope.test(x)) ins[n_in++] = &pool[live[i]];
-            else live[k++] = live[i];
+        for (size_t l = 0; l < live.size(); ++l) {
+            if (pool[live[l]].scope.test(x)) ins[n_in++] = &pool[live[l]];
+            else live[k++] = live[l];
         }
         live.resize(k);
+        // Joint elimination: if the factor this step creates is a big table that the very next step consumes, both
+        // variables are summed out in one pass over the inputs and the intermediate never touches HBM.
+        if (net.fuse && i + 1 < best.size() && n_in < kMaxIn && pool.size() + 1 <= pool.capacity()) {
+            const int32_t x2 = best[i + 1];
+            bool link = false;
+            Bits u;
+            u.nw = net.nw;
+            for (int j = 0; j < n_in; ++j) { link = link || ins[j]->scope.test(x2); u.or_(ins[j]->scope); }
+            if (link && net.card[x] * net.card[x2] <= kMaxCx &&
+                scope_log2(net, u) - net.log2card[x] > std::log2((double)net.small_cells)) {
+                int n2 = n_in;
+                bool fits = true;
+                for (size_t l = 0; l < live.size(); ++l)
+                    if (pool[live[l]].scope.test(x2)) {
+                        if (n2 >= kMaxIn) { fits = false; break; }
+                        ins[n2++] = &pool[live[l]];
+                    }
+                if (fits) {
+                    const int X[2] = {x, x2};
+                    pool.emplace_back();
+                    if (em.emit(ins, n2, X, 2, false, 0, pool.back(), true)) {
+                        k = 0;
+                        for (size_t l = 0; l < live.size(); ++l)
+                            if (!pool[live[l]].scope.test(x2)) live[k++] = live[l];
+                        live.resize(k);
+                        live.push_back((int)pool.size() - 1);
+                        ++i;
+                        continue;
+                    }
+                    pool.pop_back();
+                    if (!em.err.empty()) return em.err;
+                }
+            }
+        }
         const int out = emit_limited(n_in, x, false, 0);  // pointwise_mul + sum_out (785)
         if (!em.err.empty()) return em.err;
         live.push_back(out);
@@ -810,23 +873,43 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
 // ------------------------------------------------------------------------------------ schedule
 
 const char *kernel_name(int kid) {
-    static const char *names[kNumKernels] = {
-        "seg_kernel",
-        "fiber_tile_kernel<1,4,1>", "fiber_tile_kernel<1,4,4>", "fiber_tile_kernel<1,2,1>", "fiber_tile_kernel<1,2,4>",
-        "fiber_tile_kernel<1,0,1>", "fiber_tile_kernel<1,0,4>", "fiber_tile_kernel<2,4,1>", "fiber_tile_kernel<2,4,4>",
-        "fiber_tile_kernel<2,2,1>", "fiber_tile_kernel<2,2,4>", "fiber_tile_kernel<2,0,1>", "fiber_tile_kernel<2,0,4>",
-        "generic_tile_kernel<1>", "generic_tile_kernel<2>", "generic_tile_kernel<3>", "generic_tile_kernel<4>",
-        "generic_tile_kernel<5>", "generic_tile_kernel<6>"};
-    return kid >= 0 && kid < kNumKernels ? names[kid] : "?";
+    static std::string names[kNumKernels];
+    static bool init = false;
+    if (!init) {
+        names[kKidSeg] = "seg_kernel";
+        static const char *cxn[3] = {"cx4", "cx16", "cxN"}, *ncn[4] = {"nc1", "nc4", "nc16", "ncN"};
+        for (int nb = 1; nb <= 2; ++nb)
+            for (int c = 0; c < 3; ++c)
+                for (int n = 0; n < 4; ++n)
+                    names[kKidFiber0 + (nb - 1) * 12 + c * 4 + n] =
+                        "fiber_tile_kernel<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
+        for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic_tile_kernel<" + std::to_string(j + 1) + ">";
+        init = true;
+    }
+    return kid >= 0 && kid < kNumKernels ? names[kid].c_str() : "?";
+}
+
+int fiber_cx_class(const uint32_t *w) {
+    const int cx = (int)(w[1] & 0xffff), c1 = (int)(w[8] >> 16);
+    if (cx == 4 && c1 == 4) return 0;
+    if (cx == 16 && c1 == 4) return 1;
+    return 2;
+}
+
+int fiber_nc_class(const uint32_t *w) {
+    const int NC = (int)(w[7] >> 16);
+    const bool contig = ((w[1] >> 16) & kFlagContig) != 0;
+    if (NC == 1) return 0;
+    if (NC == 4 && contig) return 1;
+    if (NC == 16 && contig) return 2;
+    return 3;
 }
 
 int kernel_id_of_step(const uint32_t *w) {
     const uint32_t kind = w[0] & 0xff;
-    const int cx = (int)(w[1] & 0xffff);
     if (kind == kKindFiber) {
-        const int nb = w[7] & 0xf, NC = (int)(w[7] >> 16);
-        const int cxc = cx == 4 ? 0 : (cx == 2 ? 1 : 2);
-        return kKidFiber0 + (nb - 1) * 6 + cxc * 2 + (NC > 1 ? 1 : 0);
+        const int nb = w[7] & 0xf;
+        return kKidFiber0 + (nb - 1) * 12 + fiber_cx_class(w) * 4 + fiber_nc_class(w);
     }
     const int n_in = (w[0] >> 8) & 0xff;
     return kKidGeneric0 + std::min(std::max(n_in, 1), kMaxIn) - 1;
@@ -835,10 +918,22 @@ int kernel_id_of_step(const uint32_t *w) {
 // section-8(d) algorithmic bytes of one step (the planner stores (input + output cells) / 4 in w9)
 int64_t step_cost_bytes(const uint32_t *w) { return 32 * (int64_t)w[9]; }
 
+bool step_is_tiled(const Network &net, const uint32_t *w) {
+    if ((w[0] & 0xff) == kKindFiber) return true;  // FIBER steps are only emitted above big_iters
+    const bool fin = (w[1] >> 16) & kFlagFinal;
+    return !fin && (int64_t)w[2] * (int64_t)w[3] >= net.big_iters;
+}
+
+int step_tile_h(const Network &net, const uint32_t *w) {
+    if (net.tile_h > 0) return std::min(net.tile_h, kTileMax);
+    // bytes one hi iteration moves = the step's section-8(d) traffic / hi (broadcast re-reads of a small "big" input
+    // are cache hits, they do not count)
+    const int64_t per_iter = std::max<int64_t>(1, step_cost_bytes(w) / std::max<int64_t>(1, (int64_t)w[3]));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(kTileMax, kTileBytes / per_iter));
+}
+
 void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<ProgBuf> &bufs, int64_t r0, int64_t r1,
                     Schedule &out) {
-    const int64_t kBigIters = net.big_iters;
-    const uint32_t kTileH = (uint32_t)std::max(1, net.tile_h);
     const int64_t n = r1 - r0;
     out.items.clear();
     out.launches.clear();
@@ -872,17 +967,12 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         };
         for (int s = 0; s < n_steps; ++s) {
             const uint32_t *w = prog + off;
-            const int64_t iters = (int64_t)w[2] * (int64_t)w[3];
-            const bool fin = (w[1] >> 16) & 1;
             const double bytes = (double)step_cost_bytes(w);
-            if (!fin && iters >= kBigIters && w[3] > 1) {
+            if (step_is_tiled(net, w)) {
                 flush();
-                const int kid = kernel_id_of_step(w);
-                const uint32_t hi = w[3];
-                for (uint32_t h = 0; h < hi; h += kTileH) {
-                    const uint32_t he = std::min(hi, h + kTileH);
-                    tagged.push_back({{(uint32_t)i, off, h, he}, level, kid, bytes * (double)(he - h) / (double)hi});
-                }
+                const uint32_t th = (uint32_t)step_tile_h(net, w);
+                const uint32_t tiles = (w[3] + th - 1) / th;
+                tagged.push_back({{(uint32_t)i, off, th, tiles}, level, kernel_id_of_step(w), bytes});  // b = tile count for now
                 ++level;
             } else {
                 if (!seg_steps) seg_first = (int)off;
@@ -907,10 +997,20 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
     for (size_t k = 0; k < nb; ++k)
         if (count[k + 1] > count[k]) {
             const int level = (int)(k / kNumKernels), kid = (int)(k % kNumKernels);
-            if (kid == kKidSeg)  // longest segments first: they are the tail of their launch
+            size_t grid = count[k + 1] - count[k];
+            if (kid == kKidSeg) {  // longest segments first: they are the tail of their launch
                 std::stable_sort(out.items.begin() + count[k], out.items.begin() + count[k + 1],
                                  [](const Item &a, const Item &b) { return a.a > b.a; });
-            out.launches.push_back({level, kid, count[k], count[k + 1] - count[k], bytes[k]});
+            } else {               // tile counts -> first-tile prefix (the kernel's binary-search key)
+                uint32_t first = 0;
+                for (size_t q = count[k]; q < count[k + 1]; ++q) {
+                    const uint32_t tiles = out.items[q].b;
+                    out.items[q].b = first;
+                    first += tiles;
+                }
+                grid = first;
+            }
+            out.launches.push_back({level, kid, count[k], count[k + 1] - count[k], grid, bytes[k]});
         }
 }
 

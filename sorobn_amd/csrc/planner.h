@@ -56,8 +56,9 @@ struct Network {
     std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier)
     int nw = 1;
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
-    int64_t big_iters = 16384;  // a step with at least this many lane-iterations is a level of its own (tiled)
-    int tile_h = 128;        // hi iterations per tile
+    int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
+    int tile_h = 0;          // hi iterations per tile; 0 = sized for kTileBytes of traffic per tile
+    int fuse = 1;            // eliminate two consecutive variables in one FIBER step when the first result would be a big table
 
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
@@ -82,39 +83,46 @@ struct PlanStats {
 //   program := n_steps, step*
 //   every step starts with a 10-word header
 //      w0 = kind | n_in<<8 | n_axes<<16 | nlo<<24      kind: 0 = GENERIC, 1 = FIBER
-//      w1 = cx | flags<<16      cx = cardinality of the eliminated axis (1 = product only)
+//      w1 = cx | flags<<16      cx = number of eliminated combinations (1 = product only)
 //      w2 = lo_cells   w3 = hi_cells     lane-varying / wave-uniform blocks of the iteration space
 //      w4,w5 = out_off (u64, doubles; arena-relative, or result-buffer-relative if FINAL)
 //      w6 = step_words (total words of this step)
-//      w7 = FIBER: n_big | n_small<<4 | n_N<<8 | n_ctrl<<12 | NC<<16        w8 = FIBER: T_cells
+//      w7 = FIBER: n_big | n_small<<4 | n_N<<8 | n_ctrl<<12 | NC<<16
+//      w8 = FIBER: T_cells | c1<<16    (c1 = cardinality of the first eliminated variable; cx = c1 * c2)
 //      w9 = (input cells + output cells) / 4  - the step's section-8(d) traffic, for per-kernel rooflines
 //
-//   GENERIC  psi[o] = sum_x prod_j phi_j[off_j(o) + x*xs_j], iteration space = output cells:
+//   GENERIC  psi[o] = sum_x prod_j phi_j[off_j(o) + x*xs_j], iteration space = output cells, one eliminated variable:
 //      per input j<n_in:  in_off lo, in_off hi (bit 63 = constants pool), xs_j
 //      card[a]            a < n_axes          (output axes, fastest first, merged)
 //      stride[j][a]       j < n_in, a < n_axes (int32, doubles)
 //
 //   FIBER    the inputs are split into big tables (<= 2, streamed from HBM) and small ones (CPT
-//      slices, <= Network::small_cells cells each).  Output axes no big input depends on are the N axes
+//      slices, <= Network::small_cells cells each).  One or two variables are eliminated in the same pass
+//      (x enumerates their joint values, x = x1 + c1*x2).  Output axes no big input depends on are the N axes
 //      (NC = prod of their cards <= kMaxNC): one lane owns one cell r of the remaining R axes, loads
 //      the cx values of each big input once and produces the whole N-fiber in registers:
 //           out[r, n] = sum_x (prod_b F_b[r, x]) * T[n, x, ctrl(r)]
-//      where T = product of the small inputs, tabulated once per step in LDS over
+//      where T = product of the small inputs, tabulated once per tile in LDS over
 //      (n fastest, x, ctrl axes = the R axes a small input depends on).  Iteration space = R cells.
-//      per big input b<n_big:     off lo, off hi, xs_b
-//      per small input s<n_small: off lo, off hi, xs_s, tstride[s][k] k < n_N + n_ctrl
+//      per big input b<n_big:     off lo, off hi, xs1_b, xs2_b        (offset of x = x1*xs1 + x2*xs2)
+//      per small input s<n_small: off lo, off hi, xs1_s, xs2_s, tstride[s][k] k < n_N + n_ctrl
 //      tcard[k]                   k < n_N + n_ctrl     (N axes, then ctrl axes)
 //      nout[n]                    n < NC               (output offset of N-combination n)
 //      card[a], ostride[a], tstride[a]    a < n_axes   (R axes, merged; tstride in T cells)
 //      bstride[b][a]              b < n_big, a < n_axes
-constexpr uint32_t kFlagFinal = 1;
+//      flag CONTIG: nout[n] == n and the lane-varying block is contiguous in the output (cell l of the block at
+//      l*NC), i.e. the lanes of a wave own one contiguous 64*NC-cell region (vector / transposed stores).
+constexpr uint32_t kFlagFinal = 1, kFlagContig = 2;
 constexpr int kHdrWords = 10;
 constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;
 constexpr int kMaxNC = 16;         // N-fiber length held in registers
 constexpr int kMaxT = 2048;        // T cells (16 KiB of LDS)
 constexpr int kMaxSmall = 4;
-constexpr int kFiberLoMax = 512;    // R cells in the lane-varying block of a FIBER step (2 per lane)
+constexpr int kFiberLoMax = 256;    // R cells in the lane-varying block of a FIBER step (1 per lane)
+constexpr int kMaxCx = 16;          // eliminated combinations of a FIBER step (register fiber of loads)
 constexpr int kMaxStepWords = 384;  // LDS copy of one step descriptor
+constexpr int kTileMax = 64;        // hi iterations per tile (their offsets are decoded in one go)
+constexpr int64_t kTileBytes = 512 << 10;  // traffic one tile should move (tile_h = 0)
 
 // Growable word buffer the planner appends programs to.  The engine backs it with pinned host memory
 // (so the upload is a true async DMA) and keeps it across calls; the default backing is malloc.
@@ -175,20 +183,26 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
 struct Item {
     uint32_t req;      // request index within the wave
     uint32_t rel_off;  // word offset of the (first) step inside the request's program
-    uint32_t a, b;     // SEGMENT: a = number of steps.  TILE: [a, b) = range of hi iterations
+    uint32_t a, b;     // SEGMENT: a = number of steps.  TILED step: a = hi iterations per tile, b = index of its first
+                       // tile within the launch (a workgroup finds its step by binary search on b)
 };
 struct Launch {
     int level, kid;
     size_t first, count;  // range in Schedule::items
-    double alg_bytes;     // algorithmic bytes of the steps (tiles pro rata) in this launch
+    size_t grid;          // workgroups: SEGMENT = count, tiled = total tiles
+    double alg_bytes;     // algorithmic bytes of the steps in this launch
 };
-constexpr int kKidSeg = 0;         // segment interpreter
-constexpr int kKidFiber0 = 1;      // 12 FIBER tile kernels: 1 + (n_big-1)*6 + cx_class*2 + (NC > 1)
-constexpr int kKidGeneric0 = 13;   // 6 GENERIC tile kernels: 13 + (n_in - 1)
-constexpr int kNumKernels = 19;
+constexpr int kKidSeg = 0;         // segment interpreter (small GENERIC steps)
+constexpr int kKidFiber0 = 1;      // 24 FIBER tile kernels: 1 + (n_big-1)*12 + cx_class*4 + nc_class
+constexpr int kKidGeneric0 = 25;   // 6 GENERIC tile kernels: 25 + (n_in - 1)
+constexpr int kNumKernels = 31;
 const char *kernel_name(int kid);
 int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
+int fiber_cx_class(const uint32_t *w);     // 0: cx = 4   1: cx = 16 = 4 x 4   2: anything else (runtime loop)
+int fiber_nc_class(const uint32_t *w);     // 0: NC = 1   1: NC = 4 contiguous   2: NC = 16 contiguous   3: anything else
 int64_t step_cost_bytes(const uint32_t *w);
+bool step_is_tiled(const Network &net, const uint32_t *w);
+int step_tile_h(const Network &net, const uint32_t *w);
 
 struct Schedule {
     std::vector<Item> items;

@@ -28,6 +28,7 @@ def lib():
         L.plan_sim_error.restype = C.c_char_p
         L.plan_sim_set_small_cells.argtypes = [C.c_int]
         L.plan_sim_set_tiling.argtypes = [C.c_int, C.c_int]
+        L.plan_sim_set_fuse.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -35,9 +36,10 @@ def lib():
 class SimEngine:
     """Same surface as sorobn_amd._capi.Engine for the exact path, executed by plan_sim."""
 
-    def __init__(self, flat, small_cells=1024, tiling=(16384, 128)):
+    def __init__(self, flat, small_cells=1024, tiling=(4096, 0), fuse=1):
         self.small_cells = small_cells  # lower it to force FIBER steps on small networks
         self.tiling = tiling            # (big_iters, tile_h): lower them to force tiled levels on small networks
+        self.fuse = fuse                # joint elimination of two variables per FIBER step
         self.f = flat
         self.card = flat.card
         self.last_stats = None
@@ -56,6 +58,7 @@ class SimEngine:
         hints = np.ascontiguousarray(self.hints.reshape(-1) if self.hints.size else [0], np.int32)
         L.plan_sim_set_small_cells(int(self.small_cells))
         L.plan_sim_set_tiling(int(self.tiling[0]), int(self.tiling[1]))
+        L.plan_sim_set_fuse(int(self.fuse))
         rc = L.plan_sim_query(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64),
                               p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
                               p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
@@ -76,17 +79,17 @@ class SimEngine:
         return (np.concatenate(outs) if outs else np.zeros(0)), off
 
 
-def sim_backend(bn, small_cells=1024, tiling=(16384, 128)):
+def sim_backend(bn, small_cells=1024, tiling=(4096, 0), fuse=1):
     """A Backend whose engine is the CPU plan simulator (bypasses Backend.__init__)."""
     b = Backend.__new__(Backend)
     b.flat = flatten(bn)
     b.fingerprint = Backend.fingerprint_of(bn)
-    b.engine = SimEngine(b.flat, small_cells, tiling)
+    b.engine = SimEngine(b.flat, small_cells, tiling, fuse)
     b._anc = {}
     return b
 
 
-def attach(bn, small_cells=1024, tiling=(16384, 128)):
+def attach(bn, small_cells=1024, tiling=(4096, 0), fuse=1):
     """Make a sorobn_amd.BayesNet answer through the simulator (tests only)."""
-    bn._backend = sim_backend(bn, small_cells, tiling)
+    bn._backend = sim_backend(bn, small_cells, tiling, fuse)
     return bn

@@ -40,27 +40,29 @@ def _check_requests(bn, requests, ctx):
 
 # small_cells < 1024 forces the FIBER (streaming) step form, normally reserved for > 8 KiB tables, onto the
 # small golden networks: mixed cardinalities, sparse CPTs, every (n_big, cx, NC) kernel specialisation
-# (big_iters, tile_h) below the defaults (16384, 128) turn small steps into tiled levels, so the tile kernels
-# of every shape run on the small golden networks too
-@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (1, (2, 1)), (6, (8, 3))])
+# (big_iters, tile_h) below the defaults (4096, auto) turn small steps into tiled levels, so the tile kernels
+# of every shape run on the small golden networks too; fuse = joint elimination of two variables per pass
+@pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (1, (2, 1), 1), (6, (8, 3), 1), (1, (2, 1), 0)])
 @pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
-def test_golden_networks(amd, fname, small_cells, tiling):
+def test_golden_networks(amd, fname, small_cells, tiling, fuse):
     for net in gu.load(fname):
         bn = netspec.build(net["spec"], amd.BayesNet)
         bn.backend.engine.set_option("small_cells", small_cells)
         bn.backend.engine.set_option("big_iters", tiling[0])
         bn.backend.engine.set_option("tile_h", tiling[1])
+        bn.backend.engine.set_option("fuse", fuse)
         _check_requests(bn, net["requests"], net["spec"]["name"])
 
 
-@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (3, (4, 1)), (20, (64, 2))])
-def test_golden_small_grids(amd, small_cells, tiling):
+@pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (3, (4, 1), 1), (20, (64, 2), 1), (3, (4, 1), 0)])
+def test_golden_small_grids(amd, small_cells, tiling, fuse):
     for entry in gu.load("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
         bn = netspec.build(spec, amd.BayesNet)
         bn.backend.engine.set_option("small_cells", small_cells)
         bn.backend.engine.set_option("big_iters", tiling[0])
         bn.backend.engine.set_option("tile_h", tiling[1])
+        bn.backend.engine.set_option("fuse", fuse)
         _check_requests(bn, entry["requests"], spec["name"])
 
 
@@ -72,6 +74,27 @@ def test_golden_grid10x10(amd):
     spec = gu.grid_spec_from_recipe(entry)
     bn = netspec.build(spec, amd.BayesNet)
     _check_requests(bn, entry["requests"], spec["name"])
+
+
+def test_c3_fused_vs_single_variable_passes(amd):
+    """Size-independent property at the full C3 shapes: eliminating two variables per pass (cx16 / nc16
+    kernels, transposed stores) and one variable per pass (cx4 kernels) are different kernels and different
+    summation orders of the same contraction - the posteriors must agree to rounding."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 1024, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    fused = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    fused_bytes = be.engine.stats()["alg_bytes"]
+    names = {k["name"] for k in be.engine.kernel_stats()}
+    assert any("cx16" in n for n in names), names
+    be.engine.set_option("fuse", 0)
+    single = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert be.engine.stats()["alg_bytes"] > 1.3 * fused_bytes
+    assert not any("cx16" in k["name"] for k in be.engine.kernel_stats())
+    assert np.allclose(fused.sum(1), 1.0, atol=1e-12)
+    assert float(np.max(np.abs(fused - single))) <= 1e-13
 
 
 def test_single_query_api_alarm(amd):

@@ -144,20 +144,21 @@ def _check_requests(bn, requests, ctx, limit=None):
 # small_cells: inputs above this size are "big" -> lowering it forces the FIBER step form (normally only
 # used for > 8 KiB tables) onto the small golden networks, mixed cardinalities and sparse CPTs included
 # tiling = (big_iters, tile_h): lowering them turns small steps into tiled levels of the level-synchronous
-# schedule (normally only steps with >= 16384 lane-iterations, in tiles of 128 hi iterations)
-@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (1, (2, 1)), (6, (8, 3))])
+# schedule (normally only steps with >= 4096 lane-iterations, in tiles sized for 512 KiB of traffic)
+# fuse: joint elimination of two consecutive variables in one FIBER step (on by default)
+@pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (1, (2, 1), 1), (6, (8, 3), 1), (1, (2, 1), 0)])
 @pytest.mark.parametrize("fname", ["examples.json", "random_dags.json"])
-def test_planner_programs_reproduce_reference(fname, small_cells, tiling):
+def test_planner_programs_reproduce_reference(fname, small_cells, tiling, fuse):
     for net in _nets(fname):
-        bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet), small_cells, tiling)
+        bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet), small_cells, tiling, fuse)
         _check_requests(bn, net["requests"], net["spec"]["name"], limit=None if small_cells == 1024 else 60)
 
 
-@pytest.mark.parametrize("small_cells,tiling", [(1024, (16384, 128)), (3, (4, 1)), (20, (64, 2))])
-def test_planner_programs_reproduce_reference_grids(small_cells, tiling):
+@pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (3, (4, 1), 1), (20, (64, 2), 1), (3, (4, 1), 0)])
+def test_planner_programs_reproduce_reference_grids(small_cells, tiling, fuse):
     for entry in _nets("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
-        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), small_cells, tiling)
+        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), small_cells, tiling, fuse)
         _check_requests(bn, entry["requests"], spec["name"])
 
 
@@ -168,6 +169,10 @@ def test_planner_programs_reproduce_reference_grid10x10():
     spec = gu.grid_spec_from_recipe(entry)
     bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
     _check_requests(bn, entry["requests"], spec["name"])
+    fused_bytes = bn.backend.engine.last_stats[0]
+    bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), fuse=0)  # one variable per pass
+    _check_requests(bn, entry["requests"][-4:], spec["name"])
+    assert fused_bytes < bn.backend.engine.last_stats[0]  # joint elimination moves fewer bytes
     worst = next(r for r in entry["requests"] if r["query"] == ["099"] and r["event"] == [["000", 0]])
     assert gu.expected(worst)[3].tolist() == [0.28215567090257165, 0.26459023658731734, 0.2448596401736336,
                                               0.20839445233647746]

@@ -30,18 +30,35 @@ def program(f, q, ev, codes):
 
 
 def decode(w):
+    """Decode a step program (planner.h encoding: 10-word header, GENERIC / FIBER bodies)."""
     steps = []
     n = int(w[0]); p = 1
     for _ in range(n):
-        w0 = int(w[p]); n_in = w0 & 0xff; na = (w0 >> 8) & 0xff; nlo = (w0 >> 16) & 0xff; fin = (w0 >> 24) & 1
-        cx, lo, hi = int(w[p + 1]), int(w[p + 2]), int(w[p + 3]); words = int(w[p + 6])
-        ins = []
-        for j in range(n_in):
-            off = int(w[p + 8 + 3 * j]) | (int(w[p + 9 + 3 * j]) << 32)
-            ins.append(("C" if off >> 63 else "A", off & ~(1 << 63), int(np.int32(w[p + 10 + 3 * j]))))
-        card = [int(x) for x in w[p + 8 + 3 * n_in:p + 8 + 3 * n_in + na]]
-        st = np.array(w[p + 8 + 3 * n_in + na:p + 8 + 3 * n_in + na + n_in * na]).astype(np.int32).reshape(n_in, na) if na else np.zeros((n_in, 0))
-        steps.append(dict(n_in=n_in, na=na, nlo=nlo, fin=fin, cx=cx, lo=lo, hi=hi, ins=ins, card=card, strides=st.tolist()))
+        w0 = int(w[p]); kind = w0 & 0xff; n_in = (w0 >> 8) & 0xff; na = (w0 >> 16) & 0xff; nlo = (w0 >> 24) & 0xff
+        cx = int(w[p + 1]) & 0xffff; fin = (int(w[p + 1]) >> 16) & 1
+        lo, hi, words = int(w[p + 2]), int(w[p + 3]), int(w[p + 6])
+        d = dict(kind="FIBER" if kind else "GENERIC", n_in=n_in, na=na, nlo=nlo, fin=fin, cx=cx, lo=lo, hi=hi,
+                 bytes=32 * int(w[p + 9]), words=words)
+        q = p + 10
+        I = lambda k: int(np.int32(w[k]))
+        if kind == 0:
+            d["ins"] = [("C" if int(w[q + 3 * j + 1]) >> 31 else "A", I(q + 3 * j + 2)) for j in range(n_in)]
+            q += 3 * n_in
+            d["card"] = [int(x) for x in w[q:q + na]]; q += na
+            d["strides"] = [[I(q + j * na + a) for a in range(na)] for j in range(n_in)]
+        else:
+            w7 = int(w[p + 7]); nb, ns, nN, nctrl, NC = w7 & 0xf, (w7 >> 4) & 0xf, (w7 >> 8) & 0xf, (w7 >> 12) & 0xf, w7 >> 16
+            nT = nN + nctrl
+            d.update(nb=nb, ns=ns, nN=nN, nctrl=nctrl, NC=NC, T=int(w[p + 8]) & 0xffff, c1=int(w[p + 8]) >> 16,
+                     contig=(int(w[p + 1]) >> 17) & 1)
+            d["big"] = [("C" if int(w[q + 4 * b + 1]) >> 31 else "A", (I(q + 4 * b + 2), I(q + 4 * b + 3))) for b in range(nb)]; q += 4 * nb
+            d["small"] = [("C" if int(w[q + k * (4 + nT) + 1]) >> 31 else "A", (I(q + k * (4 + nT) + 2), I(q + k * (4 + nT) + 3)),
+                           [I(q + k * (4 + nT) + 4 + t) for t in range(nT)]) for k in range(ns)]; q += ns * (4 + nT)
+            d["tcard"] = [int(x) for x in w[q:q + nT]]; q += nT
+            d["nout"] = [int(x) for x in w[q:q + NC]]; q += NC
+            d["rax"] = [(int(w[q + 3 * a]), I(q + 3 * a + 1), I(q + 3 * a + 2)) for a in range(na)]; q += 3 * na
+            d["bst"] = [[I(q + b * na + a) for a in range(na)] for b in range(nb)]
+        steps.append(d)
         p += words
     return steps
 
@@ -56,6 +73,11 @@ if __name__ == "__main__":
     steps = decode(program(f, [to_var[qs[i]]], to_var[evs[i]], ecs[i]))
     print("request", i, "q", qs[i], "ev", evs[i], "steps", len(steps))
     for k, s in enumerate(steps):
-        if s["lo"] * s["hi"] >= int(os.environ.get("MINCELLS", "1")):
-            print(k, f"n_in={s['n_in']} cx={s['cx']} cells={s['lo']*s['hi']:8d} lo={s['lo']} hi={s['hi']} nlo={s['nlo']} card={s['card']}",
-                  " | ".join(f"{t}{'' if t=='A' else ''} xs={xs} s={st}" for (t, o, xs), st in zip(s["ins"], s["strides"])))
+        if s["lo"] * s["hi"] < int(os.environ.get("MINCELLS", "1")):
+            continue
+        head = f"{k:3d} {s['kind']:7s} cx={s['cx']} lo={s['lo']} hi={s['hi']} nlo={s['nlo']} na={s['na']} MB={s['bytes']/1e6:8.3f}"
+        if s["kind"] == "GENERIC":
+            print(head, f"n_in={s['n_in']} card={s['card']} ins={s['ins']} strides={s['strides']}", "FINAL" if s["fin"] else "")
+        else:
+            print(head, f"nb={s['nb']} ns={s['ns']} c1={s['c1']} NC={s['NC']} contig={s['contig']} nctrl={s['nctrl']} T={s['T']} big={s['big']} small={[(t, x) for t, x, _ in s['small']]} "
+                        f"tcard={s['tcard']} nout={s['nout']} rax(card,ost,tst)={s['rax']} bst={s['bst']}")
