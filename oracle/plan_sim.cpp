@@ -190,16 +190,26 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     const uint32_t *prog = bufs[0].data + bp.local_off[0];
     int rc = 0;
     double bytes_check = 0;
+    // Execute the schedule exactly as the level kernel sees it: level by level, workgroup by workgroup, every
+    // workgroup looking its item up in wg_item and deriving its tile from (workgroup index - Item::b).
+    size_t wg_seen = 0;
     for (const Launch &L : sc.launches) {
         bytes_check += L.alg_bytes;
-        for (size_t k = L.first; k < L.first + L.count && rc == 0; ++k) {
+        if (L.wg_first != wg_seen) { g_err = "launches do not tile wg_item"; rc = -11; break; }
+        wg_seen += L.grid;
+        for (size_t wgi = L.wg_first; wgi < L.wg_first + L.grid && rc == 0; ++wgi) {
+            const uint32_t k = sc.wg_item[wgi];
+            if (k < L.first || k >= L.first + L.count) { g_err = "workgroup mapped to an item of another launch"; rc = -11; break; }
             const Item &it = sc.items[k];
+            const uint32_t wg = (uint32_t)(wgi - L.wg_level);  // level-relative index = blockIdx.x + wg_base
             const uint32_t *p = prog + it.rel_off;
-            if (L.kid == kKidSeg) {
-                for (uint32_t s = 0; s < it.a && rc == 0; ++s) {
-                    if (kernel_id_of_step(p) < 0) rc = -10;
+            if (it.a & kItemSegment) {
+                if (L.kid != kKidSeg || it.b != wg) { g_err = "segment item inconsistent"; rc = -11; break; }
+                const uint32_t n_steps = it.a & ~kItemSegment;
+                for (uint32_t s = 0; s < n_steps && rc == 0; ++s) {
+                    if ((p[0] & 0xff) != kKindGeneric) { g_err = "FIBER step inside a segment"; rc = -10; break; }
                     rc = exec_step(net, p, 0, p[3], arena, (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
-                    if (rc == 0 && ((p[1] >> 16) & 1)) {
+                    if (rc == 0 && ((p[1] >> 16) & kFlagFinal)) {
                         const uint64_t oo = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
                         const int64_t cells = (int64_t)p[2] * (int64_t)p[3];
                         double total = 0;
@@ -210,20 +220,23 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
                     p += p[6];
                 }
             } else {
-                if (kernel_id_of_step(p) != L.kid) { g_err = "tile scheduled on the wrong kernel"; rc = -11; }
-                else if (it.a < 1 || it.a > (uint32_t)kTileMax) { g_err = "tile height out of range"; rc = -11; }
-                else {
-                    // the workgroups [it.b, next item's b) of the launch each run one tile of it.a hi iterations
-                    const uint32_t next_b = k + 1 < L.first + L.count ? sc.items[k + 1].b : (uint32_t)L.grid;
+                if (kernel_id_of_step(p) != L.kid) { g_err = "tile scheduled under the wrong class"; rc = -11; break; }
+                if (it.a < 1 || it.a > (uint32_t)kTileMax || wg < it.b) { g_err = "tile geometry out of range"; rc = -11; break; }
+                const int64_t h0 = (int64_t)(wg - it.b) * it.a;
+                const int64_t h1 = std::min<int64_t>(p[3], h0 + it.a);
+                if (h0 >= (int64_t)p[3]) { g_err = "workgroup beyond the step's last tile"; rc = -11; break; }
+                // every tile is executed exactly once: the first tile of an item checks the item's tile count
+                if (wg == it.b) {
                     const uint32_t tiles = (p[3] + it.a - 1) / it.a;
-                    if (next_b - it.b != tiles) { g_err = "tile prefix does not match the step's tile count"; rc = -11; }
-                    for (uint32_t t = 0; t < tiles && rc == 0; ++t)
-                        rc = exec_step(net, p, (int64_t)t * it.a, std::min<int64_t>(p[3], (int64_t)(t + 1) * it.a), arena,
-                                       (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
+                    for (uint32_t t = 0; t < tiles; ++t)
+                        if (wgi + t >= sc.wg_item.size() || sc.wg_item[wgi + t] != k) { g_err = "item does not own all of its tiles"; rc = -11; break; }
+                    if (rc == 0 && wgi + tiles < L.wg_first + L.grid && sc.wg_item[wgi + tiles] == k) { g_err = "item owns too many workgroups"; rc = -11; }
                 }
+                if (rc == 0) rc = exec_step(net, p, h0, h1, arena, (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
             }
         }
     }
+    if (rc == 0 && wg_seen != sc.wg_item.size()) { g_err = "launches do not cover wg_item"; rc = -11; }
     if (rc == 0 && !skip && std::fabs(bytes_check - bp.st.alg_bytes) > 64.0 * bp.st.n_steps + 1e-9 * bp.st.alg_bytes) {
         g_err = "schedule bytes do not add up to the plan's algorithmic bytes";
         rc = -12;

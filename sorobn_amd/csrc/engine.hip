@@ -48,6 +48,8 @@ struct mibn_ctx {
         size_t prog_off_cap = 0;
         uint64_t *d_arena_off = nullptr;
         size_t arena_off_cap = 0;
+        uint32_t *d_wg_item = nullptr;
+        size_t wg_item_cap = 0;
         Item *d_items = nullptr;
         size_t items_cap = 0;
         std::vector<hipEvent_t> ev;          // launch boundaries of the waves in flight
@@ -60,12 +62,13 @@ struct mibn_ctx {
     } set[2];
     std::string err;
     mibn_stats stats{};
-    mibn_kernel_stat kstats[kNumKernels];
+    mibn_kernel_stat kstats[kNumKernels + 1];  // per class (split_kinds) + the level kernel as a whole
     // options
     double arena_gb = 96.0;
     int threads = 0;
     int wg_per_cu = 8;
-    int trace = 0;  // debug: one stderr line per launch
+    int trace = 0;        // debug: one stderr line per launch
+    int split_kinds = 0;  // profiling: one launch per (level, class of work) instead of one per level
     int64_t chunk = 16384;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
 };
 
@@ -135,6 +138,7 @@ void mibn_destroy(mibn_t *h) {
             (void)hipFree(st.d_prog_off);
             (void)hipFree(st.d_arena_off);
             (void)hipFree(st.d_items);
+            (void)hipFree(st.d_wg_item);
             for (auto e : st.ev) (void)hipEventDestroy(e);
         }
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -154,6 +158,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "big_iters") h->net.big_iters = std::max<int64_t>(1, (int64_t)value);  // test hooks: force tiling
     else if (n == "tile_h") h->net.tile_h = std::max(0, std::min(kTileMax, (int)value));  // 0 = sized by traffic
     else if (n == "trace") h->trace = (int)value;
+    else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "fuse") h->net.fuse = value != 0;  // joint elimination of two variables per pass
     else if (n == "small_cells") h->net.small_cells = std::max(1, std::min(kMaxT, (int)value));  // test hook: forces FIBER steps on small networks
     else { h->err = "unknown option " + n; return MIBN_E_ARG; }
@@ -244,16 +249,6 @@ int default_threads() {
     return std::max(1, std::min(64, hw / local_world));
 }
 
-using KernelFn = void (*)(LevelArgs);
-#define MIBN_FIBER_ROW(NB, C) fiber_tile_kernel<NB, C, 0>, fiber_tile_kernel<NB, C, 1>, fiber_tile_kernel<NB, C, 2>, fiber_tile_kernel<NB, C, 3>
-const KernelFn kKernels[kNumKernels] = {
-    seg_kernel,
-    MIBN_FIBER_ROW(1, 0), MIBN_FIBER_ROW(1, 1), MIBN_FIBER_ROW(1, 2),
-    MIBN_FIBER_ROW(2, 0), MIBN_FIBER_ROW(2, 1), MIBN_FIBER_ROW(2, 2),
-    generic_tile_kernel<1>, generic_tile_kernel<2>, generic_tile_kernel<3>, generic_tile_kernel<4>,
-    generic_tile_kernel<5>, generic_tile_kernel<6>};
-#undef MIBN_FIBER_ROW
-
 // wait for a set's launches and book their HIP-event durations per kernel
 int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     if (!st.busy) return MIBN_OK;
@@ -268,7 +263,7 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         k.ms += ms;
         k.alg_bytes += t.bytes;
         k.items += t.items;
-        if (h->trace) std::fprintf(stderr, "[mibn launch] %-32s wgs %8.0f MB %10.2f ms %8.4f -> %7.1f GB/s\n", kernel_name(t.kid), t.items, t.bytes / 1e6, ms, t.bytes / ms / 1e6);
+        if (h->trace) std::fprintf(stderr, "[mibn launch] %-32s wgs %8.0f MB %10.2f ms %8.4f -> %7.1f GB/s\n", h->kstats[t.kid].name, t.items, t.bytes / 1e6, ms, t.bytes / ms / 1e6);
     }
     st.timed.clear();
     st.ev_used = 0;
@@ -297,9 +292,9 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
     const double t_start = now_ms();
     h->stats = mibn_stats{};
-    for (int k = 0; k < kNumKernels; ++k) {
+    for (int k = 0; k <= kNumKernels; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
-        std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", kernel_name(k));
+        std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", k < kNumKernels ? kernel_name(k) : "ve_level_kernel");
     }
     if (B == 0) return MIBN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -385,9 +380,11 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             // time unless the chunk had to be split (then wait for the previous wave first)
             if (r0 > 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
             if ((rc = ensure(h, st.d_items, st.items_cap, sc.items.size()))) return rc;
+            if ((rc = ensure(h, st.d_wg_item, st.wg_item_cap, sc.wg_item.size()))) return rc;
             t0 = now_ms();
             HIP_TRY(h, hipMemcpyAsync(st.d_arena_off, sc.arena_off.data(), (size_t)(r1 - r0) * 8, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipMemcpyAsync(st.d_items, sc.items.data(), sc.items.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(st.d_wg_item, sc.wg_item.data(), sc.wg_item.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
             h->stats.h2d_ms += now_ms() - t0;
             LevelArgs A;
             A.prog = st.d_prog;
@@ -399,15 +396,27 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             size_t e_prev = 0;
             double n_wg = 0;
             if ((rc = next_event(h, st, e_prev))) return rc;
-            for (const Launch &L : sc.launches) {
-                A.items = st.d_items + L.first;
-                A.n_items = (int)L.count;
-                hipLaunchKernelGGL(kKernels[L.kid], dim3((unsigned)L.grid), dim3(kWG), 0, h->stream, A);
+            A.items = st.d_items;
+            for (size_t li = 0; li < sc.launches.size();) {
+                // one launch per level (all classes of work together) unless split_kinds
+                size_t lj = li + 1;
+                double bytes = sc.launches[li].alg_bytes;
+                size_t grid = sc.launches[li].grid;
+                if (!h->split_kinds)
+                    for (; lj < sc.launches.size() && sc.launches[lj].level == sc.launches[li].level; ++lj) {
+                        bytes += sc.launches[lj].alg_bytes;
+                        grid += sc.launches[lj].grid;
+                    }
+                const Launch &L = sc.launches[li];
+                A.wg_item = st.d_wg_item + L.wg_level;
+                A.wg_base = (uint32_t)(L.wg_first - L.wg_level);
+                hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, h->stream, A);
                 size_t e_next = 0;
                 if ((rc = next_event(h, st, e_next))) return rc;
-                st.timed.push_back({L.kid, e_prev, e_next, L.alg_bytes, (double)L.grid});
-                n_wg += (double)L.grid;
+                st.timed.push_back({h->split_kinds ? L.kid : kNumKernels, e_prev, e_next, bytes, (double)grid});
+                n_wg += (double)grid;
                 e_prev = e_next;
+                li = lj;
             }
             HIP_TRY(h, hipGetLastError());
             st.busy = true;
@@ -433,7 +442,7 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
 extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i < kNumKernels && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels && k < cap; ++i)
         if (h->kstats[i].launches > 0) out[k++] = h->kstats[i];
     *n = k;
     return MIBN_OK;

@@ -936,6 +936,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
                     Schedule &out) {
     const int64_t n = r1 - r0;
     out.items.clear();
+    out.wg_item.clear();
     out.launches.clear();
     out.arena_off.assign(n, 0);
     int64_t top = 0;
@@ -959,7 +960,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         double seg_bytes = 0;
         auto flush = [&]() {
             if (seg_steps) {
-                tagged.push_back({{(uint32_t)i, (uint32_t)seg_first, (uint32_t)seg_steps, 0u}, level, kKidSeg, seg_bytes});
+                tagged.push_back({{(uint32_t)i, (uint32_t)seg_first, (uint32_t)seg_steps | kItemSegment, 1u}, level, kKidSeg, seg_bytes});
                 ++level;
                 seg_steps = 0;
                 seg_bytes = 0;
@@ -994,23 +995,26 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
     out.items.resize(tagged.size());
     std::vector<size_t> cur(count.begin(), count.end() - 1);
     for (auto &t : tagged) out.items[cur[(size_t)t.level * kNumKernels + t.kid]++] = t.it;
+    size_t n_wg = 0;
+    for (auto &t : tagged) n_wg += t.it.b;  // b = workgroups of the item for now
+    out.wg_item.resize(n_wg);
+    size_t wg = 0, wg_level = 0;
+    int cur_level = -1;
     for (size_t k = 0; k < nb; ++k)
         if (count[k + 1] > count[k]) {
             const int level = (int)(k / kNumKernels), kid = (int)(k % kNumKernels);
-            size_t grid = count[k + 1] - count[k];
-            if (kid == kKidSeg) {  // longest segments first: they are the tail of their launch
+            if (level != cur_level) { cur_level = level; wg_level = wg; }
+            if (kid == kKidSeg)  // longest segments first: they are the tail of their level
                 std::stable_sort(out.items.begin() + count[k], out.items.begin() + count[k + 1],
                                  [](const Item &a, const Item &b) { return a.a > b.a; });
-            } else {               // tile counts -> first-tile prefix (the kernel's binary-search key)
-                uint32_t first = 0;
-                for (size_t q = count[k]; q < count[k + 1]; ++q) {
-                    const uint32_t tiles = out.items[q].b;
-                    out.items[q].b = first;
-                    first += tiles;
-                }
-                grid = first;
+            const size_t wg_first = wg;
+            for (size_t q = count[k]; q < count[k + 1]; ++q) {
+                const uint32_t wgs = out.items[q].b;
+                out.items[q].b = (uint32_t)(wg - wg_level);
+                std::fill(out.wg_item.begin() + wg, out.wg_item.begin() + wg + wgs, (uint32_t)q);
+                wg += wgs;
             }
-            out.launches.push_back({level, kid, count[k], count[k + 1] - count[k], grid, bytes[k]});
+            out.launches.push_back({level, kid, count[k], count[k + 1] - count[k], wg_first, wg - wg_first, wg_level, bytes[k]});
         }
 }
 

@@ -183,18 +183,21 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
 struct Item {
     uint32_t req;      // request index within the wave
     uint32_t rel_off;  // word offset of the (first) step inside the request's program
-    uint32_t a, b;     // SEGMENT: a = number of steps.  TILED step: a = hi iterations per tile, b = index of its first
-                       // tile within the launch (a workgroup finds its step by binary search on b)
+    uint32_t a, b;     // SEGMENT: a = number of steps | kItemSegment.  TILED step: a = hi iterations per tile.
+                       // b = index of the item's first workgroup within its level
 };
+constexpr uint32_t kItemSegment = 1u << 31;
 struct Launch {
-    int level, kid;
+    int level, kid;       // kid: the class of work (kernel_name), for per-class accounting
     size_t first, count;  // range in Schedule::items
-    size_t grid;          // workgroups: SEGMENT = count, tiled = total tiles
+    size_t wg_first;      // range in Schedule::wg_item: workgroups [wg_first, wg_first + grid)
+    size_t grid;
+    size_t wg_level;      // wg_item index of the level's first workgroup (Item::b is relative to it)
     double alg_bytes;     // algorithmic bytes of the steps in this launch
 };
-constexpr int kKidSeg = 0;         // segment interpreter (small GENERIC steps)
-constexpr int kKidFiber0 = 1;      // 24 FIBER tile kernels: 1 + (n_big-1)*12 + cx_class*4 + nc_class
-constexpr int kKidGeneric0 = 25;   // 6 GENERIC tile kernels: 25 + (n_in - 1)
+constexpr int kKidSeg = 0;         // segments of small GENERIC steps
+constexpr int kKidFiber0 = 1;      // 24 FIBER tile classes: 1 + (n_big-1)*12 + cx_class*4 + nc_class
+constexpr int kKidGeneric0 = 25;   // 6 GENERIC tile classes: 25 + (n_in - 1)
 constexpr int kNumKernels = 31;
 const char *kernel_name(int kid);
 int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
@@ -206,7 +209,8 @@ int step_tile_h(const Network &net, const uint32_t *w);
 
 struct Schedule {
     std::vector<Item> items;
-    std::vector<Launch> launches;
+    std::vector<uint32_t> wg_item;    // item index of every workgroup, level by level
+    std::vector<Launch> launches;     // ordered by (level, kid); the launches of a level are contiguous in wg_item
     std::vector<uint64_t> arena_off;  // per request of the wave: offset (doubles) of its private arena
     int64_t arena_cells = 0;          // total
     int n_levels = 0;

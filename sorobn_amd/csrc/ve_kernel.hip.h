@@ -1,4 +1,4 @@
-// CDNA4 (gfx950) variable-elimination kernels.
+// CDNA4 (gfx950) variable-elimination kernel.
 //
 // A step is the fused replacement of `pointwise_mul(...)` + `.cdt.sum_out(x)`
 // (sorobn/bayes_net.py:780-785, 233-256, 100-103):
@@ -8,28 +8,30 @@
 // over dense fp64 tables; the product table of the reference (up to 4^11 rows on the 10x10 grid) is
 // never materialised.  Every request owns a private arena in HBM for its intermediates.
 //
-// Execution is level-synchronous (schedule: planner.h).  Three kernel families, all 256-lane
-// workgroups (4 wave64):
-//  * fiber_tile_kernel<NBIG, CXC, NCC> - the streaming form, > 95 % of the bytes on the 10x10 grid.  A tile =
-//    a few wave-uniform iterations x <= 256 lane cells of one big step (~512 KiB of traffic).  The inputs are
-//    one or two big tables (the elimination frontier, MBs, streamed from HBM) and a few CPT slices (<= 8 KiB)
-//    whose product is tabulated once per tile in LDS (T, <= 16 KiB).  A lane owns one cell r of the big
-//    tables' shared axes: it loads the cx values F[r, x] up front - the eliminated variables are the slowest
-//    axes of F, so consecutive lanes read consecutive addresses, 512 B per wave instruction, cx (<= 16)
-//    independent loads in flight per lane - and produces the whole fiber over the new (CPT-only) axes
-//    in registers,  out[r, n] = sum_x F[r, x] * T[n, x, ctrl(r)].  With two variables eliminated per pass
-//    (cx = 16, NC = 16: 256 FMAs per 256 bytes moved, still < 20 % of the fp64 vector rate) the frontier is
-//    read and written once per *pair* of eliminations.  NC = 4 fibers are stored as two 16-byte vectors per
-//    lane; NC = 16 fibers (128 B per lane) are transposed through a wave-private LDS buffer so that every
-//    store instruction writes full 64-byte segments (direct 128-byte-strided stores reach only 3.8 TB/s
-//    against 5.2 TB/s transposed - tools/ubench/stream_variants.hip).
-//  * generic_tile_kernel<NIN> - big steps of any other shape, one output cell per lane-iteration.
-//  * seg_kernel - a run of small steps of one request (start / end of a program, the final normalised
+// Execution is level-synchronous (schedule: planner.h): ONE launch of `ve_level_kernel` per level, 256-lane
+// workgroups (4 wave64), one work item per workgroup - a tile of a big step or a segment of small steps; the only
+// synchronisation between dependent steps is the launch boundary.  Three families of work:
+//  * FIBER tiles <NBIG, CXC, NCC> - the streaming form, > 95 % of the bytes on the 10x10 grid.  A tile = a few
+//    wave-uniform iterations x <= 256 lane cells of one big step (~512 KiB of traffic).  The inputs are one or two
+//    big tables (the elimination frontier, MBs, streamed from HBM) and a few CPT slices (<= 8 KiB) whose product
+//    is tabulated once per tile in LDS (T, <= 16 KiB).  A lane owns one cell r of the big tables' shared axes: it
+//    loads the cx values F[r, x] - the eliminated variables are the slowest axes of F, so consecutive lanes read
+//    consecutive addresses, 512 B per wave instruction - and produces the whole fiber over the new (CPT-only)
+//    axes in registers,  out[r, n] = sum_x F[r, x] * T[n, x, ctrl(r)].  With two variables eliminated per pass
+//    (cx = 16, NC = 16: 256 FMAs per 256 bytes moved, < 20 % of the fp64 vector rate) the frontier is read and
+//    written once per *pair* of eliminations.  The loop is software-pipelined: the 16 loads of the next trip
+//    (one cx = 16 iteration or four cx = 4 iterations) are in flight while the current one is reduced and
+//    stored; their addresses are a per-trip scalar base plus one 32-bit lane offset.  NC = 4 fibers are stored
+//    as two 16-byte vectors per lane; NC = 16 fibers (128 B per lane) are transposed through a wave-private LDS
+//    buffer so that every store instruction writes full 64-byte segments (direct 128-byte-strided stores
+//    reach only 3.8 TB/s against 5.2 TB/s transposed - tools/ubench/stream_variants.hip).
+//  * GENERIC tiles <NIN> - big steps of any other shape, one output cell per lane-iteration.
+//  * segments - a run of small steps of one request (start / end of a program, the final normalised
 //    product) executed back to back by one workgroup; only `__syncthreads()` between steps (same CU).
 //
 // Index math: every table is laid out with the longest-living variable fastest, the iteration space
 // is split into a lane-varying block (lo) and a wave-uniform block (hi).  Lane offsets are decoded
-// once per tile; hi offsets are decoded by the lanes in parallel into LDS and broadcast from LDS in the
+// once per tile; hi offsets are decoded by the lanes in parallel into LDS and read back as scalars in the
 // streaming loop, which therefore contains only loads, fp64 FMAs and stores.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -48,14 +50,17 @@ struct LevelArgs {
     const double *pool;         // CPT tables (constants pool)
     double *arena;              // scratch
     double *results;            // dense posteriors of the chunk
-    const Item *items;          // work items of this launch
-    int n_items;
+    const Item *items;          // work items of this chunk
+    const uint32_t *wg_item;    // item of every workgroup of this level
+    uint32_t wg_base;           // level-relative index of this launch's first workgroup
 };
 
 __device__ __forceinline__ const double *table_ptr(uint32_t lo, uint32_t hi, const double *pool, const double *slot) {
     const uint64_t o = (uint64_t)lo | ((uint64_t)hi << 32);
     return (o & kConstFlag) ? pool + (o & ~kConstFlag) : slot + o;
 }
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------------------------------- GENERIC
 template <int NIN, int MAXC, int CX>
@@ -157,227 +162,309 @@ __device__ __forceinline__ void generic_body(const uint32_t *sw, int (*sh_hoff)[
 }
 
 template <int NIN, int MAXC>
-__device__ __forceinline__ void generic_cx(const uint32_t *sw, int (*sh_hoff)[kTileMax], const double *pool, double *slot,
-                                           double *results, int tid, int h_begin, int h_end) {
+__device__ __forceinline__ void generic_call(const uint32_t *sw, int (*sh_hoff)[kTileMax], const double *pool, double *slot,
+                                          double *results, int tid, int h_begin, int h_end) {
     const int cx = (int)(sw[1] & 0xffff);
     if (cx == 4) generic_body<NIN, MAXC, 4>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
     else if (cx == 2) generic_body<NIN, MAXC, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
     else generic_body<NIN, MAXC, 0>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
 }
 
+__device__ __forceinline__ void generic_dispatch(int n_in, const uint32_t *sw, int (*sh_hoff)[kTileMax], const double *pool,
+                                                 double *slot, double *results, int tid, int h_begin, int h_end) {
+    switch (n_in) {
+        case 1: generic_call<1, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 2: generic_call<2, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 3: generic_call<3, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 4: generic_call<4, 1>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 5: generic_call<5, 1>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        default: generic_call<6, 1>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ FIBER
-// NBIG big inputs.  CXC: 0 = cx 4 (one variable), 1 = cx 16 (two 4-state variables), 2 = runtime (cx <= 16).
-// NCC: 0 = NC 1, 1 = NC 4 contiguous, 2 = NC 16 contiguous, 3 = runtime (NC <= 16, scattered stores).
-// Tile = hi iterations [h_begin, h_end), at most kTileMax of them.
-template <int NBIG, int CXC, int NCC>
-__device__ __forceinline__ void fiber_body(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
-                                           uint32_t *__restrict__ shX, const double *__restrict__ pool,
-                                           double *__restrict__ slot, const int tid, const int h_begin, const int h_end) {
-    constexpr int CX = CXC == 0 ? 4 : (CXC == 1 ? 16 : 0);
-    constexpr int NCT = NCC == 0 ? 1 : (NCC == 1 ? 4 : (NCC == 2 ? 16 : 0));
-    const uint32_t w0 = sw[0];
-    const int na = (w0 >> 16) & 0xff;
-    const int nlo = (w0 >> 24) & 0xff;
-    const int cx = CX ? CX : (int)(sw[1] & 0xffff);
-    const int c1 = CX ? 4 : (int)(sw[8] >> 16);
-    const int lo_cells = (int)sw[2];
-    double *__restrict__ outp = slot + ((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
-    const int ns = (sw[7] >> 4) & 0xf, nN = (sw[7] >> 8) & 0xf, nctrl = (sw[7] >> 12) & 0xf;
-    const int NC = NCT ? NCT : (int)(sw[7] >> 16);
-    const int T = (int)(sw[8] & 0xffff);
-    const int nT = nN + nctrl;
+// Decoded layout of a FIBER step descriptor (LDS copy).
+struct FiberDesc {
+    int na, nlo, cx, c1, lo_cells, ns, nN, nctrl, NC, T, nT, nb;
+    const uint32_t *bigs, *smalls, *tcard, *nout, *rax;
+    const int *bst;
+};
 
+__device__ __forceinline__ FiberDesc fiber_desc(const uint32_t *sw) {
+    FiberDesc d;
+    d.na = (sw[0] >> 16) & 0xff;
+    d.nlo = (sw[0] >> 24) & 0xff;
+    d.cx = (int)(sw[1] & 0xffff);
+    d.c1 = (int)(sw[8] >> 16);
+    d.lo_cells = (int)sw[2];
+    d.nb = sw[7] & 0xf;
+    d.ns = (sw[7] >> 4) & 0xf;
+    d.nN = (sw[7] >> 8) & 0xf;
+    d.nctrl = (sw[7] >> 12) & 0xf;
+    d.NC = (int)(sw[7] >> 16);
+    d.T = (int)(sw[8] & 0xffff);
+    d.nT = d.nN + d.nctrl;
     const uint32_t *q = sw + kHdrWords;
-    const double *__restrict__ big[NBIG];
-    int bxs1[NBIG], bxs2[NBIG];
-#pragma unroll
-    for (int b = 0; b < NBIG; ++b) {
-        big[b] = table_ptr(q[0], q[1], pool, slot);
-        bxs1[b] = (int)q[2];
-        bxs2[b] = (int)q[3];
-        q += 4;
-    }
-    const uint32_t *smalls = q;  // ns records of (4 + nT) words
-    q += ns * (4 + nT);
-    const uint32_t *tcard = q;
-    q += nT;
-    const uint32_t *nout = q;
-    q += NC;
-    const uint32_t *rax = q;  // (card, ostride, tstride) per R axis
-    q += 3 * na;
-    const int *bst = (const int *)q;  // bst[b * na + a]
+    d.bigs = q;
+    q += 4 * d.nb;
+    d.smalls = q;  // ns records of (4 + nT) words
+    q += d.ns * (4 + d.nT);
+    d.tcard = q;
+    q += d.nT;
+    d.nout = q;
+    q += d.NC;
+    d.rax = q;  // (card, ostride, tstride) per R axis
+    q += 3 * d.na;
+    d.bst = (const int *)q;  // bst[b * na + a]
+    return d;
+}
 
-    // T[n + NC*(x + cx*ctrl)] = product of the small inputs (the CPT slices), once per tile
-    for (int t = tid; t < T; t += kWG) {
-        int r = t;
-        const int qn = r / NC;
-        const int rn = r - qn * NC;
-        r = qn;
-        const int qx = r / cx;
-        const int x = r - qx * cx;
-        r = qx;
-        const int x2 = x / c1, x1 = x - x2 * c1;
-        double v = 1.0;
-        for (int j = 0; j < ns; ++j) {
-            const uint32_t *rec = smalls + j * (4 + nT);
-            const int *sts = (const int *)(rec + 4);
-            int off = x1 * (int)rec[2] + x2 * (int)rec[3];
-            int a = rn, c = r;
-            for (int k = 0; k < nN; ++k) { const int cd = (int)tcard[k]; const int qq = a / cd; off += (a - qq * cd) * sts[k]; a = qq; }
-            for (int k = nN; k < nT; ++k) { const int cd = (int)tcard[k]; const int qq = c / cd; off += (c - qq * cd) * sts[k]; c = qq; }
-            v *= table_ptr(rec[0], rec[1], pool, slot)[off];
+// Tile prologue shared by every FIBER specialisation:
+//  * T[n + NC*(x + cx*ctrl)] = product of the small inputs (the CPT slices)
+//  * wave-uniform offsets of the tile's iterations -> sh_hoff[0] (output), [1] (T), [2 + b] (big input b)
+//  * this lane's offsets (one R cell per lane) -> lane_off[0] (output), [1] (T), [2 + b]
+__device__ __noinline__ void fiber_prologue(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
+                                            const double *__restrict__ pool, const double *__restrict__ slot, const int tid,
+                                            const int h_begin, const int h_end, int *lane_off) {
+    const FiberDesc d = fiber_desc(sw);
+    for (int t0 = 0; t0 < d.T; t0 += 2 * kWG) {  // two entries per lane and trip: their loads overlap
+        double v[2] = {1.0, 1.0};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = t0 + e * kWG + tid;
+            if (t < d.T) {
+                int r = t;
+                const int qn = r / d.NC;
+                const int rn = r - qn * d.NC;
+                r = qn;
+                const int qx = r / d.cx;
+                const int x = r - qx * d.cx;
+                r = qx;
+                const int x2 = x / d.c1, x1 = x - x2 * d.c1;
+                for (int j = 0; j < d.ns; ++j) {
+                    const uint32_t *rec = d.smalls + j * (4 + d.nT);
+                    const int *sts = (const int *)(rec + 4);
+                    int off = x1 * (int)rec[2] + x2 * (int)rec[3];
+                    int a = rn, c = r;
+                    for (int k = 0; k < d.nN; ++k) { const int cd = (int)d.tcard[k]; const int qq = a / cd; off += (a - qq * cd) * sts[k]; a = qq; }
+                    for (int k = d.nN; k < d.nT; ++k) { const int cd = (int)d.tcard[k]; const int qq = c / cd; off += (c - qq * cd) * sts[k]; c = qq; }
+                    v[e] *= table_ptr(rec[0], rec[1], pool, slot)[off];
+                }
+            }
         }
-        shT[t] = v;
-    }
-
-    // lane offsets (one R cell per lane)
-    const bool active = tid < lo_cells;
-    int lo_o = 0, lo_t = 0, lo_b[NBIG];
 #pragma unroll
-    for (int b = 0; b < NBIG; ++b) lo_b[b] = 0;
-    if (active) {
+        for (int e = 0; e < 2; ++e) {
+            const int t = t0 + e * kWG + tid;
+            if (t < d.T) shT[t] = v[e];
+        }
+    }
+    int lo[4] = {0, 0, 0, 0};
+    if (tid < d.lo_cells) {
         int r = tid;
-        for (int a = 0; a < nlo; ++a) {
-            const int cd = (int)rax[3 * a];
+        for (int a = 0; a < d.nlo; ++a) {
+            const int cd = (int)d.rax[3 * a];
             const int qq = r / cd;
-            const int d = r - qq * cd;
+            const int dg = r - qq * cd;
             r = qq;
-            lo_o += d * (int)rax[3 * a + 1];
-            lo_t += d * (int)rax[3 * a + 2];
-#pragma unroll
-            for (int b = 0; b < NBIG; ++b) lo_b[b] += d * bst[b * na + a];
+            lo[0] += dg * (int)d.rax[3 * a + 1];
+            lo[1] += dg * (int)d.rax[3 * a + 2];
+            for (int b = 0; b < d.nb; ++b) lo[2 + b] += dg * d.bst[b * d.na + a];
         }
     }
-    // wave-uniform offsets of this tile's iterations
     const int nh = h_end - h_begin;
     if (tid < nh) {
-        int ao = 0, at = 0, ab[NBIG];
-#pragma unroll
-        for (int b = 0; b < NBIG; ++b) ab[b] = 0;
+        int hi[4] = {0, 0, 0, 0};
         int r = h_begin + tid;
-        for (int a = nlo; a < na; ++a) {
-            const int cd = (int)rax[3 * a];
+        for (int a = d.nlo; a < d.na; ++a) {
+            const int cd = (int)d.rax[3 * a];
             const int qq = r / cd;
-            const int d = r - qq * cd;
+            const int dg = r - qq * cd;
             r = qq;
-            ao += d * (int)rax[3 * a + 1];
-            at += d * (int)rax[3 * a + 2];
-#pragma unroll
-            for (int b = 0; b < NBIG; ++b) ab[b] += d * bst[b * na + a];
+            hi[0] += dg * (int)d.rax[3 * a + 1];
+            hi[1] += dg * (int)d.rax[3 * a + 2];
+            for (int b = 0; b < d.nb; ++b) hi[2 + b] += dg * d.bst[b * d.na + a];
         }
-        sh_hoff[0][tid] = ao;
-        sh_hoff[1][tid] = at;
-#pragma unroll
-        for (int b = 0; b < NBIG; ++b) sh_hoff[2 + b][tid] = ab[b];
+        sh_hoff[0][tid] = hi[0];
+        sh_hoff[1][tid] = hi[1];
+        sh_hoff[2][tid] = hi[2];
+        sh_hoff[3][tid] = hi[3];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lane_off[k] = lo[k];
     __syncthreads();  // T and the offsets are ready
+}
 
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int hh = 0; hh < nh; ++hh) {
-        const int ho = sh_hoff[0][hh], ht = sh_hoff[1][hh];
-        int hb[NBIG];
+// Reduce one loaded fiber f[0..CX) against T and store the NC outputs.  NCT = compile-time NC (1, 4, 16) or 0.
+template <int CX, int NCT>
+__device__ __forceinline__ void fiber_reduce_store(const double (&f)[CX], const double *__restrict__ Tp, double *__restrict__ o,
+                                                   double *__restrict__ Ob, uint32_t *__restrict__ X, const uint32_t *nout,
+                                                   const int NC, const bool active, const int lane, const int cells_in_wave) {
+    if (NCT == 1) {
+        double s = 0.0;
 #pragma unroll
-        for (int b = 0; b < NBIG; ++b) hb[b] = sh_hoff[2 + b][hh];
-        const double *__restrict__ Tp = shT + (ht + lo_t);
-        double *__restrict__ o = outp + (ho + lo_o);
-        if (CX) {
-            // all loads of this iteration (NBIG tables x CX values) are issued before the first use
-            double f[CX ? CX : 1];
+        for (int x = 0; x < CX; ++x) s += f[x] * Tp[x];
+        if (active) o[0] = s;
+    } else if (NCT == 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int x = 0; x < (CX ? CX : 1); ++x) {
-                double p = active ? big[0][hb[0] + lo_b[0] + (x & 3) * bxs1[0] + (x >> 2) * bxs2[0]] : 0.0;
+        for (int x = 0; x < CX; ++x) {
 #pragma unroll
-                for (int b = 1; b < NBIG; ++b) p *= active ? big[b][hb[b] + lo_b[b] + (x & 3) * bxs1[b] + (x >> 2) * bxs2[b]] : 0.0;
-                f[x] = p;
+            for (int n = 0; n < 4; ++n) acc[n] += f[x] * Tp[x * 4 + n];
+        }
+        if (active) {
+            *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[1]);
+            *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2], acc[3]);
+        }
+    } else if (NCT == 16) {
+        // the wave's 64 fibers are one contiguous 64*16-cell region (Ob): two rounds of 8 cells per lane through the
+        // wave-private transpose buffer X, every store instruction then writes 64-byte segments
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int x = 0; x < CX; ++x) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc[n] += f[x] * Tp[x * 16 + half * 8 + n];
             }
-            if (NCT == 1) {
-                double s = 0.0;
 #pragma unroll
-                for (int x = 0; x < (CX ? CX : 1); ++x) s += f[x] * Tp[x];
-                if (active) o[0] = s;
-            } else if (NCT == 4) {
+            for (int n = 0; n < 8; n += 2)
+                *reinterpret_cast<double2 *>(X + lane * kXRow + 2 * n) = make_double2(acc[n], acc[n + 1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int g = k * 64 + lane;  // 16-byte chunk of this round: owner lane g / 4, piece g % 4
+                const int owner = g >> 2, piece = g & 3;
+                const double2 v = *reinterpret_cast<const double2 *>(X + owner * kXRow + 4 * piece);
+                if (owner < cells_in_wave) *reinterpret_cast<double2 *>(Ob + owner * 16 + half * 8 + 2 * piece) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
+        if (active) {
+            for (int n0 = 0; n0 < NC; n0 += 4) {
                 double acc[4];
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
                     double s = 0.0;
+                    if (n0 + n < NC) {
 #pragma unroll
-                    for (int x = 0; x < (CX ? CX : 1); ++x) s += f[x] * Tp[x * 4 + n];
+                        for (int x = 0; x < CX; ++x) s += f[x] * Tp[x * NC + n0 + n];
+                    }
                     acc[n] = s;
                 }
-                if (active) {
-                    *reinterpret_cast<double2 *>(o) = make_double2(acc[0], acc[1]);
-                    *reinterpret_cast<double2 *>(o + 2) = make_double2(acc[2], acc[3]);
-                }
-            } else if (NCT == 16) {
-                // the wave's 64 fibers are one contiguous 64*16-cell region: two rounds of 8 cells per lane through
-                // the wave-private transpose buffer, every store instruction then writes 64-byte segments
-                uint32_t *__restrict__ X = shX + wave * (64 * kXRow);
-                double *__restrict__ Ob = outp + ho + (wave * 64) * 16;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    double acc[8];
+                for (int n = 0; n < 4; ++n)
+                    if (n0 + n < NC) o[nout[n0 + n]] = acc[n];
+            }
+        }
+    }
+}
+
+// NBIG big inputs.  CXC: 0 = cx 4 (one variable), 1 = cx 16 (two 4-state variables), 2 = runtime (cx <= 16).
+// NCC: 0 = NC 1, 1 = NC 4 contiguous, 2 = NC 16 contiguous, 3 = runtime (NC <= 16, scattered stores).
+// Tile = hi iterations [h_begin, h_end), at most kTileMax of them.
+template <int NBIG, int CXC, int NCC>
+__device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
+                                        uint32_t *__restrict__ shX, const double *__restrict__ pool, double *__restrict__ slot,
+                                        const int tid, const int h_begin, const int h_end) {
+    constexpr int CX = CXC == 0 ? 4 : (CXC == 1 ? 16 : 0);
+    constexpr int NCT = NCC == 0 ? 1 : (NCC == 1 ? 4 : (NCC == 2 ? 16 : 0));
+    constexpr int U = CX ? 16 / CX : 1;  // iterations per trip: 16 loads in flight per lane and big input
+    int lane_off[4];
+    fiber_prologue(sw, shT, sh_hoff, pool, slot, tid, h_begin, h_end, lane_off);
+    const FiberDesc d = fiber_desc(sw);
+    const int NC = NCT ? NCT : d.NC;
+    double *__restrict__ outp = slot + ((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+    const double *__restrict__ big[NBIG];
+    int bxs1[NBIG], bxs2[NBIG];
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        double s = 0.0;
+    for (int b = 0; b < NBIG; ++b) {
+        big[b] = table_ptr(d.bigs[4 * b], d.bigs[4 * b + 1], pool, slot);
+        bxs1[b] = (int)d.bigs[4 * b + 2];
+        bxs2[b] = (int)d.bigs[4 * b + 3];
+    }
+    const bool active = tid < d.lo_cells;
+    const int lo_o = lane_off[0], lo_t = lane_off[1];
+    const int nh = h_end - h_begin;
+    const int wave = tid >> 6, lane = tid & 63;
+    uint32_t *__restrict__ X = shX + wave * (64 * kXRow);
+    const int cells_in_wave = d.lo_cells - wave * 64;
+
+    if (CX) {
+        // issue the loads of iterations [hh, hh + U): the address is a scalar base (table + wave-uniform offset +
+        // x offset) plus this lane's 32-bit offset
+        auto issue = [&](const int hh, double (&dst)[U][CX ? CX : 1]) {
 #pragma unroll
-                        for (int x = 0; x < (CX ? CX : 1); ++x) s += f[x] * Tp[x * 16 + half * 8 + n];
-                        acc[n] = s;
-                    }
+            for (int u = 0; u < U; ++u) {
+                if (hh + u < nh) {
 #pragma unroll
-                    for (int n = 0; n < 8; n += 2)
-                        *reinterpret_cast<double2 *>(X + lane * kXRow + 2 * n) = make_double2(acc[n], acc[n + 1]);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int g = k * 64 + lane;  // 16-byte chunk of this round: owner lane g / 4, piece g % 4
-                        const int owner = g >> 2, piece = g & 3;
-                        const double2 v = *reinterpret_cast<const double2 *>(X + owner * kXRow + 4 * piece);
-                        if (wave * 64 + owner < lo_cells)
-                            *reinterpret_cast<double2 *>(Ob + owner * 16 + half * 8 + 2 * piece) = v;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-            } else {
-                if (active) {
-                    for (int n0 = 0; n0 < NC; n0 += 4) {
-                        double acc[4];
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            double s = 0.0;
-                            if (n0 + n < NC) {
-#pragma unroll
-                                for (int x = 0; x < (CX ? CX : 1); ++x) s += f[x] * Tp[x * NC + n0 + n];
-                            }
-                            acc[n] = s;
+                    for (int x = 0; x < (CX ? CX : 1); ++x) {
+                        const double *__restrict__ b0 = big[0] + (uni(sh_hoff[2][hh + u]) + (x & 3) * bxs1[0] + (x >> 2) * bxs2[0]);
+                        // (inactive lanes carry offset 0: they load a valid cell and never store)
+                        double p = b0[(uint32_t)lane_off[2]];
+                        if (NBIG > 1) {
+                            const double *__restrict__ b1 = big[NBIG - 1] + (uni(sh_hoff[3][hh + u]) + (x & 3) * bxs1[NBIG - 1] + (x >> 2) * bxs2[NBIG - 1]);
+                            p *= b1[(uint32_t)lane_off[3]];
                         }
-#pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            if (n0 + n < NC) o[nout[n0 + n]] = acc[n];
+                        dst[u][x] = p;
                     }
                 }
             }
+        };
+        auto finish = [&](const int hh, const double (&src)[U][CX ? CX : 1]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (hh + u < nh) {
+                    const int ho = uni(sh_hoff[0][hh + u]), ht = uni(sh_hoff[1][hh + u]);
+                    fiber_reduce_store<(CX ? CX : 1), NCT>(src[u], shT + (ht + lo_t), outp + (ho + lo_o), outp + ho + (wave * 64) * 16, X,
+                                                          d.nout, NC, active, lane, cells_in_wave);
+                }
+            }
+        };
+        if (NBIG == 1) {
+            // software pipeline: the next trip's loads are in flight while this trip is reduced and stored
+            double fa[U][CX ? CX : 1], fb[U][CX ? CX : 1];
+            issue(0, fa);
+            for (int hh = 0; hh < nh; hh += 2 * U) {
+                if (hh + U < nh) issue(hh + U, fb);
+                finish(hh, fa);
+                if (hh + U < nh) {
+                    if (hh + 2 * U < nh) issue(hh + 2 * U, fa);
+                    finish(hh + U, fb);
+                }
+            }
         } else {
+            double fa[U][CX ? CX : 1];
+            for (int hh = 0; hh < nh; hh += U) {
+                issue(hh, fa);
+                finish(hh, fa);
+            }
+        }
+    } else {
+        const int cx = d.cx, c1 = d.c1;
+        for (int hh = 0; hh < nh; ++hh) {
             if (active) {
+                const double *__restrict__ Tp = shT + (sh_hoff[1][hh] + lo_t);
+                double *__restrict__ o = outp + (sh_hoff[0][hh] + lo_o);
                 for (int n0 = 0; n0 < NC; n0 += 4) {
                     double acc[4];
 #pragma unroll
                     for (int n = 0; n < 4; ++n) acc[n] = 0.0;
                     for (int x = 0; x < cx; ++x) {
                         const int x2 = x / c1, x1 = x - x2 * c1;
-                        double p = big[0][hb[0] + lo_b[0] + x1 * bxs1[0] + x2 * bxs2[0]];
-#pragma unroll
-                        for (int b = 1; b < NBIG; ++b) p *= big[b][hb[b] + lo_b[b] + x1 * bxs1[b] + x2 * bxs2[b]];
+                        double p = big[0][sh_hoff[2][hh] + lane_off[2] + x1 * bxs1[0] + x2 * bxs2[0]];
+                        if (NBIG > 1) p *= big[NBIG - 1][sh_hoff[3][hh] + lane_off[3] + x1 * bxs1[NBIG - 1] + x2 * bxs2[NBIG - 1]];
 #pragma unroll
                         for (int n = 0; n < 4; ++n)
                             if (n0 + n < NC) acc[n] += p * Tp[x * NC + n0 + n];
                     }
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
-                        if (n0 + n < NC) o[nout[n0 + n]] = acc[n];
+                        if (n0 + n < NC) o[d.nout[n0 + n]] = acc[n];
                 }
             }
         }
@@ -398,91 +485,64 @@ __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double 
     __syncthreads();
 }
 
-// ---- out-of-line wrappers for the segment interpreter: each specialisation keeps its own register allocation
-template <int NIN, int MAXC>
-__device__ __noinline__ void generic_call(const uint32_t *sw, int (*sh_hoff)[kTileMax], const double *pool, double *slot,
-                                          double *results, int tid) {
-    generic_cx<NIN, MAXC>(sw, sh_hoff, pool, slot, results, tid, 0, (int)sw[3]);
-}
+#define MIBN_FIBER_CASES(NB, C)                                                                        \
+    case (NB - 1) * 12 + C * 4 + 0: fiber_call<NB, C, 0>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 12 + C * 4 + 1: fiber_call<NB, C, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 12 + C * 4 + 2: fiber_call<NB, C, 2>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 12 + C * 4 + 3: fiber_call<NB, C, 3>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
 
-// SEGMENT: a run of small GENERIC steps of one request, executed back to back by one workgroup
-__global__ __launch_bounds__(kWG) void seg_kernel(const LevelArgs A) {
+// One level of the schedule: workgroup b runs item wg_item[b] - a tile of a big step or a segment of small steps.
+__global__ __launch_bounds__(kWG, 4) void ve_level_kernel(const LevelArgs A) {
+    __shared__ __attribute__((aligned(16))) double shT[kMaxT];
+    __shared__ __attribute__((aligned(16))) uint32_t shX[4 * 64 * kXRow];
     __shared__ uint32_t sh_step[kMaxStepWords];
     __shared__ int sh_hoff[kMaxIn][kTileMax];
     __shared__ double sh_red[kWG / 64];
     const int tid = threadIdx.x;
-    const Item it = A.items[blockIdx.x];
+    const uint32_t wg = blockIdx.x + A.wg_base;
+    const Item it = A.items[A.wg_item[wg]];
     double *slot = A.arena + A.arena_off[it.req];
     const uint32_t *p = A.prog + A.prog_off[it.req] + it.rel_off;
-    const int n_steps = (int)it.a;
-    for (int s = 0; s < n_steps; ++s) {
-        const int words = (int)p[6];
-        __syncthreads();  // previous step's stores are done and visible to the workgroup; sh_step reusable
-        for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
-        __syncthreads();
-        const int n_in = (sh_step[0] >> 8) & 0xff;
-        switch (n_in) {
-            case 1: generic_call<1, 2>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-            case 2: generic_call<2, 2>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-            case 3: generic_call<3, 2>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-            case 4: generic_call<4, 1>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-            case 5: generic_call<5, 1>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
-            default: generic_call<6, 1>(sh_step, sh_hoff, A.pool, slot, A.results, tid); break;
+    if (it.a & kItemSegment) {
+        // SEGMENT: small GENERIC steps of one request, back to back
+        const int n_steps = (int)(it.a & ~kItemSegment);
+        for (int s = 0; s < n_steps; ++s) {
+            const int words = (int)p[6];
+            __syncthreads();  // previous step's stores are done and visible to the workgroup; sh_step reusable
+            for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
+            __syncthreads();
+            generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, 0, (int)sh_step[3]);
+            if ((sh_step[1] >> 16) & kFlagFinal) {
+                const uint64_t out_off = (uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32);
+                normalise(A.results + out_off, (int)(sh_step[2] * sh_step[3]), sh_red, tid);
+            }
+            p += words;
         }
-        if ((sh_step[1] >> 16) & kFlagFinal) {
-            const uint64_t out_off = (uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32);
-            const int n = (int)(sh_step[2] * sh_step[3]);
-            normalise(A.results + out_off, n, sh_red, tid);
-        }
-        p += words;
+        return;
     }
-}
-
-// Which tiled step does this workgroup work on?  items[k].b = first tile of step k within the launch (ascending).
-__device__ __forceinline__ int find_item(const Item *__restrict__ items, int n, uint32_t wg) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid].b <= wg) lo = mid;
-        else hi = mid - 1;
-    }
-    return lo;
-}
-
-// TILE of a big FIBER step
-template <int NBIG, int CXC, int NCC>
-__global__ __launch_bounds__(kWG) void fiber_tile_kernel(const LevelArgs A) {
-    __shared__ __attribute__((aligned(16))) double shT[kMaxT];
-    __shared__ __attribute__((aligned(16))) uint32_t shX[NCC == 2 ? 4 * 64 * kXRow : 4];
-    __shared__ uint32_t sh_step[kMaxStepWords];
-    __shared__ int sh_hoff[2 + NBIG][kTileMax];
-    const int tid = threadIdx.x;
-    const Item it = A.items[find_item(A.items, A.n_items, blockIdx.x)];
-    double *slot = A.arena + A.arena_off[it.req];
-    const uint32_t *p = A.prog + A.prog_off[it.req] + it.rel_off;
+    // TILE of a big step: hi iterations [h0, h1)
     const int words = (int)p[6];
     for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
     __syncthreads();
-    const int h0 = (int)((blockIdx.x - it.b) * it.a);
+    const int h0 = (int)((wg - it.b) * it.a);
     const int h1 = min((int)sh_step[3], h0 + (int)it.a);
-    fiber_body<NBIG, CXC, NCC>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1);
+    if ((sh_step[0] & 0xff) == kKindFiber) {
+        const int cx = (int)(sh_step[1] & 0xffff), c1 = (int)(sh_step[8] >> 16), NC = (int)(sh_step[7] >> 16);
+        const bool contig = ((sh_step[1] >> 16) & kFlagContig) != 0;
+        const int cxc = (cx == 4 && c1 == 4) ? 0 : ((cx == 16 && c1 == 4) ? 1 : 2);
+        const int ncc = NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && contig) ? 2 : 3));
+        switch (((int)(sh_step[7] & 0xf) - 1) * 12 + cxc * 4 + ncc) {
+            MIBN_FIBER_CASES(1, 0)
+            MIBN_FIBER_CASES(1, 1)
+            MIBN_FIBER_CASES(1, 2)
+            MIBN_FIBER_CASES(2, 0)
+            MIBN_FIBER_CASES(2, 1)
+            MIBN_FIBER_CASES(2, 2)
+        }
+    } else {
+        generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);
+    }
 }
-
-// TILE of a big GENERIC step
-template <int NIN>
-__global__ __launch_bounds__(kWG) void generic_tile_kernel(const LevelArgs A) {
-    __shared__ uint32_t sh_step[kMaxStepWords];
-    __shared__ int sh_hoff[NIN][kTileMax];
-    const int tid = threadIdx.x;
-    const Item it = A.items[find_item(A.items, A.n_items, blockIdx.x)];
-    double *slot = A.arena + A.arena_off[it.req];
-    const uint32_t *p = A.prog + A.prog_off[it.req] + it.rel_off;
-    const int words = (int)p[6];
-    for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
-    __syncthreads();
-    const int h0 = (int)((blockIdx.x - it.b) * it.a);
-    const int h1 = min((int)sh_step[3], h0 + (int)it.a);
-    generic_cx<NIN, (NIN <= 3 ? 2 : 1)>(sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);
-}
+#undef MIBN_FIBER_CASES
 
 }  // namespace mibn

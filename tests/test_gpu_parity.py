@@ -85,6 +85,7 @@ def test_c3_fused_vs_single_variable_passes(amd):
     be = bn.backend
     q, ev, ec = netspec.c3_requests(100, 4, 1024, 4, seed=1)
     to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    be.engine.set_option("split_kinds", 1)  # one launch per class of work: kernel_stats() names the classes that ran
     fused = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
     fused_bytes = be.engine.stats()["alg_bytes"]
     names = {k["name"] for k in be.engine.kernel_stats()}
