@@ -38,7 +38,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
     const uint32_t kind = w0 & 0xff;
     const int n_in = (w0 >> 8) & 0xff, na = (w0 >> 16) & 0xff;
     const int cx = (int)(p[1] & 0xffff);
-    const bool fin = (p[1] >> 16) & 1;
+    const bool fin = (p[1] >> 16) & kFlagFinal;
     const int64_t lo = p[2];
     const uint64_t out_off = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
     double *slot = arena.data() + arena_base;
@@ -109,6 +109,22 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
             if ((int64_t)rax[3 * a + 1] != expect) { g_err = "CONTIG step whose lane block is not contiguous"; return -9; }
             expect *= rax[3 * a];
         }
+    }
+    if (const int rs = (p[1] >> kRowStrideShift) & 0xff) {
+        // MFMA form: within every wave (64 consecutive lane cells) the 16 cells of a row block share their T offset
+        if (rs != 1 && rs != 4 && rs != 16) { g_err = "bad MFMA row stride"; return -9; }
+        const int nlo_m = (p[0] >> 24) & 0xff;
+        auto lo_t = [&](int64_t cell) {
+            int64_t r = cell, to = 0;
+            for (int a = 0; a < nlo_m; ++a) { to += (r % rax[3 * a]) * (int64_t)rax[3 * a + 2]; r /= rax[3 * a]; }
+            return to;
+        };
+        for (int64_t w0 = 0; w0 < lo; w0 += 64)
+            for (int rb = 0; rb < 4; ++rb)
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t c0 = w0 + rs * rb, c = w0 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+                    if (c < lo && c0 < lo && lo_t(c) != lo_t(c0)) { g_err = "MFMA row block mixes T slices"; return -9; }
+                }
     }
     std::vector<double> Tt((size_t)T);
     for (int t = 0; t < T; ++t) {

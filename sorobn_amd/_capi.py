@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmibn.so")
+LIB_PATH = os.environ.get("MIBN_LIB") or os.path.join(_HERE, "libmibn.so")  # MIBN_LIB: kernel-variant experiments
 
 # every symbol include/mibn.h declares (tests check that the library exports all of them)
 SYMBOLS = [

@@ -241,7 +241,7 @@ struct Arena {
     int nf = 0;
     int64_t top = 0;
     int64_t alloc(int64_t n) {
-        n = (n + 1) & ~int64_t(1);  // keep 16-byte alignment
+        n = (n + 15) & ~int64_t(15);  // 128-byte aligned tables: a wave's 512-byte load or store touches exactly 4 cache lines
         for (int i = 0; i < nf; ++i)
             if (fsz[i] >= n) {
                 const int64_t o = foff[i];
@@ -261,7 +261,7 @@ struct Arena {
         return o;
     }
     void release(int64_t o, int64_t n) {
-        n = (n + 1) & ~int64_t(1);
+        n = (n + 15) & ~int64_t(15);
         int i = 0;
         while (i < nf && foff[i] < o) ++i;
         const bool left = i > 0 && foff[i - 1] + fsz[i - 1] == o;
@@ -435,6 +435,20 @@ struct Emitter {
         uint32_t *w = prog.extend(words);
         header(w, kKindFiber, nb + ns, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
         if (contig) w[1] |= kFlagContig << 16;
+        {
+            // row stride of the MFMA form: at most one ctrl axis inside a wave's 64 cells, 4 states, cell stride 1/4/16
+            int row_stride = 16, inside = 0;
+            int64_t cs = 1;
+            for (int i = 0; i < nlo && cs < 64; ++i) {
+                if (rtst[i] != 0) {
+                    ++inside;
+                    row_stride = (rcard[i] == 4 && (cs == 1 || cs == 4 || cs == 16)) ? (int)cs : 0;
+                }
+                cs *= rcard[i];
+            }
+            if (inside > 1) row_stride = 0;
+            w[1] |= (uint32_t)row_stride << kRowStrideShift;
+        }
         w[7] = (uint32_t)nb | ((uint32_t)ns << 4) | ((uint32_t)nN << 8) | ((uint32_t)nctrl << 12) | ((uint32_t)NC << 16);
         w[8] = (uint32_t)T | ((uint32_t)c1 << 16);
         uint32_t *p = w + kHdrWords;
@@ -877,11 +891,11 @@ const char *kernel_name(int kid) {
     static bool init = false;
     if (!init) {
         names[kKidSeg] = "seg_kernel";
-        static const char *cxn[3] = {"cx4", "cx16", "cxN"}, *ncn[4] = {"nc1", "nc4", "nc16", "ncN"};
+        static const char *cxn[3] = {"cx4", "cx16", "cxN"}, *ncn[5] = {"nc1", "nc4", "nc16", "ncN", "nc16-mfma"};
         for (int nb = 1; nb <= 2; ++nb)
             for (int c = 0; c < 3; ++c)
-                for (int n = 0; n < 4; ++n)
-                    names[kKidFiber0 + (nb - 1) * 12 + c * 4 + n] =
+                for (int n = 0; n < 5; ++n)
+                    names[kKidFiber0 + (nb - 1) * 15 + c * 5 + n] =
                         "fiber_tile_kernel<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
         for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic_tile_kernel<" + std::to_string(j + 1) + ">";
         init = true;
@@ -901,7 +915,7 @@ int fiber_nc_class(const uint32_t *w) {
     const bool contig = ((w[1] >> 16) & kFlagContig) != 0;
     if (NC == 1) return 0;
     if (NC == 4 && contig) return 1;
-    if (NC == 16 && contig) return 2;
+    if (NC == 16 && contig) return (((w[1] >> kRowStrideShift) & 0xff) && fiber_cx_class(w) < 2) ? 4 : 2;
     return 3;
 }
 
@@ -909,7 +923,7 @@ int kernel_id_of_step(const uint32_t *w) {
     const uint32_t kind = w[0] & 0xff;
     if (kind == kKindFiber) {
         const int nb = w[7] & 0xf;
-        return kKidFiber0 + (nb - 1) * 12 + fiber_cx_class(w) * 4 + fiber_nc_class(w);
+        return kKidFiber0 + (nb - 1) * 15 + fiber_cx_class(w) * 5 + fiber_nc_class(w);
     }
     const int n_in = (w[0] >> 8) & 0xff;
     return kKidGeneric0 + std::min(std::max(n_in, 1), kMaxIn) - 1;

@@ -112,7 +112,12 @@ struct PlanStats {
 //      bstride[b][a]              b < n_big, a < n_axes
 //      flag CONTIG: nout[n] == n and the lane-varying block is contiguous in the output (cell l of the block at
 //      l*NC), i.e. the lanes of a wave own one contiguous 64*NC-cell region (vector / transposed stores).
+//      w1 bits 20..27 = row stride s of the fp64-MFMA form (0 = not applicable): the 64 cells of a wave split into
+//      4 row blocks of 16 cells that share one T[., ., ctrl] slice - block rb = cells (i % s) + s*rb + 4*s*(i / s),
+//      i < 16 - so that per block the step is a dense [16 x cx] x [cx x 16] product.  s = 16 when no ctrl axis lies
+//      inside a wave's 64 cells, s = 1 / 4 / 16 = the cell stride of the single 4-state ctrl axis that does.
 constexpr uint32_t kFlagFinal = 1, kFlagContig = 2;
+constexpr int kRowStrideShift = 20;  // w1 bits 20..27
 constexpr int kHdrWords = 10;
 constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;
 constexpr int kMaxNC = 16;         // N-fiber length held in registers
@@ -196,13 +201,14 @@ struct Launch {
     double alg_bytes;     // algorithmic bytes of the steps in this launch
 };
 constexpr int kKidSeg = 0;         // segments of small GENERIC steps
-constexpr int kKidFiber0 = 1;      // 24 FIBER tile classes: 1 + (n_big-1)*12 + cx_class*4 + nc_class
-constexpr int kKidGeneric0 = 25;   // 6 GENERIC tile classes: 25 + (n_in - 1)
-constexpr int kNumKernels = 31;
+constexpr int kKidFiber0 = 1;      // 30 FIBER tile classes: 1 + (n_big-1)*15 + cx_class*5 + nc_class
+constexpr int kKidGeneric0 = 31;   // 6 GENERIC tile classes: 31 + (n_in - 1)
+constexpr int kNumKernels = 37;
 const char *kernel_name(int kid);
 int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
 int fiber_cx_class(const uint32_t *w);     // 0: cx = 4   1: cx = 16 = 4 x 4   2: anything else (runtime loop)
 int fiber_nc_class(const uint32_t *w);     // 0: NC = 1   1: NC = 4 contiguous   2: NC = 16 contiguous   3: anything else
+                                           // 4: NC = 16 contiguous, cx 4 or 16, row stride != 0 -> fp64 MFMA 16x16x4
 int64_t step_cost_bytes(const uint32_t *w);
 bool step_is_tiled(const Network &net, const uint32_t *w);
 int step_tile_h(const Network &net, const uint32_t *w);

@@ -41,6 +41,12 @@
 namespace mibn {
 
 constexpr int kWG = 256;
+#ifndef MIBN_MIN_WAVES
+#define MIBN_MIN_WAVES 3   // waves per SIMD the level kernel is compiled for (VGPR budget 512 / MIBN_MIN_WAVES)
+#endif
+#ifndef MIBN_PIPELINE
+#define MIBN_PIPELINE 1    // software-pipelined FIBER loop (next trip's loads in flight during the reduction)
+#endif
 constexpr int kXRow = 20;  // dwords per lane row of the transpose buffer: 8 doubles + 16 B pad (conflict-free b128 writes)
 
 struct LevelArgs {
@@ -223,9 +229,10 @@ __device__ __forceinline__ FiberDesc fiber_desc(const uint32_t *sw) {
 //  * T[n + NC*(x + cx*ctrl)] = product of the small inputs (the CPT slices)
 //  * wave-uniform offsets of the tile's iterations -> sh_hoff[0] (output), [1] (T), [2 + b] (big input b)
 //  * this lane's offsets (one R cell per lane) -> lane_off[0] (output), [1] (T), [2 + b]
-__device__ __noinline__ void fiber_prologue(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
-                                            const double *__restrict__ pool, const double *__restrict__ slot, const int tid,
-                                            const int h_begin, const int h_end, int *lane_off) {
+struct LaneOff { int o, t, b0, b1; };  // returned in registers (a pointer to the caller's array would live in scratch)
+__device__ __noinline__ LaneOff fiber_prologue(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
+                                               const double *__restrict__ pool, const double *__restrict__ slot, const int tid,
+                                               const int h_begin, const int h_end) {
     const FiberDesc d = fiber_desc(sw);
     for (int t0 = 0; t0 < d.T; t0 += 2 * kWG) {  // two entries per lane and trip: their loads overlap
         double v[2] = {1.0, 1.0};
@@ -289,9 +296,8 @@ __device__ __noinline__ void fiber_prologue(const uint32_t *sw, double *__restri
         sh_hoff[2][tid] = hi[2];
         sh_hoff[3][tid] = hi[3];
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) lane_off[k] = lo[k];
     __syncthreads();  // T and the offsets are ready
+    return LaneOff{lo[0], lo[1], lo[2], lo[3]};
 }
 
 // Reduce one loaded fiber f[0..CX) against T and store the NC outputs.  NCT = compile-time NC (1, 4, 16) or 0.
@@ -374,8 +380,8 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
     constexpr int CX = CXC == 0 ? 4 : (CXC == 1 ? 16 : 0);
     constexpr int NCT = NCC == 0 ? 1 : (NCC == 1 ? 4 : (NCC == 2 ? 16 : 0));
     constexpr int U = CX ? 16 / CX : 1;  // iterations per trip: 16 loads in flight per lane and big input
-    int lane_off[4];
-    fiber_prologue(sw, shT, sh_hoff, pool, slot, tid, h_begin, h_end, lane_off);
+    const LaneOff lane_off_ = fiber_prologue(sw, shT, sh_hoff, pool, slot, tid, h_begin, h_end);
+    const int lane_off[4] = {lane_off_.o, lane_off_.t, lane_off_.b0, lane_off_.b1};
     const FiberDesc d = fiber_desc(sw);
     const int NC = NCT ? NCT : d.NC;
     double *__restrict__ outp = slot + ((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
@@ -425,7 +431,7 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
                 }
             }
         };
-        if (NBIG == 1) {
+        if (NBIG == 1 && MIBN_PIPELINE) {
             // software pipeline: the next trip's loads are in flight while this trip is reduced and stored
             double fa[U][CX ? CX : 1], fb[U][CX ? CX : 1];
             issue(0, fa);
@@ -471,6 +477,106 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
     }
 }
 
+// fp64 MFMA classes: NC = 16 contiguous, cx = 4*KS (KS = 1: one 4-state variable, KS = 4: two), row stride s != 0.
+// The 64 cells of a wave split into 4 row blocks of 16 cells sharing one T slice (cell of row i of block rb =
+// (i % s) + s*rb + 4*s*(i / s); s = 16: consecutive cells); per block and iteration the step is the dense product
+// out[16 cells x 16] = F[16 cells x cx] . T[cx x 16]:  v_mfma_f64_16x16x4_f64, 4 x values per instruction.  Lane l holds
+//   A[row l&15][k l>>4] = F[x = 4*ks + (l>>4)][cell(rb, l&15)]        (s = 16: a load reads 4 x-slices x 128 B),
+//   B[k l>>4][col l&15] = T[n = l&15][x = 4*ks + (l>>4)][ctrl(rb)]    (4*KS doubles per lane and iteration, from LDS),
+//   D[row (l>>4) + 4*v][col l&15]  ->  out[cell(rb, 4*v + (l>>4))*16 + (l&15)]: s >= 4: 512 contiguous bytes per store.
+// Against the VALU form this removes the 256 LDS operand reads per lane-iteration (the VALU form of this shape is
+// LDS-bound: SQ_LDS_IDX_ACTIVE ~ 90 % of the kernel time) and the transposition of the 128-byte fibers.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int NBIG, int KS>
+__device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
+                                                uint32_t *__restrict__ shX, const double *__restrict__ pool,
+                                                double *__restrict__ slot, const int tid, const int h_begin, const int h_end) {
+    const LaneOff lane_off = fiber_prologue(sw, shT, sh_hoff, pool, slot, tid, h_begin, h_end);
+    const FiberDesc d = fiber_desc(sw);
+    double *__restrict__ outp = slot + ((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+    const double *__restrict__ big[NBIG];
+    int bxs1[NBIG], bxs2[NBIG];
+#pragma unroll
+    for (int b = 0; b < NBIG; ++b) {
+        big[b] = table_ptr(d.bigs[4 * b], d.bigs[4 * b + 1], pool, slot);
+        bxs1[b] = (int)d.bigs[4 * b + 2];
+        bxs2[b] = (int)d.bigs[4 * b + 3];
+    }
+    // every lane needs the offsets of the 4 cells (one per row block) it feeds: exchange them through LDS
+    int *sh_cell = reinterpret_cast<int *>(shX);  // [3][kWG]: big input 0, big input 1, T
+    sh_cell[tid] = lane_off.b0;
+    sh_cell[kWG + tid] = lane_off.b1;
+    sh_cell[2 * kWG + tid] = lane_off.t;
+    __syncthreads();
+    const int nh = h_end - h_begin;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);  // 1, 4 or 16
+    uint32_t la[NBIG][4];
+    int tb[4], ocell[4][4];  // T offset of row block rb; cell of accumulator element v of row block rb
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);  // the cell this lane loads for block rb
+#pragma unroll
+        for (int b = 0; b < NBIG; ++b) la[b][rb] = (uint32_t)(sh_cell[b * kWG + c] + lk * bxs1[b]);
+        tb[rb] = sh_cell[2 * kWG + wave * 64 + rs * rb];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = lk + 4 * v;
+            ocell[rb][v] = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+        }
+    }
+    double *__restrict__ olane = outp + lrow;
+
+    auto issue = [&](const int hh, double (&dst)[4][KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double *__restrict__ b0 = big[0] + (uni(sh_hoff[2][hh]) + ks * bxs2[0]);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                double p = b0[la[0][rb]];
+                if (NBIG > 1) {
+                    const double *__restrict__ b1 = big[NBIG - 1] + (uni(sh_hoff[3][hh]) + ks * bxs2[NBIG - 1]);
+                    p *= b1[la[NBIG - 1][rb]];
+                }
+                dst[rb][ks] = p;
+            }
+        }
+    };
+    auto finish = [&](const int hh, const double (&a)[4][KS]) {
+        const int ho = uni(sh_hoff[0][hh]), ht = uni(sh_hoff[1][hh]);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][ks], shT[ht + tb[rb] + lrow + 16 * (4 * ks + lk)], acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (ocell[rb][v] < d.lo_cells) olane[ho + ocell[rb][v] * 16] = acc[v];
+        }
+    };
+    if (NBIG == 1 && MIBN_PIPELINE) {
+        double fa[4][KS], fb[4][KS];
+        issue(0, fa);
+        for (int hh = 0; hh < nh; hh += 2) {
+            if (hh + 1 < nh) issue(hh + 1, fb);
+            finish(hh, fa);
+            if (hh + 1 < nh) {
+                if (hh + 2 < nh) issue(hh + 2, fa);
+                finish(hh + 1, fb);
+            }
+        }
+    } else {
+        double fa[4][KS];
+        for (int hh = 0; hh < nh; ++hh) {
+            issue(hh, fa);
+            finish(hh, fa);
+        }
+    }
+}
+
 // posterior / posterior.sum()  (bayes_net.py:790); an all-zero table (zero-probability evidence) stays zero
 __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double *sh_red, int tid) {
     double s = 0.0;
@@ -486,13 +592,16 @@ __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double 
 }
 
 #define MIBN_FIBER_CASES(NB, C)                                                                        \
-    case (NB - 1) * 12 + C * 4 + 0: fiber_call<NB, C, 0>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
-    case (NB - 1) * 12 + C * 4 + 1: fiber_call<NB, C, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
-    case (NB - 1) * 12 + C * 4 + 2: fiber_call<NB, C, 2>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
-    case (NB - 1) * 12 + C * 4 + 3: fiber_call<NB, C, 3>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
+    case (NB - 1) * 15 + C * 5 + 0: fiber_call<NB, C, 0>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 15 + C * 5 + 1: fiber_call<NB, C, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 15 + C * 5 + 2: fiber_call<NB, C, 2>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 15 + C * 5 + 3: fiber_call<NB, C, 3>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
+#define MIBN_MFMA_CASES(NB)                                                                            \
+    case (NB - 1) * 15 + 0 * 5 + 4: fiber_mfma_call<NB, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 15 + 1 * 5 + 4: fiber_mfma_call<NB, 4>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
 
 // One level of the schedule: workgroup b runs item wg_item[b] - a tile of a big step or a segment of small steps.
-__global__ __launch_bounds__(kWG, 4) void ve_level_kernel(const LevelArgs A) {
+__global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const LevelArgs A) {
     __shared__ __attribute__((aligned(16))) double shT[kMaxT];
     __shared__ __attribute__((aligned(16))) uint32_t shX[4 * 64 * kXRow];
     __shared__ uint32_t sh_step[kMaxStepWords];
@@ -530,19 +639,23 @@ __global__ __launch_bounds__(kWG, 4) void ve_level_kernel(const LevelArgs A) {
         const int cx = (int)(sh_step[1] & 0xffff), c1 = (int)(sh_step[8] >> 16), NC = (int)(sh_step[7] >> 16);
         const bool contig = ((sh_step[1] >> 16) & kFlagContig) != 0;
         const int cxc = (cx == 4 && c1 == 4) ? 0 : ((cx == 16 && c1 == 4) ? 1 : 2);
-        const int ncc = NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && contig) ? 2 : 3));
-        switch (((int)(sh_step[7] & 0xf) - 1) * 12 + cxc * 4 + ncc) {
+        const bool mfma = ((sh_step[1] >> kRowStrideShift) & 0xff) != 0 && cxc < 2;
+        const int ncc = NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && contig) ? (mfma ? 4 : 2) : 3));
+        switch (((int)(sh_step[7] & 0xf) - 1) * 15 + cxc * 5 + ncc) {
             MIBN_FIBER_CASES(1, 0)
             MIBN_FIBER_CASES(1, 1)
             MIBN_FIBER_CASES(1, 2)
             MIBN_FIBER_CASES(2, 0)
             MIBN_FIBER_CASES(2, 1)
             MIBN_FIBER_CASES(2, 2)
+            MIBN_MFMA_CASES(1)
+            MIBN_MFMA_CASES(2)
         }
     } else {
         generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);
     }
 }
 #undef MIBN_FIBER_CASES
+#undef MIBN_MFMA_CASES
 
 }  // namespace mibn

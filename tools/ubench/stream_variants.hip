@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void step(const double *__restrict__ in, doubl
     constexpr long R = kCells / (CX > NC ? CX : NC);  // r cells per table (input R*CX cells, output R*NC cells)
     constexpr int PADW = NC * 2 + 4;    // dwords per lane row in the transpose buffer (16 B pad)
     __shared__ __attribute__((aligned(16))) double shT[NC * CX * 4];
-    __shared__ __attribute__((aligned(16))) uint32_t shX[STORE == 1 ? 4 * 64 * PADW : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t shX[STORE == 1 ? 4 * 64 * PADW : (STORE >= 3 ? 4 * 64 * 20 : 4)];
     const int tid = threadIdx.x;
     const int req = blockIdx.x / tiles_per_req, tile = blockIdx.x % tiles_per_req;
     const double *__restrict__ F = in + (long)req * kCells;
@@ -64,6 +64,44 @@ __global__ __launch_bounds__(256) void step(const double *__restrict__ in, doubl
             } else if (STORE == 2) {
 #pragma unroll
                 for (int n = 0; n < NC; ++n) __builtin_nontemporal_store(acc[n], O + rr * NC + n);
+            } else if (STORE == 3 && NC == 16) {
+                // production pattern: two rounds of 8 cells per lane, store instructions write 64-byte segments
+                uint32_t *X = shX + wave * 64 * 20;
+                double *Ob = O + (r0 + wave * 64) * 16;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int n = 0; n < 8; n += 2) *reinterpret_cast<double2 *>(X + lane * 20 + 2 * n) = make_double2(acc[half * 8 + n], acc[half * 8 + n + 1]);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int g = k * 64 + lane;
+                        const int owner = g >> 2, piece = g & 3;
+                        const double2 v = *reinterpret_cast<const double2 *>(X + owner * 20 + 4 * piece);
+                        *reinterpret_cast<double2 *>(Ob + owner * 16 + half * 8 + 2 * piece) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else if (STORE == 4 && NC == 16) {
+                // two rounds of 32 lanes x 16 cells: every store instruction writes 1 KiB contiguous
+                uint32_t *X = shX + wave * 64 * 20;   // 32 rows of 36 dwords fit in 64 * 20
+                double *Ob = O + (r0 + wave * 64) * 16;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if ((lane >> 5) == half) {
+#pragma unroll
+                        for (int n = 0; n < 16; n += 2) *reinterpret_cast<double2 *>(X + (lane & 31) * 36 + 2 * n) = make_double2(acc[n], acc[n + 1]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int g = k * 64 + lane;             // chunk of this round's 4 KiB
+                        const int owner = g >> 3, piece = g & 7;
+                        const double2 v = *reinterpret_cast<const double2 *>(X + owner * 36 + 4 * piece);
+                        *reinterpret_cast<double2 *>(Ob + half * 512 + 2 * g) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             } else {
                 // wave-private transpose: lane row -> 16-byte chunks in global order
                 uint32_t *X = shX + wave * 64 * PADW;
@@ -129,6 +167,8 @@ int main(int argc, char **argv) {
     RUN(16, 16, 1, 32, 1, "cx16 nc16 fused pair, LDS-transposed store H=32");
     RUN(16, 16, 2, 32, 1, "cx16 nc16 fused pair, nontemporal H=32");
     RUN(16, 16, 1, 8, 1, "cx16 nc16 fused pair, LDS-transposed store H=8");
+    RUN(16, 16, 3, 8, 1, "cx16 nc16 fused pair, 2 rounds x 8 cells (64 B segments) H=8");
+    RUN(16, 16, 4, 8, 1, "cx16 nc16 fused pair, 2 rounds x 32 lanes (1 KiB stores) H=8");
     RUN(16, 4, 1, 32, 1, "cx16 nc4 (2 eliminated, 1 new), LDS-transposed H=32");
     RUN(4, 16, 1, 32, 1, "cx4 nc16 (1 eliminated, 2 new), LDS-transposed H=32");
     RUN(4, 1, 0, 128, 1, "cx4 nc1 plain sum-out H=128");
