@@ -290,7 +290,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
 extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
                                  const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
                                  int64_t B, int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars,
-                                 const int32_t *ecodes, int threads, double *stats /* bytes, steps, words */) {
+                                 const int32_t *ecodes, int threads, double *stats /* bytes, steps, words, schedule ms, items, workgroups */) {
     Network net;
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
@@ -305,8 +305,13 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     auto t0 = std::chrono::steady_clock::now();
     plan_batch(net, pool, bufs, 0, B, q_off.data(), qvars, e_off.data(), evars, ecodes, out_off.data(), nullptr, bp);
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    Schedule sc;
+    build_schedule(net, bp, bufs, 0, B, sc);  // warm-up (allocations)
+    auto t1 = std::chrono::steady_clock::now();
+    build_schedule(net, bp, bufs, 0, B, sc);
+    const double sched_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     for (auto &b : bufs) b.release();
-    if (stats) { stats[0] = bp.st.alg_bytes; stats[1] = bp.st.n_steps; stats[2] = (double)bp.total_words; }
+    if (stats) { stats[0] = bp.st.alg_bytes; stats[1] = bp.st.n_steps; stats[2] = (double)bp.total_words; stats[3] = sched_ms; stats[4] = (double)sc.items.size(); stats[5] = (double)sc.wg_item.size(); }
     g_err = bp.err;
     return ms;
 }

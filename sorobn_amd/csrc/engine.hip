@@ -40,7 +40,12 @@ struct mibn_ctx {
     size_t results_cap = 0;  // doubles
     // double-buffered chunk pipeline: workers plan chunk i+1 into pinned buffers while the GPU runs chunk i
     ThreadPool *pool = nullptr;
+    struct Staging {  // pinned host staging: pageable sources would make hipMemcpyAsync block on the stream
+        char *p = nullptr;
+        size_t cap = 0;
+    };
     struct Set {
+        Staging stage[4];           // prog_off, arena_off, items, wg_item
         std::vector<ProgBuf> bufs;  // pinned host program buffers, one per worker
         uint32_t *d_prog = nullptr;
         size_t prog_cap = 0;
@@ -139,6 +144,8 @@ void mibn_destroy(mibn_t *h) {
             (void)hipFree(st.d_arena_off);
             (void)hipFree(st.d_items);
             (void)hipFree(st.d_wg_item);
+            for (auto &sg : st.stage)
+                if (sg.p) (void)hipHostFree(sg.p);
             for (auto e : st.ev) (void)hipEventDestroy(e);
         }
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -242,6 +249,20 @@ uint32_t *pinned_grow(void *, uint32_t *old, size_t used, size_t new_cap) {
     return p;
 }
 
+// async upload through a pinned staging buffer (one per destination and set: reused only after retire())
+int upload(mibn_ctx *h, mibn_ctx::Staging &sg, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return MIBN_OK;
+    if (bytes > sg.cap) {
+        if (sg.p) { HIP_TRY(h, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
+        const size_t cap = bytes + bytes / 4 + 4096;
+        HIP_TRY(h, hipHostMalloc((void **)&sg.p, cap, hipHostMallocDefault));
+        sg.cap = cap;
+    }
+    std::memcpy(sg.p, src, bytes);
+    HIP_TRY(h, hipMemcpyAsync(dst, sg.p, bytes, hipMemcpyHostToDevice, h->stream));
+    return MIBN_OK;
+}
+
 int default_threads() {
     int hw = (int)std::thread::hardware_concurrency();
     int local_world = 1;
@@ -331,8 +352,9 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
     HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
     const int64_t budget_cells = (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes)) / 8.0);
     int64_t n_chunks = 0;
-    for (int64_t b0 = 0; b0 < B; b0 += h->chunk, ++n_chunks) {
-        const int64_t b1 = std::min(B, b0 + h->chunk);
+    // a short first chunk gets the GPU going while the host plans the first full-size one
+    for (int64_t b0 = 0, b1 = 0; b0 < B; b0 = b1, ++n_chunks) {
+        b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
         const int64_t n = b1 - b0;
         mibn_ctx::Set &st = h->set[n_chunks & 1];
         if ((rc = retire(h, st))) return rc;  // its buffers are about to be rewritten
@@ -353,7 +375,7 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
                 HIP_TRY(h, hipMemcpyAsync(st.d_prog + base, st.bufs[t].data, ck.thread_words[t] * 4, hipMemcpyHostToDevice, h->stream));
             base += ck.thread_words[t];
         }
-        HIP_TRY(h, hipMemcpyAsync(st.d_prog_off, ck.prog_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+        if ((rc = upload(h, st.stage[0], st.d_prog_off, ck.prog_off.data(), (size_t)n * 8))) return rc;
         h->stats.h2d_ms += now_ms() - t0;
         // waves: consecutive requests whose private arenas fit the scratch budget together
         for (int64_t r0 = 0; r0 < n;) {
@@ -382,9 +404,9 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             if ((rc = ensure(h, st.d_items, st.items_cap, sc.items.size()))) return rc;
             if ((rc = ensure(h, st.d_wg_item, st.wg_item_cap, sc.wg_item.size()))) return rc;
             t0 = now_ms();
-            HIP_TRY(h, hipMemcpyAsync(st.d_arena_off, sc.arena_off.data(), (size_t)(r1 - r0) * 8, hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(h, hipMemcpyAsync(st.d_items, sc.items.data(), sc.items.size() * sizeof(Item), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(h, hipMemcpyAsync(st.d_wg_item, sc.wg_item.data(), sc.wg_item.size() * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            if ((rc = upload(h, st.stage[1], st.d_arena_off, sc.arena_off.data(), (size_t)(r1 - r0) * 8))) return rc;
+            if ((rc = upload(h, st.stage[2], st.d_items, sc.items.data(), sc.items.size() * sizeof(Item)))) return rc;
+            if ((rc = upload(h, st.stage[3], st.d_wg_item, sc.wg_item.data(), sc.wg_item.size() * sizeof(uint32_t)))) return rc;
             h->stats.h2d_ms += now_ms() - t0;
             LevelArgs A;
             A.prog = st.d_prog;

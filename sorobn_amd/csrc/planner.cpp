@@ -135,6 +135,11 @@ inline double scope_log2(const Network &net, const Bits &b) {
 // per-thread scratch reused across requests
 struct Scratch {
     std::vector<Bits> sim;
+    std::vector<double> simc;
+    std::vector<int32_t> hid;
+    std::vector<int> miss;
+    std::vector<Bits> scopes;
+    std::vector<double> scope_cells;
     std::vector<Bits> adj;
     std::vector<double> w;
     std::vector<char> alive;
@@ -148,89 +153,129 @@ Scratch &scratch() {
     return s;
 }
 
-// SURVEY section 8(d) byte model of an elimination order over factor scopes.
-double simulate(const Network &net, const std::vector<Bits> &f0, const std::vector<int32_t> &order, double abort_above) {
-    std::vector<Bits> &f = scratch().sim;
+inline double scope_cells(const Network &net, const Bits &b) {
+    double c = 1;
+    b.for_each([&](int v) { c *= net.card[v]; });
+    return c;
+}
+
+// SURVEY section 8(d) byte model of an elimination order over factor scopes (f0c = cells of every scope).
+double simulate(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
+                double abort_above) {
+    Scratch &S = scratch();
+    std::vector<Bits> &f = S.sim;
+    std::vector<double> &fc = S.simc;
     f.assign(f0.begin(), f0.end());
+    fc.assign(f0c.begin(), f0c.end());
     double bytes = 0;
     for (int32_t x : order) {
         Bits u;
         u.nw = net.nw;
         double in = 0;
-        size_t k = 0;
-        for (size_t i = 0; i < f.size(); ++i) {
-            if (f[i].test(x)) {
+        const int xw = x >> 6;
+        const uint64_t xm = 1ull << (x & 63);
+        for (size_t i = 0; i < f.size();) {
+            if (f[i].w[xw] & xm) {  // consumed: swap-remove (the order of the factors does not matter)
                 u.or_(f[i]);
-                in += std::exp2(scope_log2(net, f[i]));
+                in += fc[i];
+                if (i + 1 != f.size()) { f[i] = f.back(); fc[i] = fc.back(); }
+                f.pop_back();
+                fc.pop_back();
             } else {
-                if (k != i) f[k] = f[i];
-                ++k;
+                ++i;
             }
         }
-        f.resize(k);
         u.clr(x);
-        bytes += 8.0 * (in + std::exp2(scope_log2(net, u)));
+        const double uc = scope_cells(net, u);
+        bytes += 8.0 * (in + uc);
         if (bytes > abort_above) return bytes;
         f.push_back(u);
+        fc.push_back(uc);
     }
     Bits u;
     u.nw = net.nw;
     double in = 0;
-    for (auto &s : f) {
-        u.or_(s);
-        in += std::exp2(scope_log2(net, s));
+    for (size_t i = 0; i < f.size(); ++i) {
+        u.or_(f[i]);
+        in += fc[i];
     }
-    bytes += 8.0 * (in + std::exp2(scope_log2(net, u)));
+    bytes += 8.0 * (in + scope_cells(net, u));
     return bytes;
 }
 
-// Greedy elimination on the interaction graph.  fill = false: min-weight (size of the factor the
-// elimination creates).  fill = true: min-fill (number of new edges), ties by weight.
-std::vector<int32_t> greedy_order(const Network &net, const std::vector<Bits> &f, const Bits &hidden, bool fill) {
-    const int n = net.n_vars;
+// Greedy min-fill elimination order on the interaction graph: eliminate the vertex whose elimination adds the
+// fewest edges, ties by the size of the factor it creates, then by depth and id.  The fill counts are maintained
+// incrementally: eliminating a vertex changes the neighbourhood of its neighbours (recomputed) and connects pairs
+// of them - every common neighbour of a newly connected pair loses that pair from its fill count.
+std::vector<int32_t> greedy_order(const Network &net, const std::vector<Bits> &f, const Bits &hidden) {
+    const int n = net.n_vars, nw = net.nw;
     Scratch &S = scratch();
     S.adj.assign(n, Bits{});
-    for (auto &a : S.adj) a.nw = net.nw;
+    for (auto &a : S.adj) a.nw = nw;
     for (auto &s : f) s.for_each([&](int v) { S.adj[v].or_(s); });
     for (int v = 0; v < n; ++v) S.adj[v].clr(v);
     std::vector<Bits> &adj = S.adj;
-    std::vector<int32_t> hid;
+    std::vector<int32_t> &hid = S.hid;
+    hid.clear();
     hidden.for_each([&](int v) { hid.push_back(v); });
     S.w.assign(n, 0.0);
+    S.miss.assign(n, 0);
     S.alive.assign(n, 0);
-    auto weight = [&](int x) {
-        const double s = scope_log2(net, adj[x]);
-        if (!fill) return s;
+    auto full = [&](int x) {
+        S.w[x] = scope_log2(net, adj[x]);
         int missing = 0;  // (ordered) pairs of neighbours that are not yet adjacent
-        adj[x].for_each([&](int y) {
-            for (int k = 0; k < net.nw; ++k) missing += __builtin_popcountll(adj[x].w[k] & ~adj[y].w[k]);
+        const Bits &ax = adj[x];
+        ax.for_each([&](int y) {
+            const Bits &ay = adj[y];
+            for (int k = 0; k < nw; ++k) missing += __builtin_popcountll(ax.w[k] & ~ay.w[k]);
             missing -= 1;  // y itself is in adj[x] but not in adj[y]
         });
-        return missing * 64.0 + s;
+        S.miss[x] = missing;
     };
-    for (int x : hid) { S.w[x] = weight(x); S.alive[x] = 1; }
+    for (int x : hid) { full(x); S.alive[x] = 1; }
     std::vector<int32_t> order;
     order.reserve(hid.size());
-    for (size_t it = 0; it < hid.size(); ++it) {
+    size_t n_alive = hid.size();
+    for (size_t it = 0, total = hid.size(); it < total; ++it) {
         int best = -1;
-        for (int x : hid)
-            if (S.alive[x]) {
-                if (best < 0 || S.w[x] < S.w[best] - 1e-12 ||
-                    (std::fabs(S.w[x] - S.w[best]) <= 1e-12 &&
-                     (net.depth[x] < net.depth[best] || (net.depth[x] == net.depth[best] && x < best))))
-                    best = x;
+        double wbest = 0;
+        size_t k = 0;
+        for (size_t i = 0; i < n_alive; ++i) {  // compacts the alive list while scanning it
+            const int x = hid[i];
+            if (!S.alive[x]) continue;
+            hid[k++] = x;
+            const double wx = S.miss[x] * 64.0 + S.w[x];
+            if (best < 0 || wx < wbest - 1e-12 ||
+                (std::fabs(wx - wbest) <= 1e-12 &&
+                 (net.depth[x] < net.depth[best] || (net.depth[x] == net.depth[best] && x < best)))) {
+                best = x;
+                wbest = wx;
             }
+        }
+        n_alive = k;
         order.push_back(best);
         S.alive[best] = 0;
         const Bits nb = adj[best];
-        Bits touched = nb;  // vertices whose weight can change: the neighbours and (min-fill) their neighbours
+        // pairs of neighbours this elimination connects: their common neighbours outside nb lose one missing pair
+        nb.for_each([&](int y) {
+            Bits fresh = nb;  // members of nb not yet adjacent to y
+            fresh.andnot(adj[y]);
+            fresh.clr(y);
+            fresh.for_each([&](int u) {
+                if (u < y) return;
+                Bits common;
+                common.nw = nw;
+                for (int q = 0; q < nw; ++q) common.w[q] = adj[y].w[q] & adj[u].w[q] & ~nb.w[q];
+                common.clr(best);
+                common.for_each([&](int z) { S.miss[z] -= 2; });
+            });
+        });
         nb.for_each([&](int y) {
             adj[y].or_(nb);
             adj[y].clr(best);
             adj[y].clr(y);
         });
-        if (fill) nb.for_each([&](int y) { touched.or_(adj[y]); });
-        touched.for_each([&](int y) { if (S.alive[y]) S.w[y] = weight(y); });
+        nb.for_each([&](int y) { if (S.alive[y]) full(y); });
     }
     return order;
 }
@@ -436,17 +481,24 @@ struct Emitter {
         header(w, kKindFiber, nb + ns, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
         if (contig) w[1] |= kFlagContig << 16;
         {
-            // row stride of the MFMA form: at most one ctrl axis inside a wave's 64 cells, 4 states, cell stride 1/4/16
+            // row stride of the MFMA form: at most one ctrl axis inside a wave's 64 cells (4 states, cell stride 1/4/16);
+            // ctrl axes further out must not change inside a wave (cell stride a multiple of 64)
             int row_stride = 16, inside = 0;
+            bool ok = true;
             int64_t cs = 1;
-            for (int i = 0; i < nlo && cs < 64; ++i) {
+            for (int i = 0; i < nlo; ++i) {
                 if (rtst[i] != 0) {
-                    ++inside;
-                    row_stride = (rcard[i] == 4 && (cs == 1 || cs == 4 || cs == 16)) ? (int)cs : 0;
+                    if (cs < 64) {
+                        ++inside;
+                        if (rcard[i] == 4 && (cs == 1 || cs == 4 || cs == 16)) row_stride = (int)cs;
+                        else ok = false;
+                    } else if (cs % 64 != 0) {
+                        ok = false;
+                    }
                 }
                 cs *= rcard[i];
             }
-            if (inside > 1) row_stride = 0;
+            if (inside > 1 || !ok) row_stride = 0;
             w[1] |= (uint32_t)row_stride << kRowStrideShift;
         }
         w[7] = (uint32_t)nb | ((uint32_t)ns << 4) | ((uint32_t)nN << 8) | ((uint32_t)nctrl << 12) | ((uint32_t)NC << 16);
@@ -580,7 +632,10 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
     pool.clear();
     live.clear();
     pool.reserve(3 * (size_t)net.n_vars + 64);  // never reallocates below: `ins` holds pointers into it
-    std::vector<Bits> scopes;
+    std::vector<Bits> &scopes = S.scopes;
+    std::vector<double> &scells = S.scope_cells;
+    scopes.clear();
+    scells.clear();
     std::string err;
     rel.for_each([&](int v) {
         pool.emplace_back();
@@ -605,6 +660,7 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
         f.cells = cells;
         live.push_back((int)pool.size() - 1);
         scopes.push_back(f.scope);
+        scells.push_back((double)cells);
     });
     if (!err.empty()) return err;
     // single-state variables carry no information: they are never axes, never eliminated
@@ -619,7 +675,7 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
     std::vector<int32_t> best;
     double best_cost = std::numeric_limits<double>::infinity();
     auto consider = [&](std::vector<int32_t> &&o) {
-        double c = simulate(net, scopes, o, best_cost);
+        double c = simulate(net, scopes, scells, o, best_cost);
         if (c < best_cost) { best_cost = c; best = std::move(o); }
     };
     if (!hid.empty()) {
@@ -638,8 +694,9 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
             consider(sorted_by([&](int v) { return -(double)net.depth[v]; }));  // reverse sweep
             for (auto &h : net.hints) consider(sorted_by([&](int v) { return (double)h[v]; }));
         }
-        // (greedy min-weight is evaluated too in principle, but on grids min-fill dominates it: 52.7 vs 52.5 MB mean)
-        { PROF(3); consider(greedy_order(net, scopes, hidden, true)); }
+        // greedy min-fill: the best order on 60 % of the C3 requests (52.7 MB mean against 67.6 MB for the sweeps alone),
+        // skipped where the sweeps already found a plan too cheap to be worth the host time
+        if (best_cost > net.minfill_above) { PROF(3); consider(greedy_order(net, scopes, hidden)); }
     }
 
     PROF(4);
@@ -819,6 +876,42 @@ void ThreadPool::run(const std::function<void(int)> &job) {
     }
 }
 
+// Cut one request's program into work items (see Schedule): a maximal run of small steps is one SEGMENT, every big
+// step is a level of its own, tiled.  Appends to `out`, returns the number of items.
+static uint32_t tag_request(const Network &net, const uint32_t *prog, std::vector<Tag> &out) {
+    const int n_steps = (int)prog[0];
+    const size_t first = out.size();
+    uint32_t off = 1;
+    uint16_t level = 0;
+    uint32_t seg_first = 0, seg_steps = 0;
+    double seg_bytes = 0;
+    auto flush = [&]() {
+        if (seg_steps) {
+            out.push_back({seg_first, seg_steps | kItemSegment, 1u, level, (uint16_t)kKidSeg, (float)seg_bytes});
+            ++level;
+            seg_steps = 0;
+            seg_bytes = 0;
+        }
+    };
+    for (int s = 0; s < n_steps; ++s) {
+        const uint32_t *w = prog + off;
+        const double bytes = (double)step_cost_bytes(w);
+        if (step_is_tiled(net, w)) {
+            flush();
+            const uint32_t th = (uint32_t)step_tile_h(net, w);
+            out.push_back({off, th, (w[3] + th - 1) / th, level, (uint16_t)kernel_id_of_step(w), (float)bytes});
+            ++level;
+        } else {
+            if (!seg_steps) seg_first = off;
+            ++seg_steps;
+            seg_bytes += bytes;
+        }
+        off += w[6];
+    }
+    flush();
+    return (uint32_t)(out.size() - first);
+}
+
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
                 const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck) {
@@ -834,17 +927,23 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
     ck.thread_of.assign(n, 0);
     ck.local_off.assign(n, 0);
     ck.thread_words.assign(T, 0);
+    ck.tag_first.assign(n, 0);
+    ck.tag_count.assign(n, 0);
+    if ((int)ck.tags.size() < T) ck.tags.resize(T);
     std::vector<PlanStats> tst(T);
     std::vector<std::string> terr(T);
     pool.run([&](int t) {
         const int64_t lo = n * t / T, hi = n * (t + 1) / T;
         ProgBuf &prog = bufs[t];
         prog.size = 0;
+        std::vector<Tag> &tags = ck.tags[t];
+        tags.clear();
         for (int64_t i = lo; i < hi; ++i) {
             const int64_t b = b0 + i;
             ck.prog_off[i] = prog.size;
             ck.local_off[i] = prog.size;
             ck.thread_of[i] = t;
+            ck.tag_first[i] = (uint32_t)tags.size();
             if (skip && skip[b]) { prog.push(0); continue; }  // zero steps: result stays all-zero
             Request rq;
             rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
@@ -856,6 +955,7 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             PlanStats st;
             std::string e = plan_request(net, rq, prog, st);
             if (!e.empty()) { terr[t] = e; return; }
+            ck.tag_count[i] = tag_request(net, prog.data + ck.local_off[i], tags);
             ck.cost[i] = st.alg_bytes;
             ck.arena_need[i] = st.arena_cells;
             tst[t].alg_bytes += st.alg_bytes;
@@ -948,6 +1048,8 @@ int step_tile_h(const Network &net, const uint32_t *w) {
 
 void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<ProgBuf> &bufs, int64_t r0, int64_t r1,
                     Schedule &out) {
+    (void)net;
+    (void)bufs;
     const int64_t n = r1 - r0;
     out.items.clear();
     out.wg_item.clear();
@@ -959,58 +1061,41 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         top += (bp.arena_need[r0 + i] + 15) & ~int64_t(15);  // 128-byte aligned private arenas
     }
     out.arena_cells = top;
-    // pass 1: items tagged with (level, kid); bucket sizes
-    struct Tagged { Item it; int level, kid; double bytes; };
-    std::vector<Tagged> tagged;
-    tagged.reserve((size_t)n * 8);
+    // pass 1: bucket sizes per (level, class of work) from the tags the planning workers left behind
     int n_levels = 0;
+    size_t n_tags = 0, n_wg = 0;
     for (int64_t i = 0; i < n; ++i) {
         const int64_t r = r0 + i;
-        const uint32_t *prog = bufs[bp.thread_of[r]].data + bp.local_off[r];
-        const int n_steps = (int)prog[0];
-        uint32_t off = 1;
-        int level = 0;
-        int seg_first = -1, seg_steps = 0;
-        double seg_bytes = 0;
-        auto flush = [&]() {
-            if (seg_steps) {
-                tagged.push_back({{(uint32_t)i, (uint32_t)seg_first, (uint32_t)seg_steps | kItemSegment, 1u}, level, kKidSeg, seg_bytes});
-                ++level;
-                seg_steps = 0;
-                seg_bytes = 0;
-            }
-        };
-        for (int s = 0; s < n_steps; ++s) {
-            const uint32_t *w = prog + off;
-            const double bytes = (double)step_cost_bytes(w);
-            if (step_is_tiled(net, w)) {
-                flush();
-                const uint32_t th = (uint32_t)step_tile_h(net, w);
-                const uint32_t tiles = (w[3] + th - 1) / th;
-                tagged.push_back({{(uint32_t)i, off, th, tiles}, level, kernel_id_of_step(w), bytes});  // b = tile count for now
-                ++level;
-            } else {
-                if (!seg_steps) seg_first = (int)off;
-                ++seg_steps;
-                seg_bytes += bytes;
-            }
-            off += w[6];
-        }
-        flush();
-        n_levels = std::max(n_levels, level);
+        const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
+        const uint32_t cnt = bp.tag_count[r];
+        if (cnt) n_levels = std::max(n_levels, (int)tg[cnt - 1].level + 1);
+        n_tags += cnt;
     }
     out.n_levels = n_levels;
-    // pass 2: counting sort by (level, kid)
     const size_t nb = (size_t)n_levels * kNumKernels;
     std::vector<size_t> count(nb + 1, 0);
     std::vector<double> bytes(nb, 0.0);
-    for (auto &t : tagged) { ++count[(size_t)t.level * kNumKernels + t.kid + 1]; bytes[(size_t)t.level * kNumKernels + t.kid] += t.bytes; }
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = r0 + i;
+        const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
+        for (uint32_t k = 0; k < bp.tag_count[r]; ++k) {
+            const size_t bkt = (size_t)tg[k].level * kNumKernels + tg[k].kid;
+            ++count[bkt + 1];
+            bytes[bkt] += tg[k].bytes;
+            n_wg += tg[k].wgs;
+        }
+    }
     for (size_t k = 0; k < nb; ++k) count[k + 1] += count[k];
-    out.items.resize(tagged.size());
+    // pass 2: scatter (Item::b = workgroups of the item for now)
+    out.items.resize(n_tags);
     std::vector<size_t> cur(count.begin(), count.end() - 1);
-    for (auto &t : tagged) out.items[cur[(size_t)t.level * kNumKernels + t.kid]++] = t.it;
-    size_t n_wg = 0;
-    for (auto &t : tagged) n_wg += t.it.b;  // b = workgroups of the item for now
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = r0 + i;
+        const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
+        for (uint32_t k = 0; k < bp.tag_count[r]; ++k)
+            out.items[cur[(size_t)tg[k].level * kNumKernels + tg[k].kid]++] = Item{(uint32_t)i, tg[k].rel_off, tg[k].a, tg[k].wgs};
+    }
+    // pass 3: workgroup -> item table, level by level
     out.wg_item.resize(n_wg);
     size_t wg = 0, wg_level = 0;
     int cur_level = -1;

@@ -58,6 +58,7 @@ struct Network {
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
     int tile_h = 0;          // hi iterations per tile; 0 = sized for kTileBytes of traffic per tile
+    double minfill_above = 2e7;  // run the greedy min-fill order search only if the sweep orders cost more bytes than this
     int fuse = 1;            // eliminate two consecutive variables in one FIBER step when the first result would be a big table
 
     // returns "" or an error message
@@ -160,7 +161,17 @@ private:
 };
 
 // Plan requests [b0, b1) of a CSR batch: worker t plans a contiguous share into bufs[t].
+// One work item of a request, tagged while the request's program is still in the planning worker's cache.
+struct Tag {
+    uint32_t rel_off;  // word offset of the (first) step inside the request's program
+    uint32_t a;        // SEGMENT: number of steps | kItemSegment.  TILED step: hi iterations per tile
+    uint32_t wgs;      // workgroups: 1, or the number of tiles
+    uint16_t level, kid;
+    float bytes;       // algorithmic bytes
+};
 struct BatchPlan {
+    std::vector<std::vector<Tag>> tags;        // per worker: the items of its requests, request by request
+    std::vector<uint32_t> tag_first, tag_count;  // per request: its range in tags[thread_of[i]]
     std::vector<size_t> thread_words;          // words written by each worker (bufs[t].size)
     std::vector<uint64_t> prog_off;            // per request: word offset into the concatenated buffers
     std::vector<double> cost;                  // per request: algorithmic bytes

@@ -24,7 +24,7 @@ L.plan_sim_bench.restype = C.c_double
 p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
 hints = np.ascontiguousarray(np.stack(f.hints).reshape(-1), np.int32)
 for threads in [int(t) for t in (sys.argv[2:] or ["1", "8"])]:
-    stats = np.zeros(3)
+    stats = np.zeros(6)
     best = 1e30
     for _ in range(3):
         ms = L.plan_sim_bench(C.c_int32(len(f.card)), p(f.card, C.c_int32), p(f.scope_off, C.c_int64), p(f.scope_vars, C.c_int32),
@@ -33,4 +33,5 @@ for threads in [int(t) for t in (sys.argv[2:] or ["1", "8"])]:
                               C.c_int(threads), p(stats, C.c_double))
         best = min(best, ms)
     print(f"threads {threads:3d}: {best:8.1f} ms for {B} requests = {best*1e3/B:6.1f} us/request/thread-batch, {B/best*1e3:9.0f} req/s; "
-          f"steps {stats[1]:.0f} words/request {stats[2]/B:.0f} bytes/request {stats[0]/B/1e6:.1f} MB")
+          f"steps {stats[1]:.0f} words/request {stats[2]/B:.0f} bytes/request {stats[0]/B/1e6:.1f} MB; "
+          f"build_schedule (1 thread) {stats[3]:.1f} ms, {stats[4]:.0f} items, {stats[5]:.0f} workgroups")
