@@ -528,6 +528,123 @@ struct Emitter {
         return true;
     }
 
+    // OUTER encoding (see planner.h): two big inputs and nothing else, the product is a batched dense
+    // [cells of A] x [cx] x [16 cells only B spans] contraction for the fp64 MFMA.  Returns false when it does not fit.
+    bool emit_outer(const PF *const *ins, int n_in, const Strides &s, const XStrides &xs, const PF &out, int cx, int c1) {
+        if (n_in != 2 || !((cx == 4 && c1 == 4) || (cx == 16 && c1 == 4))) return false;
+        if (ins[0]->cells <= net.small_cells || ins[1]->cells <= net.small_cells) return false;
+        const int na = out.n;
+        // B = the input that owns two 4-state output axes the other one does not depend on (its N axes); of the two
+        // possible role assignments the feasible one with the faster N axes wins
+        int A = -1, B = -1, nax[2] = {-1, -1};
+        int64_t rcard[kRawAxes], rost[kRawAxes], rb[2][kRawAxes];
+        int nr = 0, nlo = 0, row_stride = 0;
+        int64_t lo = 1, rcells = 1;
+        int64_t best_key = std::numeric_limits<int64_t>::max();
+        for (int cand = 0; cand < 2; ++cand) {
+            const int b = cand, a_ = 1 - cand;
+            int found[2], nf = 0;
+            for (int ax = 0; ax < na && nf < 2; ++ax)
+                if (s[b][ax] != 0 && s[a_][ax] == 0 && net.card[out.vars[ax]] == 4) found[nf++] = ax;
+            if (nf < 2) continue;
+            const int64_t key = out.strides[found[0]] + out.strides[found[1]];
+            if (key >= best_key) continue;
+            // R axes: everything but the two N axes
+            int64_t c_card[kRawAxes], c_ost[kRawAxes], c_rb[2][kRawAxes];
+            int c_nr = 0;
+            for (int ax = 0; ax < na; ++ax) {
+                if (ax == found[0] || ax == found[1]) continue;
+                c_card[c_nr] = net.card[out.vars[ax]];
+                c_ost[c_nr] = out.strides[ax];
+                c_rb[0][c_nr] = s[a_][ax];
+                c_rb[1][c_nr] = s[b][ax];
+                ++c_nr;
+            }
+            int c_nlo = 0;
+            int64_t c_lo = 1;
+            while (c_nlo < c_nr && c_lo < kLoTarget && c_lo * c_card[c_nlo] <= kFiberLoMax) c_lo *= c_card[c_nlo++];
+            // row stride: B's dependence inside a wave's 64 cells (same rule as T's in emit_fiber)
+            int c_rs = 16, inside = 0;
+            bool ok = true;
+            int64_t cs = 1;
+            for (int i = 0; i < c_nlo; ++i) {
+                if (c_rb[1][i] != 0) {
+                    if (cs < 64) {
+                        ++inside;
+                        if (c_card[i] == 4 && (cs == 1 || cs == 4 || cs == 16)) c_rs = (int)cs;
+                        else ok = false;
+                    } else if (cs % 64 != 0) {
+                        ok = false;
+                    }
+                }
+                cs *= c_card[i];
+            }
+            if (inside > 1 || !ok) continue;
+            best_key = key;
+            A = a_; B = b; nax[0] = found[0]; nax[1] = found[1];
+            nr = c_nr; nlo = c_nlo; lo = c_lo; row_stride = c_rs;
+            rcells = 1;
+            for (int i = 0; i < c_nr; ++i) {
+                rcard[i] = c_card[i]; rost[i] = c_ost[i]; rb[0][i] = c_rb[0][i]; rb[1][i] = c_rb[1][i];
+                rcells *= c_card[i];
+            }
+        }
+        if (B < 0) return false;
+        const int big[2] = {A, B};
+        if (rcells * 16 < net.big_iters) return false;  // (an R cell is 16 output cells here)
+        uint32_t nout[16], nB[16];
+        bool contig = true;
+        for (int n = 0; n < 16; ++n) {
+            nout[n] = (uint32_t)((n & 3) * out.strides[nax[0]] + (n >> 2) * out.strides[nax[1]]);
+            nB[n] = (uint32_t)((n & 3) * s[B][nax[0]] + (n >> 2) * s[B][nax[1]]);
+            contig = contig && nout[n] == (uint32_t)n;
+        }
+        {
+            int64_t expect = 16;
+            for (int i = 0; i < nlo; ++i) { contig = contig && rost[i] == expect; expect *= rcard[i]; }
+        }
+        // merge adjacent R axes contiguous in the output and in both inputs
+        int64_t mc[kRawAxes], mo[kRawAxes], mb[2][kRawAxes];
+        int ma = 0, mlo = 0;
+        for (int i = 0; i < nr; ++i) {
+            bool merge = ma > 0 && i != nlo && mo[ma - 1] * mc[ma - 1] == rost[i] && mc[ma - 1] * rcard[i] < (1 << 30);
+            for (int b = 0; b < 2 && merge; ++b) merge = mb[b][ma - 1] * mc[ma - 1] == rb[b][i];
+            if (merge) {
+                mc[ma - 1] *= rcard[i];
+            } else {
+                mc[ma] = rcard[i];
+                mo[ma] = rost[i];
+                for (int b = 0; b < 2; ++b) mb[b][ma] = rb[b][i];
+                ++ma;
+                if (i < nlo) ++mlo;
+            }
+        }
+        if (ma > kMaxAxes) return false;
+        const int words = kHdrWords + 4 * 2 + 2 + 16 + 16 + 3 * ma + 2 * ma;
+        if (words > kMaxStepWords) return false;
+        uint32_t *w = prog.extend(words);
+        header(w, kKindFiber, 2, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
+        w[1] |= (kFlagOuter | (contig ? kFlagContig : 0u)) << 16;
+        w[1] |= (uint32_t)row_stride << kRowStrideShift;
+        w[7] = 2u | (0u << 4) | (2u << 8) | (0u << 12) | (16u << 16);
+        w[8] = 0u | ((uint32_t)c1 << 16);
+        uint32_t *p = w + kHdrWords;
+        for (int b = 0; b < 2; ++b) {
+            *p++ = (uint32_t)(ins[big[b]]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[big[b]]->off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[big[b]][0];
+            *p++ = (uint32_t)(int32_t)xs[big[b]][1];
+        }
+        *p++ = 4;  // tcard: the two N axes
+        *p++ = 4;
+        for (int n = 0; n < 16; ++n) *p++ = nout[n];
+        for (int n = 0; n < 16; ++n) *p++ = nB[n];
+        for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = 0u; }
+        for (int b = 0; b < 2; ++b)
+            for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)mb[b][a];
+        return true;
+    }
+
     // Emit one step: multiply `ins`, sum out the nx (0..2) variables X (nx = 0: product only); the new factor is
     // written to `out`.  fiber_only: emit nothing and return false unless the step fits the FIBER form (used to try
     // the joint elimination of two variables).
@@ -583,7 +700,7 @@ struct Emitter {
             out.alloc = cells;
         }
         const size_t step_base = prog.size;
-        const bool fiber = !final_ && emit_fiber(ins, n_in, s, xs, out, cx, c1);
+        const bool fiber = !final_ && ((net.outer && nx > 0 && emit_outer(ins, n_in, s, xs, out, cx, c1)) || emit_fiber(ins, n_in, s, xs, out, cx, c1));
         if (!fiber) {
             if (fiber_only) {
                 if (out.alloc) arena.release((int64_t)out.off, out.alloc);
@@ -991,11 +1108,11 @@ const char *kernel_name(int kid) {
     static bool init = false;
     if (!init) {
         names[kKidSeg] = "seg_kernel";
-        static const char *cxn[3] = {"cx4", "cx16", "cxN"}, *ncn[5] = {"nc1", "nc4", "nc16", "ncN", "nc16-mfma"};
+        static const char *cxn[3] = {"cx4", "cx16", "cxN"}, *ncn[6] = {"nc1", "nc4", "nc16", "ncN", "nc16-mfma", "outer-mfma"};
         for (int nb = 1; nb <= 2; ++nb)
             for (int c = 0; c < 3; ++c)
-                for (int n = 0; n < 5; ++n)
-                    names[kKidFiber0 + (nb - 1) * 15 + c * 5 + n] =
+                for (int n = 0; n < 6; ++n)
+                    names[kKidFiber0 + (nb - 1) * 18 + c * 6 + n] =
                         "fiber_tile_kernel<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
         for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic_tile_kernel<" + std::to_string(j + 1) + ">";
         init = true;
@@ -1013,6 +1130,7 @@ int fiber_cx_class(const uint32_t *w) {
 int fiber_nc_class(const uint32_t *w) {
     const int NC = (int)(w[7] >> 16);
     const bool contig = ((w[1] >> 16) & kFlagContig) != 0;
+    if ((w[1] >> 16) & kFlagOuter) return 5;
     if (NC == 1) return 0;
     if (NC == 4 && contig) return 1;
     if (NC == 16 && contig) return (((w[1] >> kRowStrideShift) & 0xff) && fiber_cx_class(w) < 2) ? 4 : 2;
@@ -1023,7 +1141,7 @@ int kernel_id_of_step(const uint32_t *w) {
     const uint32_t kind = w[0] & 0xff;
     if (kind == kKindFiber) {
         const int nb = w[7] & 0xf;
-        return kKidFiber0 + (nb - 1) * 15 + fiber_cx_class(w) * 5 + fiber_nc_class(w);
+        return kKidFiber0 + (nb - 1) * 18 + fiber_cx_class(w) * 6 + fiber_nc_class(w);
     }
     const int n_in = (w[0] >> 8) & 0xff;
     return kKidGeneric0 + std::min(std::max(n_in, 1), kMaxIn) - 1;

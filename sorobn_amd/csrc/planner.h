@@ -59,6 +59,7 @@ struct Network {
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
     int tile_h = 0;          // hi iterations per tile; 0 = sized for kTileBytes of traffic per tile
     double minfill_above = 2e7;  // run the greedy min-fill order search only if the sweep orders cost more bytes than this
+    int outer = 1;           // OUTER form (fp64 MFMA) for products of two big tables
     int fuse = 1;            // eliminate two consecutive variables in one FIBER step when the first result would be a big table
 
     // returns "" or an error message
@@ -113,11 +114,15 @@ struct PlanStats {
 //      bstride[b][a]              b < n_big, a < n_axes
 //      flag CONTIG: nout[n] == n and the lane-varying block is contiguous in the output (cell l of the block at
 //      l*NC), i.e. the lanes of a wave own one contiguous 64*NC-cell region (vector / transposed stores).
+//      flag OUTER (2 big inputs, no small ones): the second big input B takes the place of T.  The N axes are two
+//      4-state output axes only B depends on (NC = 16), the R axes are all the others, and
+//           out[r, n] = sum_x A[r, x] * B[r, n, x]        (B's offset: bstride[1][.] along R, nB[n] along N)
+//      - per 16-cell row block a dense [16 x cx] x [cx x 16] product.  After nout[] the step carries nB[n], n < 16.
 //      w1 bits 20..27 = row stride s of the fp64-MFMA form (0 = not applicable): the 64 cells of a wave split into
 //      4 row blocks of 16 cells that share one T[., ., ctrl] slice - block rb = cells (i % s) + s*rb + 4*s*(i / s),
 //      i < 16 - so that per block the step is a dense [16 x cx] x [cx x 16] product.  s = 16 when no ctrl axis lies
 //      inside a wave's 64 cells, s = 1 / 4 / 16 = the cell stride of the single 4-state ctrl axis that does.
-constexpr uint32_t kFlagFinal = 1, kFlagContig = 2;
+constexpr uint32_t kFlagFinal = 1, kFlagContig = 2, kFlagOuter = 4;
 constexpr int kRowStrideShift = 20;  // w1 bits 20..27
 constexpr int kHdrWords = 10;
 constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;
@@ -212,14 +217,15 @@ struct Launch {
     double alg_bytes;     // algorithmic bytes of the steps in this launch
 };
 constexpr int kKidSeg = 0;         // segments of small GENERIC steps
-constexpr int kKidFiber0 = 1;      // 30 FIBER tile classes: 1 + (n_big-1)*15 + cx_class*5 + nc_class
-constexpr int kKidGeneric0 = 31;   // 6 GENERIC tile classes: 31 + (n_in - 1)
-constexpr int kNumKernels = 37;
+constexpr int kKidFiber0 = 1;      // 36 FIBER tile classes: 1 + (n_big-1)*18 + cx_class*6 + nc_class
+constexpr int kKidGeneric0 = 37;   // 6 GENERIC tile classes: 37 + (n_in - 1)
+constexpr int kNumKernels = 43;
 const char *kernel_name(int kid);
 int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
 int fiber_cx_class(const uint32_t *w);     // 0: cx = 4   1: cx = 16 = 4 x 4   2: anything else (runtime loop)
 int fiber_nc_class(const uint32_t *w);     // 0: NC = 1   1: NC = 4 contiguous   2: NC = 16 contiguous   3: anything else
                                            // 4: NC = 16 contiguous, cx 4 or 16, row stride != 0 -> fp64 MFMA 16x16x4
+                                           // 5: OUTER form (always MFMA)
 int64_t step_cost_bytes(const uint32_t *w);
 bool step_is_tiled(const Network &net, const uint32_t *w);
 int step_tile_h(const Network &net, const uint32_t *w);

@@ -192,7 +192,7 @@ __device__ __forceinline__ void generic_dispatch(int n_in, const uint32_t *sw, i
 // Decoded layout of a FIBER step descriptor (LDS copy).
 struct FiberDesc {
     int na, nlo, cx, c1, lo_cells, ns, nN, nctrl, NC, T, nT, nb;
-    const uint32_t *bigs, *smalls, *tcard, *nout, *rax;
+    const uint32_t *bigs, *smalls, *tcard, *nout, *nB, *rax;
     const int *bst;
 };
 
@@ -219,6 +219,8 @@ __device__ __forceinline__ FiberDesc fiber_desc(const uint32_t *sw) {
     q += d.nT;
     d.nout = q;
     q += d.NC;
+    d.nB = q;  // OUTER only: offset of N-combination n in the second big input
+    if ((sw[1] >> 16) & kFlagOuter) q += d.NC;
     d.rax = q;  // (card, ostride, tstride) per R axis
     q += 3 * d.na;
     d.bst = (const int *)q;  // bst[b * na + a]
@@ -577,6 +579,67 @@ __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__re
     }
 }
 
+// OUTER class: out[r, n] = sum_x A[r, x] * B[r, n, x] with two big inputs (planner.h), as the same fp64 MFMA row-block
+// product as fiber_mfma_call - the B operand comes from the second table instead of T: lane l of row block rb
+// reads B[hi offset + row block's offset + nB[l & 15] + x(4*ks + (l >> 4))], mostly L2 hits (every B element feeds
+// all the cells of A that share its batch axes).  2 x 16 loads per 1024 outputs instead of 32 per 64.
+template <int KS>
+__device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
+                                                uint32_t *__restrict__ shX, const double *__restrict__ pool,
+                                                double *__restrict__ slot, const int tid, const int h_begin, const int h_end) {
+    const LaneOff lane_off = fiber_prologue(sw, shT, sh_hoff, pool, slot, tid, h_begin, h_end);
+    const FiberDesc d = fiber_desc(sw);
+    double *__restrict__ outp = slot + ((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+    const double *__restrict__ bigA = table_ptr(d.bigs[0], d.bigs[1], pool, slot);
+    const double *__restrict__ bigB = table_ptr(d.bigs[4], d.bigs[5], pool, slot);
+    const int axs1 = (int)d.bigs[2], axs2 = (int)d.bigs[3], bxs1 = (int)d.bigs[6], bxs2 = (int)d.bigs[7];
+    int *sh_cell = reinterpret_cast<int *>(shX);  // [3][kWG]: A offset, B offset, output offset of every lane cell
+    sh_cell[tid] = lane_off.b0;
+    sh_cell[kWG + tid] = lane_off.b1;
+    sh_cell[2 * kWG + tid] = lane_off.o;
+    __syncthreads();
+    const int nh = h_end - h_begin;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);
+    uint32_t la[4], lb[4];
+    int oc[4][4];       // output offset of accumulator element v of row block rb (-1: beyond the lane block)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);
+        la[rb] = (uint32_t)(sh_cell[c] + lk * axs1);
+        lb[rb] = (uint32_t)(sh_cell[kWG + wave * 64 + rs * rb] + (int)d.nB[lrow] + lk * bxs1);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = lk + 4 * v;
+            const int oc_cell = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+            oc[rb][v] = oc_cell < d.lo_cells ? sh_cell[2 * kWG + oc_cell] + (int)d.nout[lrow] : -1;
+        }
+    }
+    for (int hh = 0; hh < nh; ++hh) {
+        const int ho = uni(sh_hoff[0][hh]);
+        const double *__restrict__ a0 = bigA + uni(sh_hoff[2][hh]);
+        const double *__restrict__ b0 = bigB + uni(sh_hoff[3][hh]);
+        double a[4][KS], b[4][KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                a[rb][ks] = a0[la[rb] + (uint32_t)(ks * axs2)];
+                b[rb][ks] = b0[lb[rb] + (uint32_t)(ks * bxs2)];
+            }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][ks], b[rb][ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (oc[rb][v] >= 0) outp[ho + oc[rb][v]] = acc[v];
+        }
+    }
+}
+
 // posterior / posterior.sum()  (bayes_net.py:790); an all-zero table (zero-probability evidence) stays zero
 __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double *sh_red, int tid) {
     double s = 0.0;
@@ -592,13 +655,13 @@ __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double 
 }
 
 #define MIBN_FIBER_CASES(NB, C)                                                                        \
-    case (NB - 1) * 15 + C * 5 + 0: fiber_call<NB, C, 0>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
-    case (NB - 1) * 15 + C * 5 + 1: fiber_call<NB, C, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
-    case (NB - 1) * 15 + C * 5 + 2: fiber_call<NB, C, 2>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
-    case (NB - 1) * 15 + C * 5 + 3: fiber_call<NB, C, 3>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
+    case (NB - 1) * 18 + C * 6 + 0: fiber_call<NB, C, 0>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 18 + C * 6 + 1: fiber_call<NB, C, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 18 + C * 6 + 2: fiber_call<NB, C, 2>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 18 + C * 6 + 3: fiber_call<NB, C, 3>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
 #define MIBN_MFMA_CASES(NB)                                                                            \
-    case (NB - 1) * 15 + 0 * 5 + 4: fiber_mfma_call<NB, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
-    case (NB - 1) * 15 + 1 * 5 + 4: fiber_mfma_call<NB, 4>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
+    case (NB - 1) * 18 + 0 * 6 + 4: fiber_mfma_call<NB, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
+    case (NB - 1) * 18 + 1 * 6 + 4: fiber_mfma_call<NB, 4>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
 
 // One level of the schedule: workgroup b runs item wg_item[b] - a tile of a big step or a segment of small steps.
 __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const LevelArgs A) {
@@ -640,8 +703,9 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
         const bool contig = ((sh_step[1] >> 16) & kFlagContig) != 0;
         const int cxc = (cx == 4 && c1 == 4) ? 0 : ((cx == 16 && c1 == 4) ? 1 : 2);
         const bool mfma = ((sh_step[1] >> kRowStrideShift) & 0xff) != 0 && cxc < 2;
-        const int ncc = NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && contig) ? (mfma ? 4 : 2) : 3));
-        switch (((int)(sh_step[7] & 0xf) - 1) * 15 + cxc * 5 + ncc) {
+        const bool outer = ((sh_step[1] >> 16) & kFlagOuter) != 0;
+        const int ncc = outer ? 5 : (NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && contig) ? (mfma ? 4 : 2) : 3)));
+        switch (((int)(sh_step[7] & 0xf) - 1) * 18 + cxc * 6 + ncc) {
             MIBN_FIBER_CASES(1, 0)
             MIBN_FIBER_CASES(1, 1)
             MIBN_FIBER_CASES(1, 2)
@@ -650,6 +714,8 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
             MIBN_FIBER_CASES(2, 2)
             MIBN_MFMA_CASES(1)
             MIBN_MFMA_CASES(2)
+            case 18 + 0 * 6 + 5: outer_mfma_call<1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
+            case 18 + 1 * 6 + 5: outer_mfma_call<4>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
         }
     } else {
         generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);

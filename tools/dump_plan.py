@@ -37,7 +37,7 @@ def decode(w):
         w0 = int(w[p]); kind = w0 & 0xff; n_in = (w0 >> 8) & 0xff; na = (w0 >> 16) & 0xff; nlo = (w0 >> 24) & 0xff
         cx = int(w[p + 1]) & 0xffff; fin = (int(w[p + 1]) >> 16) & 1
         lo, hi, words = int(w[p + 2]), int(w[p + 3]), int(w[p + 6])
-        d = dict(kind="FIBER" if kind else "GENERIC", n_in=n_in, na=na, nlo=nlo, fin=fin, cx=cx, lo=lo, hi=hi,
+        d = dict(w1=int(w[p + 1]), kind="FIBER" if kind else "GENERIC", n_in=n_in, na=na, nlo=nlo, fin=fin, cx=cx, lo=lo, hi=hi,
                  bytes=32 * int(w[p + 9]), words=words)
         q = p + 10
         I = lambda k: int(np.int32(w[k]))
@@ -56,6 +56,9 @@ def decode(w):
                            [I(q + k * (4 + nT) + 4 + t) for t in range(nT)]) for k in range(ns)]; q += ns * (4 + nT)
             d["tcard"] = [int(x) for x in w[q:q + nT]]; q += nT
             d["nout"] = [int(x) for x in w[q:q + NC]]; q += NC
+            d["outer"] = (int(w[p + 1]) >> 18) & 1
+            if d["outer"]:
+                d["nB"] = [int(x) for x in w[q:q + NC]]; q += NC
             d["rax"] = [(int(w[q + 3 * a]), I(q + 3 * a + 1), I(q + 3 * a + 2)) for a in range(na)]; q += 3 * na
             d["bst"] = [[I(q + b * na + a) for a in range(na)] for b in range(nb)]
         steps.append(d)
@@ -79,5 +82,5 @@ if __name__ == "__main__":
         if s["kind"] == "GENERIC":
             print(head, f"n_in={s['n_in']} card={s['card']} ins={s['ins']} strides={s['strides']}", "FINAL" if s["fin"] else "")
         else:
-            print(head, f"nb={s['nb']} ns={s['ns']} c1={s['c1']} NC={s['NC']} contig={s['contig']} nctrl={s['nctrl']} T={s['T']} big={s['big']} small={[(t, x) for t, x, _ in s['small']]} "
+            print(head, f"nb={s['nb']} ns={s['ns']} c1={s['c1']} NC={s['NC']} contig={s['contig']} outer={s['outer']} rs={(s['w1'] >> 20) & 0xff} nctrl={s['nctrl']} T={s['T']} big={s['big']} small={[(t, x) for t, x, _ in s['small']]} "
                         f"tcard={s['tcard']} nout={s['nout']} rax(card,ost,tst)={s['rax']} bst={s['bst']}")
