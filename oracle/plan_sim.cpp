@@ -100,7 +100,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
     const uint32_t *nout = q; q += NC;
     const bool outer = ((p[1] >> 16) & kFlagOuter) != 0;
     const uint32_t *nB = q;  // OUTER: offset of N-combination n in the second big input
-    if (outer) { if (nb != 2 || ns != 0 || NC != 16 || T != 0) { g_err = "malformed OUTER step"; return -9; } q += NC; }
+    if (outer) { if (nb != 2 || NC != 16 || (ns == 0) != (T == 0)) { g_err = "malformed OUTER step"; return -9; } q += NC; }
     const uint32_t *rax = q; q += 3 * na;   // card, ostride, tstride per R axis
     const int32_t *bst = (const int32_t *)q;  // [b][a]
     if ((p[1] >> 16) & kFlagContig) {  // the kernel's vector / transposed stores rely on this
@@ -119,7 +119,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
         const int nlo_m = (p[0] >> 24) & 0xff;
         auto lo_t = [&](int64_t cell) {
             int64_t r = cell, to = 0;
-            for (int a = 0; a < nlo_m; ++a) { to += (r % rax[3 * a]) * (outer ? (int64_t)bst[na + a] : (int64_t)rax[3 * a + 2]); r /= rax[3 * a]; }
+            for (int a = 0; a < nlo_m; ++a) { to += (r % rax[3 * a]) * (outer ? (int64_t)bst[na + a] * 4096 + (int64_t)rax[3 * a + 2] : (int64_t)rax[3 * a + 2]); r /= rax[3 * a]; }
             return to;
         };
         for (int64_t w0 = 0; w0 < lo; w0 += 64)
@@ -161,7 +161,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
                 double f = 1.0;
                 for (int b = 0; b < nb; ++b)
                     f *= big[b][bo[b] + (outer && b == 1 ? (int64_t)nB[n] : 0) + (int64_t)(x % c1) * bxs1[b] + (int64_t)(x / c1) * bxs2[b]];
-                acc += outer ? f : f * Tt[(size_t)(to + (int64_t)x * NC + n)];
+                acc += T ? f * Tt[(size_t)(to + (int64_t)x * NC + n)] : f;
             }
             const int64_t o = oo + nout[n];
             if (o < 0 || o >= total_cells) { g_err = "fiber output offset out of range"; return -8; }

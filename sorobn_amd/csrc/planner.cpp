@@ -528,47 +528,67 @@ struct Emitter {
         return true;
     }
 
-    // OUTER encoding (see planner.h): two big inputs and nothing else, the product is a batched dense
+    // OUTER encoding (see planner.h): two big inputs (+ CPT slices), the product is a batched dense
     // [cells of A] x [cx] x [16 cells only B spans] contraction for the fp64 MFMA.  Returns false when it does not fit.
     bool emit_outer(const PF *const *ins, int n_in, const Strides &s, const XStrides &xs, const PF &out, int cx, int c1) {
-        if (n_in != 2 || !((cx == 4 && c1 == 4) || (cx == 16 && c1 == 4))) return false;
-        if (ins[0]->cells <= net.small_cells || ins[1]->cells <= net.small_cells) return false;
+        if (!((cx == 4 && c1 == 4) || (cx == 16 && c1 == 4))) return false;
+        int bigs[kMaxIn], small[kMaxIn], nbig = 0, ns = 0;
+        for (int j = 0; j < n_in; ++j) {
+            if (ins[j]->cells > net.small_cells) bigs[nbig++] = j;
+            else small[ns++] = j;
+        }
+        if (nbig != 2 || ns > kMaxSmall) return false;
         const int na = out.n;
-        // B = the input that owns two 4-state output axes the other one does not depend on (its N axes); of the two
-        // possible role assignments the feasible one with the faster N axes wins
+        // B = the big input that owns two 4-state output axes the other one does not depend on (its N axes); of the
+        // two possible role assignments the feasible one with the faster N axes wins
         int A = -1, B = -1, nax[2] = {-1, -1};
-        int64_t rcard[kRawAxes], rost[kRawAxes], rb[2][kRawAxes];
-        int nr = 0, nlo = 0, row_stride = 0;
-        int64_t lo = 1, rcells = 1;
+        int64_t rcard[kRawAxes], rost[kRawAxes], rtst[kRawAxes], rb[2][kRawAxes];
+        int raxis[kRawAxes], ctrl[kRawAxes];
+        int nr = 0, nlo = 0, row_stride = 0, nctrl = 0;
+        int64_t lo = 1, rcells = 1, T = 0;
         int64_t best_key = std::numeric_limits<int64_t>::max();
         for (int cand = 0; cand < 2; ++cand) {
-            const int b = cand, a_ = 1 - cand;
+            const int b = bigs[cand], a_ = bigs[1 - cand];
             int found[2], nf = 0;
             for (int ax = 0; ax < na && nf < 2; ++ax)
                 if (s[b][ax] != 0 && s[a_][ax] == 0 && net.card[out.vars[ax]] == 4) found[nf++] = ax;
             if (nf < 2) continue;
             const int64_t key = out.strides[found[0]] + out.strides[found[1]];
             if (key >= best_key) continue;
-            // R axes: everything but the two N axes
-            int64_t c_card[kRawAxes], c_ost[kRawAxes], c_rb[2][kRawAxes];
-            int c_nr = 0;
-            for (int ax = 0; ax < na; ++ax) {
+            // R axes: everything but the two N axes; ctrl axes = R axes a small input depends on
+            int64_t c_card[kRawAxes], c_ost[kRawAxes], c_tst[kRawAxes], c_rb[2][kRawAxes];
+            int c_axis[kRawAxes], c_ctrl[kRawAxes];
+            int c_nr = 0, c_nctrl = 0;
+            int64_t c_T = ns ? 16 * (int64_t)cx : 0;
+            bool ok = true;
+            for (int ax = 0; ax < na && ok; ++ax) {
                 if (ax == found[0] || ax == found[1]) continue;
+                c_axis[c_nr] = ax;
                 c_card[c_nr] = net.card[out.vars[ax]];
                 c_ost[c_nr] = out.strides[ax];
                 c_rb[0][c_nr] = s[a_][ax];
                 c_rb[1][c_nr] = s[b][ax];
+                bool dep = false;
+                for (int k = 0; k < ns; ++k) dep = dep || s[small[k]][ax] != 0;
+                c_tst[c_nr] = 0;
+                if (dep) {
+                    if (c_nctrl >= 13) ok = false;
+                    c_ctrl[c_nctrl++] = ax;
+                    c_tst[c_nr] = c_T;
+                    c_T *= c_card[c_nr];
+                    if (c_T > kMaxT) ok = false;
+                }
                 ++c_nr;
             }
+            if (!ok) continue;
             int c_nlo = 0;
             int64_t c_lo = 1;
             while (c_nlo < c_nr && c_lo < kLoTarget && c_lo * c_card[c_nlo] <= kFiberLoMax) c_lo *= c_card[c_nlo++];
-            // row stride: B's dependence inside a wave's 64 cells (same rule as T's in emit_fiber)
+            // row stride: what the B operand (B and T) depends on inside a wave's 64 cells (same rule as emit_fiber)
             int c_rs = 16, inside = 0;
-            bool ok = true;
             int64_t cs = 1;
             for (int i = 0; i < c_nlo; ++i) {
-                if (c_rb[1][i] != 0) {
+                if (c_rb[1][i] != 0 || c_tst[i] != 0) {
                     if (cs < 64) {
                         ++inside;
                         if (c_card[i] == 4 && (cs == 1 || cs == 4 || cs == 16)) c_rs = (int)cs;
@@ -582,14 +602,17 @@ struct Emitter {
             if (inside > 1 || !ok) continue;
             best_key = key;
             A = a_; B = b; nax[0] = found[0]; nax[1] = found[1];
-            nr = c_nr; nlo = c_nlo; lo = c_lo; row_stride = c_rs;
+            nr = c_nr; nlo = c_nlo; lo = c_lo; row_stride = c_rs; nctrl = c_nctrl; T = c_T;
             rcells = 1;
             for (int i = 0; i < c_nr; ++i) {
-                rcard[i] = c_card[i]; rost[i] = c_ost[i]; rb[0][i] = c_rb[0][i]; rb[1][i] = c_rb[1][i];
+                raxis[i] = c_axis[i]; rcard[i] = c_card[i]; rost[i] = c_ost[i]; rtst[i] = c_tst[i];
+                rb[0][i] = c_rb[0][i]; rb[1][i] = c_rb[1][i];
                 rcells *= c_card[i];
             }
+            for (int i = 0; i < c_nctrl; ++i) ctrl[i] = c_ctrl[i];
         }
         if (B < 0) return false;
+        (void)raxis;
         const int big[2] = {A, B};
         if (rcells * 16 < net.big_iters) return false;  // (an R cell is 16 output cells here)
         uint32_t nout[16], nB[16];
@@ -603,31 +626,34 @@ struct Emitter {
             int64_t expect = 16;
             for (int i = 0; i < nlo; ++i) { contig = contig && rost[i] == expect; expect *= rcard[i]; }
         }
-        // merge adjacent R axes contiguous in the output and in both inputs
-        int64_t mc[kRawAxes], mo[kRawAxes], mb[2][kRawAxes];
+        // merge adjacent R axes contiguous in the output, in T and in both inputs
+        int64_t mc[kRawAxes], mo[kRawAxes], mt[kRawAxes], mb[2][kRawAxes];
         int ma = 0, mlo = 0;
         for (int i = 0; i < nr; ++i) {
-            bool merge = ma > 0 && i != nlo && mo[ma - 1] * mc[ma - 1] == rost[i] && mc[ma - 1] * rcard[i] < (1 << 30);
+            bool merge = ma > 0 && i != nlo && mo[ma - 1] * mc[ma - 1] == rost[i] && mt[ma - 1] * mc[ma - 1] == rtst[i] &&
+                         mc[ma - 1] * rcard[i] < (1 << 30);
             for (int b = 0; b < 2 && merge; ++b) merge = mb[b][ma - 1] * mc[ma - 1] == rb[b][i];
             if (merge) {
                 mc[ma - 1] *= rcard[i];
             } else {
                 mc[ma] = rcard[i];
                 mo[ma] = rost[i];
+                mt[ma] = rtst[i];
                 for (int b = 0; b < 2; ++b) mb[b][ma] = rb[b][i];
                 ++ma;
                 if (i < nlo) ++mlo;
             }
         }
         if (ma > kMaxAxes) return false;
-        const int words = kHdrWords + 4 * 2 + 2 + 16 + 16 + 3 * ma + 2 * ma;
+        const int nT = 2 + nctrl;
+        const int words = kHdrWords + 4 * 2 + ns * (4 + nT) + nT + 16 + 16 + 3 * ma + 2 * ma;
         if (words > kMaxStepWords) return false;
         uint32_t *w = prog.extend(words);
-        header(w, kKindFiber, 2, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
+        header(w, kKindFiber, 2 + ns, ma, mlo, cx, false, lo, rcells / lo, out.off, words);
         w[1] |= (kFlagOuter | (contig ? kFlagContig : 0u)) << 16;
         w[1] |= (uint32_t)row_stride << kRowStrideShift;
-        w[7] = 2u | (0u << 4) | (2u << 8) | (0u << 12) | (16u << 16);
-        w[8] = 0u | ((uint32_t)c1 << 16);
+        w[7] = 2u | ((uint32_t)ns << 4) | (2u << 8) | ((uint32_t)nctrl << 12) | (16u << 16);
+        w[8] = (uint32_t)T | ((uint32_t)c1 << 16);
         uint32_t *p = w + kHdrWords;
         for (int b = 0; b < 2; ++b) {
             *p++ = (uint32_t)(ins[big[b]]->off & 0xffffffffu);
@@ -635,11 +661,22 @@ struct Emitter {
             *p++ = (uint32_t)(int32_t)xs[big[b]][0];
             *p++ = (uint32_t)(int32_t)xs[big[b]][1];
         }
-        *p++ = 4;  // tcard: the two N axes
+        for (int k = 0; k < ns; ++k) {
+            const int j = small[k];
+            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j]->off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[j][0];
+            *p++ = (uint32_t)(int32_t)xs[j][1];
+            *p++ = (uint32_t)(int32_t)s[j][nax[0]];
+            *p++ = (uint32_t)(int32_t)s[j][nax[1]];
+            for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)(int32_t)s[j][ctrl[i]];
+        }
+        *p++ = 4;  // tcard: the two N axes, then the ctrl axes
         *p++ = 4;
+        for (int i = 0; i < nctrl; ++i) *p++ = (uint32_t)net.card[out.vars[ctrl[i]]];
         for (int n = 0; n < 16; ++n) *p++ = nout[n];
         for (int n = 0; n < 16; ++n) *p++ = nB[n];
-        for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = 0u; }
+        for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = (uint32_t)mt[a]; }
         for (int b = 0; b < 2; ++b)
             for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)mb[b][a];
         return true;
@@ -1133,7 +1170,8 @@ int fiber_nc_class(const uint32_t *w) {
     if ((w[1] >> 16) & kFlagOuter) return 5;
     if (NC == 1) return 0;
     if (NC == 4 && contig) return 1;
-    if (NC == 16 && contig) return (((w[1] >> kRowStrideShift) & 0xff) && fiber_cx_class(w) < 2) ? 4 : 2;
+    if (NC == 16 && ((w[1] >> kRowStrideShift) & 0xff) && fiber_cx_class(w) < 2) return 4;
+    if (NC == 16 && contig) return 2;
     return 3;
 }
 

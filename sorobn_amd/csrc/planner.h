@@ -224,7 +224,7 @@ const char *kernel_name(int kid);
 int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
 int fiber_cx_class(const uint32_t *w);     // 0: cx = 4   1: cx = 16 = 4 x 4   2: anything else (runtime loop)
 int fiber_nc_class(const uint32_t *w);     // 0: NC = 1   1: NC = 4 contiguous   2: NC = 16 contiguous   3: anything else
-                                           // 4: NC = 16 contiguous, cx 4 or 16, row stride != 0 -> fp64 MFMA 16x16x4
+                                           // 4: NC = 16, cx 4 or 16, row stride != 0 -> fp64 MFMA 16x16x4
                                            // 5: OUTER form (always MFMA)
 int64_t step_cost_bytes(const uint32_t *w);
 bool step_is_tiled(const Network &net, const uint32_t *w);

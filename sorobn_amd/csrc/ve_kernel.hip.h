@@ -506,17 +506,18 @@ __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__re
         bxs2[b] = (int)d.bigs[4 * b + 3];
     }
     // every lane needs the offsets of the 4 cells (one per row block) it feeds: exchange them through LDS
-    int *sh_cell = reinterpret_cast<int *>(shX);  // [3][kWG]: big input 0, big input 1, T
+    int *sh_cell = reinterpret_cast<int *>(shX);  // [4][kWG]: big input 0, big input 1, T, output
     sh_cell[tid] = lane_off.b0;
     sh_cell[kWG + tid] = lane_off.b1;
     sh_cell[2 * kWG + tid] = lane_off.t;
+    sh_cell[3 * kWG + tid] = lane_off.o;
     __syncthreads();
     const int nh = h_end - h_begin;
     const int wave = tid >> 6, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
     const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);  // 1, 4 or 16
     uint32_t la[NBIG][4];
-    int tb[4], ocell[4][4];  // T offset of row block rb; cell of accumulator element v of row block rb
+    int tb[4], oc[4][4];  // T offset of row block rb; output offset of accumulator element v of row block rb (-1: none)
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);  // the cell this lane loads for block rb
@@ -526,10 +527,11 @@ __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__re
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = lk + 4 * v;
-            ocell[rb][v] = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+            const int cell = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+            // (contiguous steps: cell*16 + lrow, i.e. 512 contiguous bytes per store instruction for rs >= 4)
+            oc[rb][v] = cell < d.lo_cells ? sh_cell[3 * kWG + cell] + (int)d.nout[lrow] : -1;
         }
     }
-    double *__restrict__ olane = outp + lrow;
 
     auto issue = [&](const int hh, double (&dst)[4][KS]) {
 #pragma unroll
@@ -556,7 +558,7 @@ __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__re
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][ks], shT[ht + tb[rb] + lrow + 16 * (4 * ks + lk)], acc, 0, 0, 0);
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (ocell[rb][v] < d.lo_cells) olane[ho + ocell[rb][v] * 16] = acc[v];
+                if (oc[rb][v] >= 0) outp[ho + oc[rb][v]] = acc[v];
         }
     };
     if (NBIG == 1 && MIBN_PIPELINE) {
@@ -593,22 +595,26 @@ __device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__re
     const double *__restrict__ bigA = table_ptr(d.bigs[0], d.bigs[1], pool, slot);
     const double *__restrict__ bigB = table_ptr(d.bigs[4], d.bigs[5], pool, slot);
     const int axs1 = (int)d.bigs[2], axs2 = (int)d.bigs[3], bxs1 = (int)d.bigs[6], bxs2 = (int)d.bigs[7];
-    int *sh_cell = reinterpret_cast<int *>(shX);  // [3][kWG]: A offset, B offset, output offset of every lane cell
+    int *sh_cell = reinterpret_cast<int *>(shX);  // [4][kWG]: A offset, B offset, output offset, T offset of every lane cell
     sh_cell[tid] = lane_off.b0;
     sh_cell[kWG + tid] = lane_off.b1;
     sh_cell[2 * kWG + tid] = lane_off.o;
+    sh_cell[3 * kWG + tid] = lane_off.t;
     __syncthreads();
+    const bool has_t = d.T > 0;  // CPT slices among the inputs: their product T[n, x, ctrl] scales the B operand
     const int nh = h_end - h_begin;
     const int wave = tid >> 6, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
     const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);
     uint32_t la[4], lb[4];
+    int tb[4];          // T offset of row block rb
     int oc[4][4];       // output offset of accumulator element v of row block rb (-1: beyond the lane block)
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);
         la[rb] = (uint32_t)(sh_cell[c] + lk * axs1);
         lb[rb] = (uint32_t)(sh_cell[kWG + wave * 64 + rs * rb] + (int)d.nB[lrow] + lk * bxs1);
+        tb[rb] = sh_cell[3 * kWG + wave * 64 + rs * rb] + lrow + 16 * lk;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = lk + 4 * v;
@@ -628,6 +634,13 @@ __device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__re
                 a[rb][ks] = a0[la[rb] + (uint32_t)(ks * axs2)];
                 b[rb][ks] = b0[lb[rb] + (uint32_t)(ks * bxs2)];
             }
+        if (has_t) {
+            const int ht = uni(sh_hoff[1][hh]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) b[rb][ks] *= shT[ht + tb[rb] + 64 * ks];
+        }
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -704,7 +717,7 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
         const int cxc = (cx == 4 && c1 == 4) ? 0 : ((cx == 16 && c1 == 4) ? 1 : 2);
         const bool mfma = ((sh_step[1] >> kRowStrideShift) & 0xff) != 0 && cxc < 2;
         const bool outer = ((sh_step[1] >> 16) & kFlagOuter) != 0;
-        const int ncc = outer ? 5 : (NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && contig) ? (mfma ? 4 : 2) : 3)));
+        const int ncc = outer ? 5 : (NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && mfma) ? 4 : ((NC == 16 && contig) ? 2 : 3))));
         switch (((int)(sh_step[7] & 0xf) - 1) * 18 + cxc * 6 + ncc) {
             MIBN_FIBER_CASES(1, 0)
             MIBN_FIBER_CASES(1, 1)
