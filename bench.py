@@ -30,9 +30,25 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# HBM bytes per launch from the rocprofv3 PMC passes (profiles/): not measurable inside this process,
-# so the bench reports null; the committed profile summary holds the measured value.
-TRAFFIC_NOTE = None
+# HBM bytes per launch come from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE / WRITE_SIZE
+# runs, corrected as MI355X_MICROARCH.md prescribes): they cannot be collected inside this process, so the bench
+# reports the figure of the newest committed pass (profiles/r*_pmc.json) together with its provenance, or null.
+
+
+def pmc_traffic(kernel):
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel") == kernel:
+            best = (f, d)
+    if not best:
+        return None, None
+    f, d = best
+    return d["traffic_bytes_per_launch"], {"file": os.path.relpath(f, ROOT), "alg_bytes_per_launch_same_run": d.get("alg_bytes_per_launch_same_run")}
 
 
 def cpu_baseline(spec, qv, ev, ec, gpu_post, budget_s, max_rows=3e7):
@@ -200,7 +216,7 @@ def main():
             lo = first_lo
             cb, err = cpu_baseline(spec, qv[lo:lo + a.batch], ev[lo:lo + a.batch], ec[lo:lo + a.batch],
                                    first_post, a.cpu_seconds)
-            out["roofline"]["traffic"] = TRAFFIC_NOTE
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(dom)
             out["cpu_baseline"] = cb
             out["max_abs_marginal_err_vs_oracle"] = err
         print(json.dumps(out), flush=True)
