@@ -120,7 +120,10 @@ int mibn_plan_stats(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e,
                     const int32_t *e_vars, mibn_stats *out);
 int mibn_create_planner(mibn_t **out); /* host-only context: set_network/plan_stats work, queries fail */
 
-/* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "wg_per_cu". */
+/* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "chunk" (requests per planning /
+ * launch chunk).  Test and profiling hooks: "small_cells", "big_iters", "tile_h", "fuse", "outer" (force the
+ * kernels' step forms onto small networks), "split_kinds" (one launch per class of work and level, so that
+ * mibn_last_kernel_stats reports per-class rates), "trace" (one stderr line per launch). */
 int mibn_set_option(mibn_t *h, const char *name, double value);
 
 /*
