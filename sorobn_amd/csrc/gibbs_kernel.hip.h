@@ -4,8 +4,13 @@
 //     P(v | mb(v))  ~  P(v | pa(v)) * prod_{c in children(v)} P(c | pa(c))      (bayes_net.py:700-710)
 // is evaluated on the fly from the dense CPTs (L1/L2 resident) instead of materialising the
 // reference's per-node posterior tables (8^7 rows = 16 MiB per interior node in config 5).
-// Chain state lives in LDS as state[var][lane] bytes.  Random numbers: Philox4x32-10 keyed by
-// (seed, chain), counter = update index; statistical parity only (see include/mibn.h).
+// Chain state lives in LDS as state[var][lane] bytes.  Every cycle position has a precompiled *update program*
+// (wave-uniform words -> scalar loads): the factors mentioning the variable (its CPT and its children's), for each
+// the table offset, the variable's stride and the (other variable, stride) pairs.  An update computes each
+// factor's base offset once from the chain state and then the card x n_factors table values as independent
+// loads, the weights stay in registers (cards up to 16; larger cards take a two-pass loop).  The kernel is
+// latency-bound by construction (config 5 = 128 chains = 2 waves per GPU).  Random numbers: Philox4x32-10 keyed
+// by (seed, chain), counter = update index; statistical parity only (see include/mibn.h).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -49,6 +54,8 @@ struct GibbsArgs {
     const int32_t *scope_stride;
     const int32_t *children;      // flattened children lists
     const int32_t *cycle;         // update order (non-evidence variables)
+    const int32_t *uprog;         // update programs: card, n_factors, {table_off, stride of v, n_other, {var, stride}*}*
+    const int32_t *uprog_off;     // word offset of cycle position i's program
     const int32_t *qvars;
     const int32_t *qstride;       // stride of each query variable in the joint histogram
     unsigned long long *counts;   // global histogram
@@ -115,23 +122,60 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
     __syncthreads();
 
     int cyc = 0;
+    constexpr int kRegCard = 16;
     for (int64_t it = 0; it < A.n_iterations; ++it) {
         const int v = A.cycle[cyc];
+        const int32_t *up = A.uprog + A.uprog_off[cyc];
         cyc = cyc + 1 == A.n_cycle ? 0 : cyc + 1;
-        const GibbsVar V = A.vars[v];
-        double total = 0;
-        for (int x = 0; x < V.card; ++x) total += gibbs_weight(A, V, v, x, st, lane);
-        if (total > 0) {
-            const double u = philox_uniform((uint64_t)it, 0u, k0, k1) * total;
-            double acc = 0;
-            int val = -1, last = 0;
-            for (int x = 0; x < V.card; ++x) {
-                const double w = gibbs_weight(A, V, v, x, st, lane);
-                if (w > 0) last = x;
-                acc += w;
-                if (val < 0 && u < acc) val = x;
+        const int card = up[0], nf = up[1];
+        up += 2;
+        if (card <= kRegCard) {
+            double w[kRegCard];
+#pragma unroll
+            for (int x = 0; x < kRegCard; ++x) w[x] = 1.0;
+            for (int f = 0; f < nf; ++f) {
+                const int sv = up[1], no = up[2];
+                int base = up[0];
+                for (int k = 0; k < no; ++k) base += (int)st[up[3 + 2 * k] * 64 + lane] * up[4 + 2 * k];
+                up += 3 + 2 * no;
+                const double *__restrict__ tp = A.pool + base;
+#pragma unroll
+                for (int x = 0; x < kRegCard; ++x)
+                    if (x < card) w[x] *= tp[x * sv];
             }
-            st[v * 64 + lane] = (uint8_t)(val < 0 ? last : val);
+            double total = 0;
+#pragma unroll
+            for (int x = 0; x < kRegCard; ++x)
+                if (x < card) total += w[x];
+            if (total > 0) {
+                const double u = philox_uniform((uint64_t)it, 0u, k0, k1) * total;
+                double acc = 0;
+                int val = -1, last = 0;
+#pragma unroll
+                for (int x = 0; x < kRegCard; ++x)
+                    if (x < card) {
+                        if (w[x] > 0) last = x;
+                        acc += w[x];
+                        if (val < 0 && u < acc) val = x;
+                    }
+                st[v * 64 + lane] = (uint8_t)(val < 0 ? last : val);
+            }
+        } else {
+            const GibbsVar V = A.vars[v];
+            double total = 0;
+            for (int x = 0; x < V.card; ++x) total += gibbs_weight(A, V, v, x, st, lane);
+            if (total > 0) {
+                const double u = philox_uniform((uint64_t)it, 0u, k0, k1) * total;
+                double acc = 0;
+                int val = -1, last = 0;
+                for (int x = 0; x < V.card; ++x) {
+                    const double w = gibbs_weight(A, V, v, x, st, lane);
+                    if (w > 0) last = x;
+                    acc += w;
+                    if (val < 0 && u < acc) val = x;
+                }
+                st[v * 64 + lane] = (uint8_t)(val < 0 ? last : val);
+            }
         }
         // record the joint query state (bayes_net.py:732-733: every iteration, no burn-in)
         if (active) {
@@ -199,6 +243,28 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
             if (!vars[v].is_evidence) cycle.push_back(v);
     }
     if (cycle.empty()) { err = "gibbs: every variable is evidence"; return MIBN_E_ARG; }
+    // update programs, one per cycle position
+    std::vector<int32_t> uprog, uprog_off;
+    for (int v : cycle) {
+        uprog_off.push_back((int32_t)uprog.size());
+        uprog.push_back(net.card[v]);
+        uprog.push_back(1 + (int32_t)ch[v].size());
+        auto factor = [&](int c) {  // CPT of c as a function of v's value
+            int32_t sv = 0;
+            std::vector<int32_t> others;
+            for (size_t k = 0; k < net.scope[c].size(); ++k) {
+                const int u = net.scope[c][k];
+                if (u == v) sv = (int32_t)net.cstride[c][k];
+                else { others.push_back(u); others.push_back((int32_t)net.cstride[c][k]); }
+            }
+            uprog.push_back((int32_t)net.pool_off[c]);
+            uprog.push_back(sv);
+            uprog.push_back((int32_t)(others.size() / 2));
+            uprog.insert(uprog.end(), others.begin(), others.end());
+        };
+        factor(v);
+        for (int c : ch[v]) factor(c);
+    }
     std::vector<int32_t> qstride(n_q);
     int64_t cells = 1;
     for (int i = n_q - 1; i >= 0; --i) { qstride[i] = (int32_t)cells; cells *= net.card[q_vars[i]]; }
@@ -212,6 +278,7 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     auto put = [&](const std::vector<int32_t> &a) { size_t o = pack.size(); pack.insert(pack.end(), a.begin(), a.end()); return o; };
     const size_t o_sv = put(scope_var), o_ss = put(scope_stride), o_ch = put(children), o_cy = put(cycle);
     const size_t o_q = put(std::vector<int32_t>(q_vars, q_vars + n_q)), o_qs = put(qstride);
+    const size_t o_up = put(uprog), o_uo = put(uprog_off);
     auto fail = [&](hipError_t e) { err = std::string("gibbs: ") + hipGetErrorString(e); hipFree(d_vars); hipFree(d_i32); hipFree(d_counts); return MIBN_E_HIP; };
     hipError_t e;
     if ((e = hipMalloc(&d_vars, sizeof(GibbsVar) * n)) != hipSuccess) return fail(e);
@@ -227,6 +294,8 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     A.scope_stride = d_i32 + o_ss;
     A.children = d_i32 + o_ch;
     A.cycle = d_i32 + o_cy;
+    A.uprog = d_i32 + o_up;
+    A.uprog_off = d_i32 + o_uo;
     A.qvars = d_i32 + o_q;
     A.qstride = d_i32 + o_qs;
     A.counts = d_counts;

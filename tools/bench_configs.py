@@ -1,0 +1,75 @@
+"""Supplementary measurements of the other BASELINE.json configurations (GPU box): C2 = Asia, 100k exact queries in one
+batch; C5 = 50-node K=8 grid, algorithm='gibbs', 100k single-site updates x 128 chains (one GPU's share of 1024).
+The bench line proper (bench.py) is C3."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import golden_util as gu  # noqa: E402
+import netspec  # noqa: E402
+import sorobn_amd  # noqa: E402
+
+out = {}
+
+# ---- C2: Asia, requests per SURVEY 8(d): query var uniform over the 8 nodes, 1-3 evidence nodes, values uniform
+spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "asia")["spec"]
+bn = netspec.build(spec, sorobn_amd.BayesNet)
+be = bn.backend
+eng = be.engine
+n = len(be.flat.card)
+rng = np.random.default_rng(0)
+B = 100_000
+q_off = np.arange(B + 1, dtype=np.int64)
+q_vars = rng.integers(0, n, B).astype(np.int32)
+ne = rng.integers(1, 4, B)
+e_off = np.concatenate([[0], np.cumsum(ne)]).astype(np.int64)
+e_vars = np.empty(e_off[-1], np.int32)
+for b in range(B):
+    others = np.delete(np.arange(n), q_vars[b])
+    e_vars[e_off[b]:e_off[b + 1]] = rng.choice(others, ne[b], replace=False)
+e_codes = rng.integers(0, 2, e_off[-1]).astype(np.int32)
+for _ in range(2):
+    t0 = time.perf_counter()
+    post, off = eng.query_batch(q_off, q_vars, e_off, e_vars, e_codes)
+    dt = time.perf_counter() - t0
+s = eng.stats()
+sums = np.add.reduceat(post, off[:-1])
+out["C2_asia_100k"] = {"queries_per_s": B / dt, "wall_ms": dt * 1e3, "kernel_ms": s["kernel_ms"], "plan_ms": s["plan_ms"],
+                       "launches": s["n_launches"], "zero_probability_evidence": int((sums == 0).sum()),
+                       "note": "36 CPT numbers: LDS/L2 resident, launch- and host-bound, HBM roofline n/a"}
+# single-query latency through the reference-shaped API (config C1 shape)
+alarm = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "alarm")["spec"]
+bna = netspec.build(alarm, sorobn_amd.BayesNet)
+bna.query("Burglary", event={"Mary calls": True, "John calls": True})
+t0 = time.perf_counter()
+for _ in range(200):
+    ans = bna.query("Burglary", event={"Mary calls": True, "John calls": True})
+out["C1_alarm_single_query"] = {"ms_per_query": (time.perf_counter() - t0) / 200 * 1e3, "answer": ans.to_numpy().tolist()}
+
+# ---- C5: Gibbs
+spec5 = netspec.grid_spec(5, 10, 8, seed=0)
+bn5 = netspec.build(spec5, sorobn_amd.BayesNet)
+rng = np.random.default_rng(1)
+ev = {f"{k:03d}": int(rng.integers(0, 8)) for k in (0, 9, 40, 49, 22)}
+exact = bn5.query("025", event=ev)
+chains, iters = 128, 100_000
+bn5.query("025", event=ev, algorithm="gibbs", n_iterations=1000, n_chains=chains)
+t0 = time.perf_counter()
+got = bn5.query("025", event=ev, algorithm="gibbs", n_iterations=iters, n_chains=chains)
+dt = time.perf_counter() - t0
+out["C5_gibbs_128_chains_100k"] = {"wall_ms": dt * 1e3, "updates_per_s": chains * iters / dt,
+                                   "max_abs_err_vs_exact": float(np.max(np.abs(got.to_numpy() - exact.to_numpy()))),
+                                   "note": "one GPU's share (128 of 1024 chains); latency/LDS-bound, HBM roofline n/a"}
+for chains in (1024, 8192):
+    t0 = time.perf_counter()
+    got = bn5.query("025", event=ev, algorithm="gibbs", n_iterations=iters, n_chains=chains)
+    dt = time.perf_counter() - t0
+    out[f"C5_gibbs_{chains}_chains_100k"] = {"wall_ms": dt * 1e3, "updates_per_s": chains * iters / dt,
+                                             "max_abs_err_vs_exact": float(np.max(np.abs(got.to_numpy() - exact.to_numpy())))}
+print(json.dumps(out, indent=1))
