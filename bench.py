@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--n-evidence", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--threads", type=int, default=0, help="planner threads of this rank (0 = host threads / ranks on the node)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,6 +124,8 @@ def main():
     bn = netspec.build(spec, sorobn_amd.BayesNet).use_device(local_rank)
     be = bn.backend  # flatten + upload: network resident in HBM from here on
     eng = be.engine
+    if a.threads:
+        eng.set_option("threads", a.threads)
 
     total_steps = a.warmup + a.steps
     n_req = total_steps * world * a.batch

@@ -233,7 +233,7 @@ template <class T>
 int ensure(mibn_ctx *h, T *&ptr, size_t &cap, size_t need) {
     if (need <= cap) return MIBN_OK;
     if (ptr) { HIP_TRY(h, hipFree(ptr)); ptr = nullptr; cap = 0; }
-    size_t n = need + need / 4 + 1024;
+    size_t n = need + need / 2 + 1024;
     HIP_TRY(h, hipMalloc(&ptr, n * sizeof(T)));
     cap = n;
     return MIBN_OK;
@@ -264,11 +264,37 @@ int upload(mibn_ctx *h, mibn_ctx::Staging &sg, void *dst, const void *src, size_
     return MIBN_OK;
 }
 
+// CPUs this process may actually use: the cgroup CPU quota when there is one (a container that sees 256 hardware
+// threads may be limited to 16 CPUs' worth of time; more runnable threads than ~2x the quota only get throttled)
+double cpu_quota() {
+    double q = 0;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char a[64] = {0};
+        double period = 0;
+        if (std::fscanf(f, "%63s %lf", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0) q = std::atof(a) / period;
+        std::fclose(f);
+    } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        double quota = 0, period = 0;
+        if (std::fscanf(g, "%lf", &quota) == 1 && quota > 0) {
+            if (FILE *p = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(p, "%lf", &period) == 1 && period > 0) q = quota / period;
+                std::fclose(p);
+            }
+        }
+        std::fclose(g);
+    }
+    return q;
+}
+
 int default_threads() {
     int hw = (int)std::thread::hardware_concurrency();
     int local_world = 1;
     if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, std::atoi(e));
-    return std::max(1, std::min(64, hw / local_world));
+    double cpus = hw;
+    const double quota = cpu_quota();
+    if (quota > 0) cpus = std::min(cpus, 4.0 * quota);  // planning is bursty (~1/3 duty cycle): 4 threads per quota CPU finish a
+                                                        // chunk sooner inside the same CPU-time budget (measured: 64 beat 32 threads at quota 16)
+    return std::max(1, std::min(64, (int)(cpus / local_world)));
 }
 
 // wait for a set's launches and book their HIP-event durations per kernel
@@ -394,10 +420,12 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             h->stats.plan_ms += now_ms() - t0;
             const size_t need_bytes = (size_t)std::max<int64_t>(16, sc.arena_cells) * sizeof(double);
             if (need_bytes > h->arena_bytes) {
+                // grow with headroom (chunks differ by ~10 %): re-allocating tens of GB costs hundreds of ms
                 HIP_TRY(h, hipStreamSynchronize(h->stream));  // earlier launches still use the old arena
                 if (h->d_arena) { HIP_TRY(h, hipFree(h->d_arena)); h->d_arena = nullptr; h->arena_bytes = 0; }
-                HIP_TRY(h, hipMalloc(&h->d_arena, need_bytes));
-                h->arena_bytes = need_bytes;
+                const size_t want = std::max(need_bytes, std::min((size_t)((double)budget_cells * 8.0), need_bytes + need_bytes / 3));
+                HIP_TRY(h, hipMalloc(&h->d_arena, want));
+                h->arena_bytes = want;
             }
             // items / arena offsets of this wave live until the wave's launches have run: one wave per set at a
             // time unless the chunk had to be split (then wait for the previous wave first)

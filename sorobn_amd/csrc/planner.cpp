@@ -2,6 +2,7 @@
 #include "planner.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1174,13 +1175,20 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
     if ((int)ck.tags.size() < T) ck.tags.resize(T);
     std::vector<PlanStats> tst(T);
     std::vector<std::string> terr(T);
+    // dynamic distribution in blocks of 32 requests: request costs vary 100x and a worker may lose its core to
+    // another rank's planner, a static split would wait for the slowest worker
+    std::atomic<int64_t> next{0};
+    constexpr int64_t kBlock = 32;
     pool.run([&](int t) {
-        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
         ProgBuf &prog = bufs[t];
         prog.size = 0;
         std::vector<Tag> &tags = ck.tags[t];
         tags.clear();
-        for (int64_t i = lo; i < hi; ++i) {
+        for (;;) {
+          const int64_t lo = next.fetch_add(kBlock, std::memory_order_relaxed);
+          if (lo >= n) break;
+          const int64_t hi = std::min(n, lo + kBlock);
+          for (int64_t i = lo; i < hi; ++i) {
             const int64_t b = b0 + i;
             ck.prog_off[i] = prog.size;
             ck.local_off[i] = prog.size;
@@ -1205,15 +1213,19 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             tst[t].n_steps += st.n_steps;
             tst[t].max_step_cells = std::max(tst[t].max_step_cells, st.max_step_cells);
             tst[t].arena_cells = std::max(tst[t].arena_cells, st.arena_cells);
+          }
         }
         ck.thread_words[t] = prog.size;
     });
+    std::vector<size_t> tbase(T, 0);
     size_t base = 0;
     for (int t = 0; t < T; ++t) {
-        if (!terr[t].empty()) ck.err = terr[t];
-        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
-        for (int64_t i = lo; i < hi; ++i) ck.prog_off[i] += base;
+        tbase[t] = base;
         base += ck.thread_words[t];
+    }
+    for (int64_t i = 0; i < n; ++i) ck.prog_off[i] = tbase[ck.thread_of[i]] + ck.local_off[i];
+    for (int t = 0; t < T; ++t) {
+        if (!terr[t].empty()) ck.err = terr[t];
         ck.st.alg_bytes += tst[t].alg_bytes;
         ck.st.alg_flops += tst[t].alg_flops;
         ck.st.n_steps += tst[t].n_steps;
@@ -1221,9 +1233,6 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
         ck.arena_cells = std::max(ck.arena_cells, tst[t].arena_cells);
     }
     ck.total_words = base;
-    ck.order.resize(n);
-    std::iota(ck.order.begin(), ck.order.end(), 0);
-    std::stable_sort(ck.order.begin(), ck.order.end(), [&](int32_t a, int32_t b) { return ck.cost[a] > ck.cost[b]; });
 }
 
 // ------------------------------------------------------------------------------------ schedule

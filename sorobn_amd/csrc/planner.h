@@ -183,7 +183,6 @@ struct BatchPlan {
     std::vector<int64_t> arena_need;           // per request: scratch cells
     std::vector<int32_t> thread_of;            // per request: worker that planned it
     std::vector<uint64_t> local_off;           // per request: word offset inside that worker's buffer
-    std::vector<int32_t> order;                // execution order, heaviest first
     int64_t arena_cells = 0;                   // largest per-request scratch need
     size_t total_words = 0;
     PlanStats st;                              // totals
