@@ -160,9 +160,65 @@ inline double scope_cells(const Network &net, const Bits &b) {
     return c;
 }
 
+// Two-word bitsets for networks of up to 128 variables (the common case): the byte model and the min-fill search
+// below run ~3x faster on them than on the generic kMaxVars-wide Bits.
+struct B2 {
+    uint64_t a = 0, b = 0;
+    bool test(int i) const { return ((i < 64 ? a : b) >> (i & 63)) & 1; }
+    void set(int i) { (i < 64 ? a : b) |= 1ull << (i & 63); }
+    void clr(int i) { (i < 64 ? a : b) &= ~(1ull << (i & 63)); }
+};
+template <class F> inline void b2_each(const B2 &s, F f) {
+    for (uint64_t m = s.a; m; m &= m - 1) f(__builtin_ctzll(m));
+    for (uint64_t m = s.b; m; m &= m - 1) f(64 + __builtin_ctzll(m));
+}
+// simulate() for networks of up to 128 variables
+double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
+                    double abort_above) {
+    constexpr int kCap = 512;
+    B2 f[kCap];
+    double fc[kCap];
+    int nf = (int)f0.size();
+    for (int i = 0; i < nf; ++i) { f[i] = B2{f0[i].w[0], f0[i].w[1]}; fc[i] = f0c[i]; }
+    auto cells = [&](const B2 &u) {
+        double c = 1;
+        b2_each(u, [&](int v) { c *= net.card[v]; });
+        return c;
+    };
+    double bytes = 0;
+    for (int32_t x : order) {
+        B2 u;
+        double in = 0;
+        for (int i = 0; i < nf;) {
+            if (f[i].test(x)) {
+                u.a |= f[i].a;
+                u.b |= f[i].b;
+                in += fc[i];
+                --nf;
+                f[i] = f[nf];
+                fc[i] = fc[nf];
+            } else {
+                ++i;
+            }
+        }
+        u.clr(x);
+        const double uc = cells(u);
+        bytes += 8.0 * (in + uc);
+        if (bytes > abort_above) return bytes;
+        f[nf] = u;
+        fc[nf] = uc;
+        ++nf;
+    }
+    B2 u;
+    double in = 0;
+    for (int i = 0; i < nf; ++i) { u.a |= f[i].a; u.b |= f[i].b; in += fc[i]; }
+    return bytes + 8.0 * (in + cells(u));
+}
+
 // SURVEY section 8(d) byte model of an elimination order over factor scopes (f0c = cells of every scope).
 double simulate(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
                 double abort_above) {
+    if (net.n_vars <= 128 && f0.size() + order.size() + 1 <= 512) return simulate_128(net, f0, f0c, order, abort_above);
     Scratch &S = scratch();
     std::vector<Bits> &f = S.sim;
     std::vector<double> &fc = S.simc;
@@ -204,18 +260,6 @@ double simulate(const Network &net, const std::vector<Bits> &f0, const std::vect
     return bytes;
 }
 
-// Two-word bitsets for networks of up to 128 variables (the common case): the same min-fill search as
-// greedy_order below, ~3x faster than the generic kMaxVars-wide loops.
-struct B2 {
-    uint64_t a = 0, b = 0;
-    bool test(int i) const { return ((i < 64 ? a : b) >> (i & 63)) & 1; }
-    void set(int i) { (i < 64 ? a : b) |= 1ull << (i & 63); }
-    void clr(int i) { (i < 64 ? a : b) &= ~(1ull << (i & 63)); }
-};
-template <class F> inline void b2_each(const B2 &s, F f) {
-    for (uint64_t m = s.a; m; m &= m - 1) f(__builtin_ctzll(m));
-    for (uint64_t m = s.b; m; m &= m - 1) f(64 + __builtin_ctzll(m));
-}
 void greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits &hidden, std::vector<int32_t> &order) {
     const int n = net.n_vars;
     B2 adj[128];
@@ -996,7 +1040,23 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
                     if (pool[live[l]].scope.test(x2)) {
                         if (n2 >= kMaxIn) { fits = false; break; }
                         ins[n2++] = &pool[live[l]];
+                        u.or_(pool[live[l]].scope);
                     }
+                // cheap necessary conditions of the FIBER form, before any emission work (most candidates fail here):
+                // one or two big inputs, and enough R cells (output cells / predicted NC) for a tiled step
+                if (fits) {
+                    int nbig = 0;
+                    Bits bigscope;
+                    bigscope.nw = net.nw;
+                    for (int j = 0; j < n2; ++j)
+                        if (ins[j]->cells > net.small_cells) { ++nbig; bigscope.or_(ins[j]->scope); }
+                    Bits nvars = u;  // output variables no big input depends on: the N axes
+                    nvars.andnot(bigscope);
+                    double nc = 1;
+                    nvars.for_each([&](int v) { if (v != x && v != x2 && nc * net.card[v] <= kMaxNC) nc *= net.card[v]; });
+                    const double out_log2 = scope_log2(net, u) - net.log2card[x] - net.log2card[x2];
+                    if (nbig < 1 || nbig > 2 || out_log2 - std::log2(nc) < std::log2((double)net.big_iters)) fits = false;
+                }
                 if (fits) {
                     const int X[2] = {x, x2};
                     pool.emplace_back();
