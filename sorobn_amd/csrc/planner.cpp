@@ -571,7 +571,7 @@ struct Emitter {
         while (nlo < nr && lo < kLoTarget && lo * rcard[nlo] <= kFiberLoMax) lo *= rcard[nlo++];
         int64_t rcells = 1;
         for (int i = 0; i < nr; ++i) rcells *= rcard[i];
-        if (rcells < net.big_iters) return false;  // small steps run in the segment interpreter (GENERIC form)
+        if (rcells * NC < net.big_iters) return false;  // small steps (< big_iters output cells) run in the segment interpreter (GENERIC form)
         // contiguous fibers: N-combination n at offset n, lane cell l at l*NC
         bool contig = true;
         {
@@ -1055,7 +1055,7 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
                     double nc = 1;
                     nvars.for_each([&](int v) { if (v != x && v != x2 && nc * net.card[v] <= kMaxNC) nc *= net.card[v]; });
                     const double out_log2 = scope_log2(net, u) - net.log2card[x] - net.log2card[x2];
-                    if (nbig < 1 || nbig > 2 || out_log2 - std::log2(nc) < std::log2((double)net.big_iters)) fits = false;
+                    if (nbig < 1 || nbig > 2 || out_log2 < std::log2((double)net.big_iters)) fits = false;
                 }
                 if (fits) {
                     const int X[2] = {x, x2};
