@@ -184,6 +184,30 @@ def dags_fixture():
     netspec.save(os.path.join(HERE, "random_dags.json"), nets)
 
 
+def wide_fixture():
+    """Higher cardinalities than the other fixtures (the kernels' runtime-cx / runtime-NC classes, joint
+    eliminations of unequal cards, cx up to 16 from one variable): random DAGs with cards up to 11 and small
+    K = 8 / K = 16 grids."""
+    nets = []
+    for seed in range(8):
+        spec = netspec.random_dag_spec(100 + seed, n_nodes=6 + seed % 4, cards=(2, 3, 6, 8, 11),
+                                       labels="str" if seed % 2 else "int")
+        spec["name"] = f"wide_dag{seed}"
+        bn = netspec.build(spec, sorobn.BayesNet, wrap=refload.HashedName)
+        reqs = random_requests(spec, 16, seed=2000 + seed, max_q=2, max_e=3)
+        nets.append({"spec": spec, "requests": run_requests(bn, reqs, refload.HashedName)})
+        print("wide dag", seed, len(spec["nodes"]), flush=True)
+    for R, C, K in [(3, 3, 8), (3, 4, 8), (2, 3, 16), (2, 5, 7)]:
+        spec = netspec.grid_spec(R, C, K, seed=0)
+        bn = netspec.build(spec, sorobn.BayesNet, wrap=refload.HashedName)
+        n = R * C
+        reqs = [((f"{0:03d}",), [(f"{n - 1:03d}", 0)]), ((f"{n - 1:03d}",), [(f"{0:03d}", K - 1)])]
+        reqs += random_requests(spec, 8, seed=R * 100 + C * 10 + K, max_q=2, max_e=3)
+        nets.append({"spec": spec, "requests": run_requests(bn, reqs, refload.HashedName)})
+        print("wide grid", R, C, K, flush=True)
+    netspec.save(os.path.join(HERE, "wide_cards.json"), nets)
+
+
 def grids_fixture(heavy):
     nets = []
     small = [(2, 2, 2), (2, 3, 3), (3, 3, 4), (3, 4, 2), (4, 4, 4), (4, 5, 3), (5, 5, 4), (6, 6, 4),
@@ -237,7 +261,7 @@ if __name__ == "__main__":
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids"]
+    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide"]
     if "examples" in todo:
         examples_fixture()
     if "impute" in todo:
@@ -246,3 +270,5 @@ if __name__ == "__main__":
         dags_fixture()
     if "grids" in todo:
         grids_fixture(a.heavy)
+    if "wide" in todo:
+        wide_fixture()
