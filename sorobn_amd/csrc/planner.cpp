@@ -172,9 +172,7 @@ template <class F> inline void b2_each(const B2 &s, F f) {
     for (uint64_t m = s.a; m; m &= m - 1) f(__builtin_ctzll(m));
     for (uint64_t m = s.b; m; m &= m - 1) f(64 + __builtin_ctzll(m));
 }
-// simulate() for networks of up to 128 variables.  Models the joint elimination of plan_request too (a big
-// intermediate consumed by the very next step never touches HBM), so that candidate orders are compared on the bytes
-// they will actually move.
+// simulate() for networks of up to 128 variables
 double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
                     double abort_above) {
     constexpr int kCap = 512;
@@ -187,20 +185,15 @@ double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::
         b2_each(u, [&](int v) { c *= net.card[v]; });
         return c;
     };
-    const double small = (double)net.small_cells, big_iters = (double)net.big_iters;
     double bytes = 0;
-    const size_t n = order.size();
-    for (size_t oi = 0; oi < n; ++oi) {
-        const int32_t x = order[oi];
+    for (int32_t x : order) {
         B2 u;
         double in = 0;
-        int nbig = 0;
         for (int i = 0; i < nf;) {
             if (f[i].test(x)) {
                 u.a |= f[i].a;
                 u.b |= f[i].b;
                 in += fc[i];
-                nbig += fc[i] > small;
                 --nf;
                 f[i] = f[nf];
                 fc[i] = fc[nf];
@@ -209,29 +202,7 @@ double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::
             }
         }
         u.clr(x);
-        double uc = cells(u);
-        if (net.fuse && oi + 1 < n && uc > small) {
-            const int32_t x2 = order[oi + 1];
-            if (u.test(x2) && net.card[x] * net.card[x2] <= kMaxCx) {
-                B2 u2 = u;
-                double in2 = 0;
-                int nbig2 = nbig;
-                for (int i = 0; i < nf; ++i)
-                    if (f[i].test(x2)) { u2.a |= f[i].a; u2.b |= f[i].b; in2 += fc[i]; nbig2 += fc[i] > small; }
-                u2.clr(x2);
-                const double uc2 = cells(u2);
-                if (nbig2 >= 1 && nbig2 <= 2 && uc2 >= big_iters) {  // (the planner's gate, without the LDS-size details)
-                    for (int i = 0; i < nf;) {
-                        if (f[i].test(x2)) { --nf; f[i] = f[nf]; fc[i] = fc[nf]; }
-                        else ++i;
-                    }
-                    in += in2;
-                    u = u2;
-                    uc = uc2;
-                    ++oi;
-                }
-            }
-        }
+        const double uc = cells(u);
         bytes += 8.0 * (in + uc);
         if (bytes > abort_above) return bytes;
         f[nf] = u;

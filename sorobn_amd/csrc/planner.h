@@ -58,7 +58,7 @@ struct Network {
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
     int tile_h = 0;          // hi iterations per tile; 0 = sized for kTileBytes of traffic per tile
-    double minfill_above = 1e7;  // run the greedy min-fill order search only if the sweep orders cost more bytes than this
+    double minfill_above = 2e7;  // run the greedy min-fill order search only if the sweep orders cost more bytes than this
     int outer = 1;           // OUTER form (fp64 MFMA) for products of two big tables
     int fuse = 1;            // eliminate two consecutive variables in one FIBER step when the first result would be a big table
 
