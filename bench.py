@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--n-evidence", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sync", action="store_true", help="one blocking mibn_query_batch per step instead of the two-deep pipeline")
     ap.add_argument("--threads", type=int, default=0, help="planner threads of this rank (0 = host threads / ranks on the node)")
     a = ap.parse_args()
 
@@ -146,33 +147,50 @@ def main():
     if world > 1:
         gathered = torch.empty((world, a.batch, 4), dtype=torch.float64, device="cuda")
 
-    def run_step(step):
+    # The K timed steps are pipelined two deep (mibn_submit_batch / mibn_wait): the host plans step s+1 while the
+    # GPU runs step s, as a server streaming batches would.  Every step is complete - posteriors on the host and,
+    # for N > 1, gathered over RCCL - before the closing barrier.
+    def submit(step):
         q, e, c, lo = shard(step)
-        post = eng.query_fixed(q[:, None], e, c)
+        return eng.submit_fixed(q[:, None], e, c), lo
+
+    def finish(pending):
+        handle, lo = pending
+        post = eng.wait(handle)
         if world > 1:  # final gather of the posteriors over xGMI (RCCL)
             mine = torch.from_numpy(post).to("cuda", non_blocking=False)
             dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
-        return post, eng.stats(), eng.kernel_stats()
+        return post, lo
 
-    for s in range(a.warmup):
-        run_step(s)
+    def run(steps):
+        first, pending = None, None
+        for s in steps:
+            nxt = submit(s)
+            if a.sync:
+                done = finish(nxt)
+                first = first or done
+                continue
+            if pending is not None:
+                done = finish(pending)
+                first = first or done
+            pending = nxt
+        if pending is not None:
+            done = finish(pending)
+            first = first or done
+        eng.drain()  # every launch finished and its HIP-event time booked
+        return first
+
+    run(range(a.warmup))
     barrier()
+    st0, ks0 = eng.total_stats(), eng.total_kernel_stats()
     t0 = time.perf_counter()
-    agg = {}
-    kagg = {}
-    first_post = None
-    for s in range(a.warmup, total_steps):
-        post, st, ks = run_step(s)
-        for k in ks:
-            d = kagg.setdefault(k["name"], {"launches": 0.0, "ms": 0.0, "alg_bytes": 0.0, "items": 0.0})
-            for f in d:
-                d[f] += k[f]
-        if first_post is None:
-            first_post, first_lo = post, shard(s)[3]
-        for k, v in st.items():
-            agg[k] = agg.get(k, 0.0) + v
+    first_post, first_lo = run(range(a.warmup, total_steps))
     barrier()
     dt = time.perf_counter() - t0
+    st1, ks1 = eng.total_stats(), eng.total_kernel_stats()
+    agg = {k: st1[k] - st0[k] for k in st1}
+    kagg = {n: {f: ks1[n][f] - ks0.get(n, {}).get(f, 0.0) for f in ks1[n]} for n in ks1}
+    kagg = {n: d for n, d in kagg.items() if d["launches"] > 0}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

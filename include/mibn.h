@@ -114,6 +114,22 @@ typedef struct mibn_kernel_stat {
 } mibn_kernel_stat;
 int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n);
 
+/*
+ * Asynchronous form of mibn_query_batch for streams of batches: mibn_submit_batch plans, uploads and launches and
+ * returns at once with a ticket; mibn_wait(ticket) blocks until that call's posteriors are in `out` (which must
+ * stay valid until then).  Up to two calls may be in flight, so the host plans call s+1 while the GPU still runs
+ * call s.  mibn_drain waits for every launch and books its time; mibn_total_stats / mibn_total_kernel_stats are
+ * the counters of mibn_last_stats / mibn_last_kernel_stats accumulated since the context was created (differences
+ * over a region of calls are what bench.py reports).
+ */
+int mibn_submit_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                      const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
+                      const int64_t *out_off, double *out, int32_t *ticket);
+int mibn_wait(mibn_t *h, int32_t ticket);
+int mibn_drain(mibn_t *h);
+int mibn_total_stats(const mibn_t *h, mibn_stats *out);
+int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n);
+
 /* Plan only (no device work): fills alg_bytes / alg_flops / n_steps / max_step_cells for one
  * request.  Also usable without a device through a context created by mibn_create_planner(). */
 int mibn_plan_stats(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e,

@@ -16,7 +16,8 @@ SYMBOLS = [
     "mibn_device_count", "mibn_version", "mibn_create", "mibn_destroy", "mibn_last_error",
     "mibn_set_network", "mibn_set_order_hints", "mibn_query_batch", "mibn_last_stats",
     "mibn_plan_stats", "mibn_create_planner", "mibn_set_option", "mibn_gibbs",
-    "mibn_last_kernel_stats",
+    "mibn_last_kernel_stats", "mibn_submit_batch", "mibn_wait", "mibn_drain", "mibn_total_stats",
+    "mibn_total_kernel_stats",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
@@ -67,6 +68,11 @@ def lib():
         L.mibn_set_network.argtypes = [vp, C.c_int32, i32p, i64p, i32p, i64p, f64p]
         L.mibn_set_order_hints.argtypes = [vp, C.c_int32, i32p]
         L.mibn_query_batch.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p]
+        L.mibn_submit_batch.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p, C.POINTER(C.c_int32)]
+        L.mibn_wait.argtypes = [vp, C.c_int32]
+        L.mibn_drain.argtypes = [vp]
+        L.mibn_total_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mibn_total_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mibn_last_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_plan_stats.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, C.POINTER(Stats)]
@@ -184,16 +190,57 @@ class Engine:
                                         ecodes.reshape(-1))
         return out.reshape(B, -1) if B else out.reshape(0, 0)
 
+    def submit_fixed(self, qvars, evars, ecodes):
+        """Asynchronous query_fixed: returns a handle for wait().  At most two calls in flight."""
+        qvars = _i32(qvars).reshape(len(qvars), -1)
+        B, nq = qvars.shape
+        evars = _i32(evars).reshape(B, -1)
+        ecodes = _i32(ecodes).reshape(B, -1)
+        ne = evars.shape[1]
+        q_off = np.arange(B + 1, dtype=np.int64) * nq
+        e_off = np.arange(B + 1, dtype=np.int64) * ne
+        cells = np.prod(self.card[qvars].astype(np.int64), axis=1) if B else np.zeros(0, np.int64)
+        out_off = np.concatenate([[0], np.cumsum(cells)]).astype(np.int64)
+        out = np.zeros(max(1, int(out_off[-1])), np.float64)
+        ticket = C.c_int32(-1)
+        keep = (q_off, qvars, e_off, evars, ecodes, out_off, out)  # the library reads them during the call only, `out` until wait
+        self._check(self._L.mibn_submit_batch(
+            self._h, B, _p(q_off, C.c_int64), _p(qvars.reshape(-1), C.c_int32), _p(e_off, C.c_int64),
+            _p(evars.reshape(-1) if ne else np.zeros(1, np.int32), C.c_int32),
+            _p(ecodes.reshape(-1) if ne else np.zeros(1, np.int32), C.c_int32), _p(out_off, C.c_int64),
+            _p(out, C.c_double), C.byref(ticket)))
+        return {"ticket": ticket.value, "out": out, "B": B, "n": int(out_off[-1]), "keep": keep}
+
+    def wait(self, handle):
+        self._check(self._L.mibn_wait(self._h, handle["ticket"]))
+        return handle["out"][:handle["n"]].reshape(handle["B"], -1) if handle["B"] else handle["out"][:0].reshape(0, 0)
+
+    def drain(self):
+        self._check(self._L.mibn_drain(self._h))
+
     def stats(self):
         s = Stats()
         self._check(self._L.mibn_last_stats(self._h, C.byref(s)))
         return s.as_dict()
 
+    def total_stats(self):
+        """Counters accumulated since the engine was created (take differences over a region of calls)."""
+        s = Stats()
+        self._check(self._L.mibn_total_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def total_kernel_stats(self):
+        arr = (KernelStat * 64)()
+        n = C.c_int32(0)
+        self._check(self._L.mibn_total_kernel_stats(self._h, 64, arr, C.byref(n)))
+        return {arr[i].name.decode(): {"launches": arr[i].launches, "ms": arr[i].ms, "alg_bytes": arr[i].alg_bytes,
+                                       "items": arr[i].items} for i in range(n.value)}
+
     def kernel_stats(self):
         """Per-kernel breakdown of the last query_batch: list of dicts (name, launches, ms, alg_bytes, items)."""
-        arr = (KernelStat * 32)()
+        arr = (KernelStat * 64)()
         n = C.c_int32(0)
-        self._check(self._L.mibn_last_kernel_stats(self._h, 32, arr, C.byref(n)))
+        self._check(self._L.mibn_last_kernel_stats(self._h, 64, arr, C.byref(n)))
         return [{"name": arr[i].name.decode(), "launches": arr[i].launches, "ms": arr[i].ms,
                  "alg_bytes": arr[i].alg_bytes, "items": arr[i].items} for i in range(n.value)]
 

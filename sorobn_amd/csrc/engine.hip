@@ -32,12 +32,20 @@ struct mibn_ctx {
     bool planner_only = false;
     int device = -1;
     int n_cu = 0;
-    hipStream_t stream = nullptr;  // gibbs + result download
+    hipStream_t stream = nullptr;       // kernels, gibbs, result download
+    hipStream_t copy_stream = nullptr;  // program / schedule uploads: overlap the previous chunk's kernels
     double *d_pool = nullptr;
     double *d_arena = nullptr;  // private arenas of the requests of the wave in flight
     size_t arena_bytes = 0;
-    double *d_results = nullptr;
-    size_t results_cap = 0;  // doubles
+    double *d_results[2] = {nullptr, nullptr};  // dense posteriors of the call in flight (two calls may overlap)
+    size_t results_cap[2] = {0, 0};             // doubles
+    struct Pending {                            // an asynchronous call whose results have not been collected yet
+        bool active = false;
+        double *out = nullptr;
+        size_t cells = 0;
+        hipEvent_t done = nullptr;
+    } pend[2];
+    int next_slot = 0;
     // double-buffered chunk pipeline: workers plan chunk i+1 into pinned buffers while the GPU runs chunk i
     ThreadPool *pool = nullptr;
     struct Staging {  // pinned host staging: pageable sources would make hipMemcpyAsync block on the stream
@@ -57,6 +65,7 @@ struct mibn_ctx {
         size_t wg_item_cap = 0;
         Item *d_items = nullptr;
         size_t items_cap = 0;
+        hipEvent_t uploaded = nullptr;       // the copy stream has delivered this set's programs and schedule
         std::vector<hipEvent_t> ev;          // launch boundaries of the waves in flight
         struct Timed { int kid; size_t e0, e1; double bytes, items; };
         std::vector<Timed> timed;
@@ -65,9 +74,11 @@ struct mibn_ctx {
         BatchPlan plan;
         Schedule sched;
     } set[2];
+    Staging res_stage[2];  // pinned landing buffers of asynchronous calls
     std::string err;
-    mibn_stats stats{};
+    mibn_stats stats{}, total{};               // last call / since creation
     mibn_kernel_stat kstats[kNumKernels + 1];  // per class (split_kinds) + the level kernel as a whole
+    mibn_kernel_stat ktotal[kNumKernels + 1];
     // options
     double arena_gb = 96.0;
     int threads = 0;
@@ -121,7 +132,8 @@ int mibn_create(int device, mibn_t **out) {
         return MIBN_E_NODEVICE;
     }
     h->n_cu = prop.multiProcessorCount;
-    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
     if (!ok) { delete h; return MIBN_E_HIP; }
     *out = h;
     return MIBN_OK;
@@ -135,7 +147,10 @@ void mibn_destroy(mibn_t *h) {
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         (void)hipFree(h->d_pool);
         (void)hipFree(h->d_arena);
-        (void)hipFree(h->d_results);
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(h->d_results[k]);
+            if (h->pend[k].done) (void)hipEventDestroy(h->pend[k].done);
+        }
         for (auto &st : h->set) {
             for (auto &b : st.bufs)
                 if (b.data) (void)hipHostFree(b.data);
@@ -147,7 +162,11 @@ void mibn_destroy(mibn_t *h) {
             for (auto &sg : st.stage)
                 if (sg.p) (void)hipHostFree(sg.p);
             for (auto e : st.ev) (void)hipEventDestroy(e);
+            if (st.uploaded) (void)hipEventDestroy(st.uploaded);
         }
+        for (auto &sg : h->res_stage)
+            if (sg.p) (void)hipHostFree(sg.p);
+        if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -260,7 +279,7 @@ int upload(mibn_ctx *h, mibn_ctx::Staging &sg, void *dst, const void *src, size_
         sg.cap = cap;
     }
     std::memcpy(sg.p, src, bytes);
-    HIP_TRY(h, hipMemcpyAsync(dst, sg.p, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dst, sg.p, bytes, hipMemcpyHostToDevice, h->copy_stream));
     return MIBN_OK;
 }
 
@@ -306,11 +325,15 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));
         h->stats.kernel_ms += ms;
         h->stats.n_launches += 1;
-        mibn_kernel_stat &k = h->kstats[t.kid];
-        k.launches += 1;
-        k.ms += ms;
-        k.alg_bytes += t.bytes;
-        k.items += t.items;
+        h->total.kernel_ms += ms;
+        h->total.n_launches += 1;
+        for (mibn_kernel_stat *ks : {&h->kstats[t.kid], &h->ktotal[t.kid]}) {
+            if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", t.kid < kNumKernels ? kernel_name(t.kid) : "ve_level_kernel");
+            ks->launches += 1;
+            ks->ms += ms;
+            ks->alg_bytes += t.bytes;
+            ks->items += t.items;
+        }
         if (h->trace) std::fprintf(stderr, "[mibn launch] %-32s wgs %8.0f MB %10.2f ms %8.4f -> %7.1f GB/s\n", h->kstats[t.kid].name, t.items, t.bytes / 1e6, ms, t.bytes / ms / 1e6);
     }
     st.timed.clear();
@@ -332,9 +355,12 @@ int next_event(mibn_ctx *h, mibn_ctx::Set &st, size_t &idx) {
 
 }  // namespace
 
-extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
-                                const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
-                                const int64_t *out_off, double *out) {
+namespace {
+// Plan, upload and launch a batch.  Synchronous (ticket == nullptr): waits and writes `out`.  Asynchronous: the
+// results land in a pinned buffer, *ticket identifies the call for mibn_wait; up to two calls may be in flight, so
+// the host plans call s+1 while the GPU still runs call s.
+int run_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
+              const int32_t *e_codes, const int64_t *out_off, double *out, int32_t *ticket) {
     if (!h || B < 0 || !q_off || !e_off || !out_off || (B && !out)) return MIBN_E_ARG;
     if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
@@ -344,6 +370,9 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
         h->kstats[k] = mibn_kernel_stat{};
         std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", k < kNumKernels ? kernel_name(k) : "ve_level_kernel");
     }
+    const int slot = h->next_slot;
+    if (h->pend[slot].active) { h->err = "two asynchronous calls are already in flight: mibn_wait the older one first"; return MIBN_E_STATE; }
+    if (ticket) *ticket = slot;
     if (B == 0) return MIBN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     // validation (bayes_net.py:840-845) and the out-of-domain-evidence short cut
@@ -373,8 +402,9 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
     }
     int rc;
     const size_t res_cells = (size_t)(out_off[B] - out_off[0]);
-    if ((rc = ensure(h, h->d_results, h->results_cap, res_cells))) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_results, 0, res_cells * 8, h->stream));
+    if ((rc = ensure(h, h->d_results[slot], h->results_cap[slot], res_cells))) return rc;
+    double *const d_results = h->d_results[slot];
+    HIP_TRY(h, hipMemsetAsync(d_results, 0, res_cells * 8, h->stream));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
     const int64_t budget_cells = (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes)) / 8.0);
@@ -399,7 +429,7 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
         size_t base = 0;
         for (size_t t = 0; t < ck.thread_words.size(); ++t) {
             if (ck.thread_words[t])
-                HIP_TRY(h, hipMemcpyAsync(st.d_prog + base, st.bufs[t].data, ck.thread_words[t] * 4, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipMemcpyAsync(st.d_prog + base, st.bufs[t].data, ck.thread_words[t] * 4, hipMemcpyHostToDevice, h->copy_stream));
             base += ck.thread_words[t];
         }
         if ((rc = upload(h, st.stage[0], st.d_prog_off, ck.prog_off.data(), (size_t)n * 8))) return rc;
@@ -429,13 +459,16 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             }
             // items / arena offsets of this wave live until the wave's launches have run: one wave per set at a
             // time unless the chunk had to be split (then wait for the previous wave first)
-            if (r0 > 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (r0 > 0) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipStreamSynchronize(h->copy_stream)); }
             if ((rc = ensure(h, st.d_items, st.items_cap, sc.items.size()))) return rc;
             if ((rc = ensure(h, st.d_wg_item, st.wg_item_cap, sc.wg_item.size()))) return rc;
             t0 = now_ms();
             if ((rc = upload(h, st.stage[1], st.d_arena_off, sc.arena_off.data(), (size_t)(r1 - r0) * 8))) return rc;
             if ((rc = upload(h, st.stage[2], st.d_items, sc.items.data(), sc.items.size() * sizeof(Item)))) return rc;
             if ((rc = upload(h, st.stage[3], st.d_wg_item, sc.wg_item.data(), sc.wg_item.size() * sizeof(uint32_t)))) return rc;
+            if (!st.uploaded) HIP_TRY(h, hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
+            HIP_TRY(h, hipEventRecord(st.uploaded, h->copy_stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, st.uploaded, 0));  // the kernels of this wave wait for its uploads only
             h->stats.h2d_ms += now_ms() - t0;
             LevelArgs A;
             A.prog = st.d_prog;
@@ -443,7 +476,7 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
             A.arena_off = st.d_arena_off;
             A.pool = h->d_pool;
             A.arena = h->d_arena;
-            A.results = h->d_results + (out_off[b0] - out_off[0]);
+            A.results = d_results + (out_off[b0] - out_off[0]);
             size_t e_prev = 0;
             double n_wg = 0;
             if ((rc = next_event(h, st, e_prev))) return rc;
@@ -480,13 +513,100 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
         h->stats.n_steps += ck.st.n_steps;
         h->stats.max_step_cells = std::max(h->stats.max_step_cells, ck.st.max_step_cells);
     }
+    auto fold = [&]() {  // the host-side counters of this call -> totals (kernel times are folded by retire())
+        h->total.plan_ms += h->stats.plan_ms;
+        h->total.h2d_ms += h->stats.h2d_ms;
+        h->total.d2h_ms += h->stats.d2h_ms;
+        h->total.total_ms += h->stats.total_ms;
+        h->total.alg_bytes += h->stats.alg_bytes;
+        h->total.alg_flops += h->stats.alg_flops;
+        h->total.n_steps += h->stats.n_steps;
+        h->total.n_workgroups += h->stats.n_workgroups;
+        h->total.arena_bytes = std::max(h->total.arena_bytes, h->stats.arena_bytes);
+        h->total.max_step_cells = std::max(h->total.max_step_cells, h->stats.max_step_cells);
+    };
+    if (ticket) {
+        mibn_ctx::Pending &pd = h->pend[slot];
+        mibn_ctx::Staging &sg = h->res_stage[slot];
+        const size_t bytes = res_cells * 8;
+        if (bytes > sg.cap) {
+            if (sg.p) { HIP_TRY(h, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
+            HIP_TRY(h, hipHostMalloc((void **)&sg.p, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+            sg.cap = bytes + bytes / 4 + 4096;
+        }
+        if (!pd.done) HIP_TRY(h, hipEventCreateWithFlags(&pd.done, hipEventDisableTiming));
+        HIP_TRY(h, hipMemcpyAsync(sg.p, d_results, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipEventRecord(pd.done, h->stream));
+        pd.active = true;
+        pd.out = out + out_off[0];
+        pd.cells = res_cells;
+        h->next_slot ^= 1;
+        h->stats.total_ms = now_ms() - t_start;
+        fold();
+        return MIBN_OK;
+    }
     for (auto &st : h->set)
         if ((rc = retire(h, st))) return rc;
     double t0 = now_ms();
-    HIP_TRY(h, hipMemcpyAsync(out + out_off[0], h->d_results, res_cells * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out + out_off[0], d_results, res_cells * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stats.d2h_ms += now_ms() - t0;
     h->stats.total_ms = now_ms() - t_start;
+    fold();
+    return MIBN_OK;
+}
+}  // namespace
+
+extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                                const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
+                                const int64_t *out_off, double *out) {
+    if (h && (h->pend[0].active || h->pend[1].active)) { h->err = "asynchronous calls in flight: collect them with mibn_wait first"; return MIBN_E_STATE; }
+    return run_batch(h, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, nullptr);
+}
+
+extern "C" int mibn_submit_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                                 const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
+                                 const int64_t *out_off, double *out, int32_t *ticket) {
+    if (!ticket) return MIBN_E_ARG;
+    return run_batch(h, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, ticket);
+}
+
+extern "C" int mibn_wait(mibn_t *h, int32_t ticket) {
+    if (!h || ticket < 0 || ticket > 1) return MIBN_E_ARG;
+    mibn_ctx::Pending &pd = h->pend[ticket];
+    if (!pd.active) return MIBN_OK;  // (an empty batch, or already collected)
+    HIP_TRY(h, hipSetDevice(h->device));
+    const double t0 = now_ms();
+    HIP_TRY(h, hipEventSynchronize(pd.done));
+    std::memcpy(pd.out, h->res_stage[ticket].p, pd.cells * 8);
+    pd.active = false;
+    h->stats.d2h_ms += now_ms() - t0;
+    h->total.d2h_ms += now_ms() - t0;
+    return MIBN_OK;
+}
+
+extern "C" int mibn_drain(mibn_t *h) {
+    if (!h) return MIBN_E_ARG;
+    if (h->planner_only) return MIBN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    for (auto &st : h->set)
+        if ((rc = retire(h, st))) return rc;
+    return MIBN_OK;
+}
+
+extern "C" int mibn_total_stats(const mibn_t *h, mibn_stats *out) {
+    if (!h || !out) return MIBN_E_ARG;
+    *out = h->total;
+    return MIBN_OK;
+}
+
+extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
+    if (!h || !out || !n) return MIBN_E_ARG;
+    int k = 0;
+    for (int i = 0; i <= kNumKernels && k < cap; ++i)
+        if (h->ktotal[i].launches > 0) out[k++] = h->ktotal[i];
+    *n = k;
     return MIBN_OK;
 }
 
