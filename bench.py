@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sync", action="store_true", help="one blocking mibn_query_batch per step instead of the two-deep pipeline")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (experiments), e.g. --opt chunk=32768")
     ap.add_argument("--threads", type=int, default=0, help="planner threads of this rank (0 = host threads / ranks on the node)")
     a = ap.parse_args()
 
@@ -127,6 +128,9 @@ def main():
     eng = be.engine
     if a.threads:
         eng.set_option("threads", a.threads)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, float(v))
 
     total_steps = a.warmup + a.steps
     n_req = total_steps * world * a.batch
