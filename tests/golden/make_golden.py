@@ -208,6 +208,21 @@ def wide_fixture():
     netspec.save(os.path.join(HERE, "wide_cards.json"), nets)
 
 
+def many_nodes_fixture():
+    """Networks with more than 128 variables: the planner's generic (kMaxVars-wide) bitset paths instead of the
+    two-word fast paths."""
+    nets = []
+    for R, C, K in [(12, 12, 2), (50, 3, 3), (90, 2, 4)]:
+        spec = netspec.grid_spec(R, C, K, seed=0)
+        bn = netspec.build(spec, sorobn.BayesNet, wrap=refload.HashedName)
+        n = R * C
+        reqs = [((f"{0:03d}",), [(f"{n - 1:03d}", 0)]), ((f"{n - 1:03d}",), [(f"{0:03d}", K - 1)])]
+        reqs += random_requests(spec, 8, seed=R * 100 + C * 10 + K, max_q=2, max_e=4)
+        nets.append({"spec": spec, "requests": run_requests(bn, reqs, refload.HashedName)})
+        print("many-nodes grid", R, C, K, [r["ref_seconds"] for r in nets[-1]["requests"]], flush=True)
+    netspec.save(os.path.join(HERE, "many_nodes.json"), nets)
+
+
 def grids_fixture(heavy):
     nets = []
     small = [(2, 2, 2), (2, 3, 3), (3, 3, 4), (3, 4, 2), (4, 4, 4), (4, 5, 3), (5, 5, 4), (6, 6, 4),
@@ -261,7 +276,7 @@ if __name__ == "__main__":
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide"]
+    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide", "many"]
     if "examples" in todo:
         examples_fixture()
     if "impute" in todo:
@@ -272,3 +287,5 @@ if __name__ == "__main__":
         grids_fixture(a.heavy)
     if "wide" in todo:
         wide_fixture()
+    if "many" in todo:
+        many_nodes_fixture()

@@ -43,7 +43,7 @@ def _check_requests(bn, requests, ctx):
 # (big_iters, tile_h) below the defaults (4096, auto) turn small steps into tiled levels, so the tile kernels
 # of every shape run on the small golden networks too; fuse = joint elimination of two variables per pass
 @pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (1, (2, 1), 1), (6, (8, 3), 1), (1, (2, 1), 0)])
-@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json"])
+@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json", "many_nodes.json"])
 def test_golden_networks(amd, fname, small_cells, tiling, fuse):
     for net in gu.load(fname):
         bn = netspec.build(net["spec"], amd.BayesNet)

@@ -74,7 +74,7 @@ def test_set_network_validation():
 
 # ------------------------------------------------------------------------------------ flatten
 
-@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json"])
+@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json", "many_nodes.json"])
 def test_flatten_is_bit_exact(fname):
     for net in _nets(fname):
         spec = net["spec"]
@@ -147,7 +147,7 @@ def _check_requests(bn, requests, ctx, limit=None):
 # schedule (normally only steps with >= 4096 lane-iterations, in tiles sized for 512 KiB of traffic)
 # fuse: joint elimination of two consecutive variables in one FIBER step (on by default)
 @pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (1, (2, 1), 1), (6, (8, 3), 1), (1, (2, 1), 0)])
-@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json"])
+@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json", "many_nodes.json"])
 def test_planner_programs_reproduce_reference(fname, small_cells, tiling, fuse):
     for net in _nets(fname):
         bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet), small_cells, tiling, fuse)

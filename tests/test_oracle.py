@@ -120,10 +120,10 @@ def _check_net(spec, requests, max_ref_seconds=None):
     return n
 
 
-@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json"])
+@pytest.mark.parametrize("fname", ["examples.json", "random_dags.json", "wide_cards.json", "many_nodes.json"])
 def test_oracle_reproduces_reference_networks(fname):
     total = sum(_check_net(net["spec"], net["requests"]) for net in gu.load(fname))
-    assert total > (500 if fname != "wide_cards.json" else 150)
+    assert total > {"wide_cards.json": 150, "many_nodes.json": 25}.get(fname, 500)
 
 
 def test_oracle_reproduces_reference_small_grids():
