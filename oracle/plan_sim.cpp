@@ -23,10 +23,11 @@
 using namespace mibn;
 
 static std::string g_err;
-static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1;
+static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1;
 extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
 extern "C" void plan_sim_set_tiling(int big_iters, int tile_h) { g_big_iters = big_iters; g_tile_h = tile_h; }
 extern "C" void plan_sim_set_fuse(int fuse) { g_fuse = fuse; }
+extern "C" void plan_sim_set_prune(int prune) { g_prune = prune; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
 
@@ -183,6 +184,7 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     net.big_iters = g_big_iters;
     net.tile_h = g_tile_h;
     net.fuse = g_fuse;
+    net.prune = g_prune;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
     // one-request batch through the product's batch planner and level-synchronous scheduler
@@ -277,6 +279,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     net.big_iters = g_big_iters;
     net.tile_h = g_tile_h;
     net.fuse = g_fuse;
+    net.prune = g_prune;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
     Request rq;

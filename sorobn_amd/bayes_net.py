@@ -7,8 +7,13 @@ CPTs are flattened once (flatten.py) and the variable-elimination loop (bayes_ne
 executed by hand-written gfx950 kernels behind the C-ABI of include/mibn.h.  There is no CPU
 fallback: without the HIP extension or without a gfx950 device `query` raises.
 
+`full_joint_dist` / `predict_proba` / `predict_log_proba` (bayes_net.py:398-465, 934-973; SURVEY.md section 8f rank
+1) ride on the same kernels: the joint is the posterior of all variables given no evidence, the likelihood of
+partially observed rows is the posterior of the observed columns given no evidence (variable elimination of the
+rest - so it also works where the reference's full joint would not fit).
+
 Out of scope here (use the reference for them): fit/partial_fit, sample,
-full_joint_dist/predict_proba, likelihood weighting and rejection sampling, graph drawing.
+likelihood weighting and rejection sampling, graph drawing.
 
 `accelerate(bn)` attaches the same backend to an *existing reference object* by replacing the two
 methods `query` dispatches to (bayes_net.py:848, 851-853); see INTEGRATION.md.
@@ -49,6 +54,50 @@ class Backend:
         if f.hints:
             self.engine.set_order_hints(np.stack(f.hints))
         self._anc = {}
+        self._presence = None
+        self._device = device
+        self._planner_only = planner_only
+
+    def presence_engine(self):
+        """A second engine over the same structure whose tables hold 1.0 where the sparse CPT has a row: its joint
+        is positive exactly on the rows of the reference's inner join (full_joint_dist(keep_zeros=True))."""
+        if self._presence is None:
+            f = self.flat
+            e = _capi.Engine(_default_device() if self._device is None else self._device, planner_only=self._planner_only)
+            e.set_network(f.card, f.scope_off, f.scope_vars, f.value_off, f.present)
+            self._presence = e
+        return self._presence
+
+    def marginal(self, names, engine=None):
+        """Dense C-order table P(names) with no evidence (all other variables eliminated)."""
+        q, _, _ = self.encode(names, {})
+        eng = self.engine if engine is None else engine
+        # every CPT takes part (bayes_net.py:460): no pruning to the ancestors - with sparse CPTs a barren node
+        # does not sum to 1
+        eng.set_option("prune", 0)
+        try:
+            return eng.query_fixed([q], np.zeros((1, 0), np.int32), np.zeros((1, 0), np.int32))[0]
+        finally:
+            eng.set_option("prune", 1)
+
+    def joint_series(self, names, keep_zeros=False):
+        """Series over the sorted `names` like `full_joint_dist` builds it (bayes_net.py:460-465): sorted levels, sorted
+        rows, zero rows dropped unless keep_zeros (then: the rows present in every CPT)."""
+        f = self.flat
+        ids = [f.id[n] for n in names]
+        dense = self.marginal(names)
+        if keep_zeros:
+            mask = self.marginal(names, self.presence_engine()) > 0
+        else:
+            mask = dense > 0
+        keep = np.flatnonzero(mask)
+        if len(ids) == 1:
+            idx = f.dom_index[ids[0]][keep].rename(names[0])
+        else:
+            codes = np.unravel_index(keep, [int(f.card[v]) for v in ids])
+            idx = pd.MultiIndex(levels=[f.dom_index[v] for v in ids], codes=list(codes), names=list(names),
+                                verify_integrity=False)
+        return pd.Series(dense[keep], index=idx)
 
     @staticmethod
     def fingerprint_of(bn):
@@ -322,12 +371,48 @@ class BayesNet:
             event[k] = v
         return pd.Series(event)
 
+    # ---- the joint and likelihoods (bayes_net.py:398-465, 934-973) -----------------
+    def _all_names(self):
+        names = []
+        for P in self.P.values():
+            for n in (P.index.names if P.index.names[0] is not None else [P.name]):
+                if n not in names:
+                    names.append(n)
+        return sorted(names)
+
+    def full_joint_dist(self, event: dict = None, keep_zeros=False) -> pd.Series:
+        """The normalised product of all CPTs (bayes_net.py:460-465; like the reference, `event` is accepted and
+        ignored).  On the device it is the posterior of all variables given no evidence."""
+        names = self._all_names()
+        fjd = self.backend.joint_series(names, keep_zeros=keep_zeros)
+        fjd.name = f"P({', '.join(names)})"
+        return fjd
+
+    def predict_proba(self, X):
+        """Likelihood of one sample (dict -> float) or of the rows of a DataFrame (bayes_net.py:934-962).  The
+        reference marginalises its full joint onto the observed columns; here the unobserved variables are
+        eliminated on the device, which is the same table.  As in the reference, a single observed column returns
+        that column's marginal (not indexed by the rows), and a row of probability zero raises KeyError."""
+        if isinstance(X, dict):
+            return self.predict_proba(pd.DataFrame([X])).iloc[0]
+        names = self._all_names()
+        observed = [n for n in names if n in set(X.columns)]
+        fjd = self.backend.joint_series(observed)
+        fjd.name = f"P({', '.join(names)})"
+        if len(observed) > 1:
+            return fjd[pd.MultiIndex.from_frame(X[observed])]
+        return fjd
+
+    def predict_log_proba(self, X):
+        """bayes_net.py:964-973."""
+        return np.log(self.predict_proba(X))
+
     # ---- out of scope ---------------------------------------------------------------------------
     def _out_of_scope(self, *a, **k):
         raise NotImplementedError("outside the MI355X hot path (SURVEY.md section 8f); "
                                   "use the reference implementation")
 
-    fit = partial_fit = sample = full_joint_dist = predict_proba = predict_log_proba = _out_of_scope
+    fit = partial_fit = sample = _out_of_scope
 
 
 def accelerate(bn, device=None):
@@ -335,7 +420,8 @@ def accelerate(bn, device=None):
 
     Replaces the two bound methods `BayesNet.query` dispatches to - `_variable_elimination`
     (bayes_net.py:848) and `_gibbs_sampling` (851-853) - and leaves `query`'s own post-processing
-    (869-875) and `impute` (877-908) untouched, so naming / sorting stay byte-identical.
+    (869-875) and `impute` (877-908) untouched, so naming / sorting stay byte-identical; also replaces
+    `full_joint_dist` (398-465), on which the reference's `predict_proba` / `predict_log_proba` build.
     """
     state = {"backend": None}
 
@@ -352,7 +438,14 @@ def accelerate(bn, device=None):
         return backend().gibbs_sampling(*query, event=event, n_iterations=n_iterations,
                                         seed=getattr(self, "seed", None) or 0)
 
+    def full_joint_dist(self, event: dict = None, keep_zeros=False):  # bayes_net.py:398-465
+        names = sorted({n for P in self.P.values() for n in P.index.names})
+        fjd = backend().joint_series(names, keep_zeros=keep_zeros)
+        fjd.name = f"P({', '.join(names)})"
+        return fjd
+
     bn._variable_elimination = types.MethodType(_variable_elimination, bn)
     bn._gibbs_sampling = types.MethodType(_gibbs_sampling, bn)
+    bn.full_joint_dist = types.MethodType(full_joint_dist, bn)  # predict_proba / predict_log_proba build on it (952)
     bn._mibn_backend = backend
     return bn

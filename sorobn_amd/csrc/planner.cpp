@@ -903,6 +903,8 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
     rel.nw = qb.nw = eb.nw = net.nw;
     for (int i = 0; i < rq.nq; ++i) { qb.set(rq.qvars[i]); rel.set(rq.qvars[i]); rel.or_(net.anc[rq.qvars[i]]); }
     for (int i = 0; i < rq.ne; ++i) { eb.set(rq.evars[i]); rel.set(rq.evars[i]); rel.or_(net.anc[rq.evars[i]]); }
+    if (!net.prune)  // full_joint_dist / predict_proba multiply *all* CPTs (bayes_net.py:460): with sparse or
+        for (int v = 0; v < net.n_vars; ++v) rel.set(v);  // unnormalised CPTs a barren node does not sum to 1
     Bits hidden = rel;
     hidden.andnot(qb);
     hidden.andnot(eb);

@@ -59,6 +59,7 @@ struct Network {
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
     int tile_h = 0;          // hi iterations per tile; 0 = sized for kTileBytes of traffic per tile
     double minfill_above = 2e7;  // run the greedy min-fill order search only if the sweep orders cost more bytes than this
+    int prune = 1;           // restrict a request to the ancestors of its query / evidence variables (bayes_net.py:763-765)
     int outer = 1;           // OUTER form (fp64 MFMA) for products of two big tables
     int fuse = 1;            // eliminate two consecutive variables in one FIBER step when the first result would be a big table
 

@@ -18,7 +18,7 @@ import pandas as pd
 
 class FlatNetwork:
     __slots__ = ("names", "id", "domains", "dom_index", "card", "scope", "scope_off",
-                 "scope_vars", "value_off", "values", "hints", "missing", "parents")
+                 "scope_vars", "value_off", "values", "present", "hints", "missing", "parents")
 
     def code_of(self, var_id, label):
         """Evidence labels match by Python equality (`get_level_values(var) == val`,
@@ -85,15 +85,17 @@ def flatten(bn) -> FlatNetwork:
         dom_index.append(pd.Index(dom, name=node) if dom else pd.Index([], name=node))
 
     card = np.array([max(1, len(d)) for d in domains], np.int32)
-    scope_off, scope_vars, value_off, chunks = [0], [], [0], []
+    scope_off, scope_vars, value_off, chunks, pchunks = [0], [], [0], [], []
     for v in range(len(names)):
         if v in missing:
             sc = [v]
             dense = np.ones(int(card[v]), np.float64)  # never read: queries touching it raise KeyError
+            pres = dense
         else:
             sc = scopes[v]
             shape = [int(card[u]) for u in sc]
             dense = np.zeros(int(np.prod(shape, dtype=np.int64)), np.float64)
+            pres = np.zeros(len(dense), np.float64)  # 1.0 where the sparse CPT has a row (even with p = 0)
             if len(tables[v]):
                 flat = np.zeros(len(tables[v]), np.int64)
                 for u, col in zip(sc, level_values[v]):
@@ -104,9 +106,11 @@ def flatten(bn) -> FlatNetwork:
                                           for x in col.tolist()], np.int64)
                     flat = flat * int(card[u]) + codes
                 dense[flat] = tables[v]
+                pres[flat] = 1.0
         scope_vars += sc
         scope_off.append(len(scope_vars))
         chunks.append(dense)
+        pchunks.append(pres)
         value_off.append(value_off[-1] + len(dense))
 
     fn = FlatNetwork()
@@ -120,6 +124,7 @@ def flatten(bn) -> FlatNetwork:
     fn.scope_vars = np.array(scope_vars, np.int32)
     fn.value_off = np.array(value_off, np.int64)
     fn.values = np.concatenate(chunks) if chunks else np.zeros(0, np.float64)
+    fn.present = np.concatenate(pchunks) if pchunks else np.zeros(0, np.float64)
     fn.missing = missing
     fn.parents = [[u for u in sc if u != v] for v, sc in enumerate(fn.scope)]
     # elimination-order hint: rank by sorted name (row-major on zero-padded grid ids; the order the

@@ -173,6 +173,45 @@ def impute_fixture():
     netspec.save(os.path.join(HERE, "impute.json"), out)
 
 
+def joint_fixture():
+    """full_joint_dist (both keep_zeros settings), predict_proba / predict_log_proba for
+    DataFrames over all / some / one column and for dicts (bayes_net.py:398-465, 934-973)."""
+    out = []
+    nets = {"alarm": sorobn.examples.alarm(), "asia": sorobn.examples.asia(), "sprinkler": sorobn.examples.sprinkler(),
+            "grades": sorobn.examples.grades()}
+    for seed in (0, 3, 5):  # sparse CPTs with zeros and missing rows
+        spec = netspec.random_dag_spec(seed, n_nodes=6, labels="str" if seed == 3 else "int")
+        nets[f"dag{seed}"] = (spec, netspec.build(spec, sorobn.BayesNet, wrap=refload.HashedName))
+    for name, bn in nets.items():
+        if isinstance(bn, tuple):
+            spec, bn = bn
+            spec = dict(spec, name=name)
+        else:
+            spec = netspec.dump(bn, name)
+        entry = {"spec": spec, "fjd": series_to_json(bn.full_joint_dist()),
+                 "fjd_keep_zeros": series_to_json(bn.full_joint_dist(keep_zeros=True)), "predict": []}
+        fjd = bn.full_joint_dist()
+        names = [str(n) for n in fjd.index.names]
+        rng = np.random.default_rng(11)
+        rows = fjd.index.to_frame(index=False).iloc[rng.integers(0, len(fjd), 12)].reset_index(drop=True)
+        rows.columns = names
+        wrapn = (lambda n: refload.HashedName(n)) if name.startswith("dag") else (lambda n: n)
+        for cols in (names, names[:2], names[1:4], names[-1:]):
+            X = rows[list(cols)].copy()
+            X.columns = [wrapn(c) for c in cols]
+            res = bn.predict_proba(X)
+            lres = bn.predict_log_proba(X)
+            entry["predict"].append({"columns": list(cols), "rows": [[netspec._py(v) for v in r] for r in X.values.tolist()],
+                                     "expect": series_to_json(res),
+                                     "log_values_hex": [float(v).hex() for v in lres.tolist()]})
+        d = {wrapn(k): v for k, v in zip(names, rows.iloc[0].tolist())}
+        entry["predict_dict"] = {"sample": [[str(k), netspec._py(v)] for k, v in d.items()],
+                                 "expect_hex": float(bn.predict_proba(d)).hex()}
+        out.append(entry)
+        print("joint", name, len(fjd), flush=True)
+    netspec.save(os.path.join(HERE, "joint.json"), out)
+
+
 def dags_fixture():
     nets = []
     for seed in range(24):
@@ -276,7 +315,7 @@ if __name__ == "__main__":
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide", "many"]
+    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide", "many", "joint"]
     if "examples" in todo:
         examples_fixture()
     if "impute" in todo:
@@ -289,3 +328,5 @@ if __name__ == "__main__":
         wide_fixture()
     if "many" in todo:
         many_nodes_fixture()
+    if "joint" in todo:
+        joint_fixture()

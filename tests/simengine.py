@@ -4,6 +4,7 @@ Lets `pytest -m "not gpu"` exercise the real host logic - flatten.py, Backend.en
 posterior_series, BayesNet.query / impute post-processing and the C++ planner - in the GPU-less
 build container.  Never imported by the product package.
 """
+import copy
 import ctypes as C
 import os
 import subprocess
@@ -29,6 +30,7 @@ def lib():
         L.plan_sim_set_small_cells.argtypes = [C.c_int]
         L.plan_sim_set_tiling.argtypes = [C.c_int, C.c_int]
         L.plan_sim_set_fuse.argtypes = [C.c_int]
+        L.plan_sim_set_prune.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -40,6 +42,7 @@ class SimEngine:
         self.small_cells = small_cells  # lower it to force FIBER steps on small networks
         self.tiling = tiling            # (big_iters, tile_h): lower them to force tiled levels on small networks
         self.fuse = fuse                # joint elimination of two variables per FIBER step
+        self.prune = 1                  # 0: multiply every CPT (full_joint_dist / predict_proba)
         self.f = flat
         self.card = flat.card
         self.last_stats = None
@@ -59,6 +62,7 @@ class SimEngine:
         L.plan_sim_set_small_cells(int(self.small_cells))
         L.plan_sim_set_tiling(int(self.tiling[0]), int(self.tiling[1]))
         L.plan_sim_set_fuse(int(self.fuse))
+        L.plan_sim_set_prune(int(self.prune))
         rc = L.plan_sim_query(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64),
                               p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
                               p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
@@ -68,6 +72,12 @@ class SimEngine:
             raise RuntimeError(f"plan_sim_query rc={rc}: {L.plan_sim_error().decode()}")
         self.last_stats = stats
         return out
+
+    def set_option(self, name, value):
+        if name == "prune":
+            self.prune = int(value)
+        else:
+            raise KeyError(name)
 
     def query_fixed(self, qvars, evars, ecodes):
         return np.stack([self._one(q, e, c) for q, e, c in zip(qvars, evars, ecodes)])
@@ -86,6 +96,11 @@ def sim_backend(bn, small_cells=1024, tiling=(4096, 0), fuse=1):
     b.fingerprint = Backend.fingerprint_of(bn)
     b.engine = SimEngine(b.flat, small_cells, tiling, fuse)
     b._anc = {}
+    # the presence network (full_joint_dist(keep_zeros=True)): same structure, tables = 1.0 where a CPT row exists
+    pf = copy.copy(b.flat)
+    pf.values = b.flat.present
+    b._presence = SimEngine(pf, small_cells, tiling, fuse)
+    b._device, b._planner_only = None, True
     return b
 
 
