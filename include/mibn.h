@@ -158,6 +158,24 @@ int mibn_gibbs(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const
                const int32_t *e_codes, const int32_t *cycle, int64_t n_chains, int64_t n_iterations,
                uint64_t seed, int64_t *counts);
 
+/*
+ * Forward (ancestral) sampling and the two approximate algorithms built on it.
+ *   mibn_sample          BayesNet.sample(n, init) / _forward_sample (bayes_net.py:518-575): n_samples joint samples,
+ *                        states[sample * n_vars + v] = label code of variable v; `init` variables are clamped
+ *   mibn_sampling_query  mode MIBN_REJECTION = _rejection_sampling (577-619): counts[cell] = samples that agree with
+ *                        the event, per joint query state; mode MIBN_LIKELIHOOD = _llh_weighting (621-663): the event
+ *                        is clamped, weight_sum[cell] = sum of the sample likelihoods (the product of P(value |
+ *                        parents) over ALL nodes, as the reference computes it) and counts[cell] = samples per state;
+ *                        the reference's answer is (weight_sum / counts) normalised
+ * Random stream: Philox4x32-10 keyed by (seed, sample, variable); statistical parity only (see mibn_gibbs).
+ */
+#define MIBN_REJECTION 1
+#define MIBN_LIKELIHOOD 2
+int mibn_sample(mibn_t *h, int64_t n_samples, int32_t n_init, const int32_t *init_vars, const int32_t *init_codes,
+                uint64_t seed, uint8_t *states);
+int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                        const int32_t *e_codes, int64_t n_samples, uint64_t seed, double *weight_sum, int64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

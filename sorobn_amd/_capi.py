@@ -17,7 +17,7 @@ SYMBOLS = [
     "mibn_set_network", "mibn_set_order_hints", "mibn_query_batch", "mibn_last_stats",
     "mibn_plan_stats", "mibn_create_planner", "mibn_set_option", "mibn_gibbs",
     "mibn_last_kernel_stats", "mibn_submit_batch", "mibn_wait", "mibn_drain", "mibn_total_stats",
-    "mibn_total_kernel_stats",
+    "mibn_total_kernel_stats", "mibn_sample", "mibn_sampling_query",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
@@ -73,6 +73,8 @@ def lib():
         L.mibn_drain.argtypes = [vp]
         L.mibn_total_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mibn_total_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
+        L.mibn_sample.argtypes = [vp, C.c_int64, C.c_int32, i32p, i32p, C.c_uint64, C.POINTER(C.c_uint8)]
+        L.mibn_sampling_query.argtypes = [vp, C.c_int32, C.c_int32, i32p, C.c_int32, i32p, i32p, C.c_int64, C.c_uint64, f64p, i64p]
         L.mibn_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mibn_last_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_plan_stats.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, C.POINTER(Stats)]
@@ -267,3 +269,26 @@ class Engine:
                                        int(n_iterations), int(seed) & (2**64 - 1),
                                        _p(counts, C.c_int64)))
         return counts
+
+    def sample(self, n_samples, init_vars=(), init_codes=(), seed=0):
+        """Forward samples: uint8 codes [n_samples, n_vars]."""
+        iv, ic = _i32(init_vars), _i32(init_codes)
+        out = np.zeros((int(n_samples), len(self.card)), np.uint8)
+        iv_ = iv if len(iv) else np.zeros(1, np.int32)
+        ic_ = ic if len(ic) else np.zeros(1, np.int32)
+        self._check(self._L.mibn_sample(self._h, int(n_samples), len(iv), _p(iv_, C.c_int32), _p(ic_, C.c_int32),
+                                        int(seed) & (2**64 - 1), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def sampling_query(self, mode, qvars, evars, ecodes, n_samples, seed=0):
+        """mode 1 = rejection, 2 = likelihood weighting -> (weight_sum, counts) per joint query state."""
+        q, e, c = _i32(qvars), _i32(evars), _i32(ecodes)
+        e_ = e if len(e) else np.zeros(1, np.int32)
+        c_ = c if len(c) else np.zeros(1, np.int32)
+        cells = int(np.prod(self.card[q].astype(np.int64)))
+        wsum = np.zeros(cells, np.float64)
+        counts = np.zeros(cells, np.int64)
+        self._check(self._L.mibn_sampling_query(self._h, int(mode), len(q), _p(q, C.c_int32), len(e), _p(e_, C.c_int32),
+                                                _p(c_, C.c_int32), int(n_samples), int(seed) & (2**64 - 1),
+                                                _p(wsum, C.c_double), _p(counts, C.c_int64)))
+        return wsum, counts

@@ -12,8 +12,11 @@ fallback: without the HIP extension or without a gfx950 device `query` raises.
 partially observed rows is the posterior of the observed columns given no evidence (variable elimination of the
 rest - so it also works where the reference's full joint would not fit).
 
-Out of scope here (use the reference for them): fit/partial_fit, sample,
-likelihood weighting and rejection sampling, graph drawing.
+`sample`, `query(algorithm="rejection" / "likelihood")` (bayes_net.py:518-663; section 8f rank 2) run on a forward-
+sampling kernel (one sample per lane); like Gibbs their parity is statistical (the reference's stream needs `vose`).
+
+Out of scope here (use the reference for them): fit/partial_fit, Chow-Liu, graph
+drawing.
 
 `accelerate(bn)` attaches the same backend to an *existing reference object* by replacing the two
 methods `query` dispatches to (bayes_net.py:848, 851-853); see INTEGRATION.md.
@@ -186,6 +189,48 @@ class Backend:
         dense = counts.astype(np.float64) / float(max(1, n_chains * n_iterations))
         return self.posterior_series(query, dense)
 
+    # ---- forward sampling and the algorithms built on it ---------------------------
+    def _cells_series(self, query, values, present):
+        """Series over the joint query states `present` (flat C-order cell ids), like a pandas groupby builds it."""
+        f = self.flat
+        ids = [f.id[n] for n in query]
+        keep = np.flatnonzero(present)
+        if len(ids) == 1:
+            idx = f.dom_index[ids[0]][keep].rename(query[0])
+        else:
+            codes = np.unravel_index(keep, [int(f.card[v]) for v in ids])
+            idx = pd.MultiIndex(levels=[f.dom_index[v] for v in ids], codes=list(codes), names=list(query),
+                                verify_integrity=False)
+        return pd.Series(np.asarray(values, np.float64)[keep], index=idx)
+
+    def rejection_sampling(self, *query, event, n_iterations, seed=0):
+        """bayes_net.py:577-619: the share of each query state among the forward samples that agree with the event."""
+        q, ev, codes = self.encode(query, event)
+        _, counts = self.engine.sampling_query(1, q, ev, codes, n_iterations, seed=seed)
+        total = counts.sum()
+        return self._cells_series(query, counts / float(total) if total else counts.astype(np.float64), counts > 0)
+
+    def likelihood_weighting(self, *query, event, n_iterations, seed=0):
+        """bayes_net.py:621-663: per query state the mean likelihood of the samples drawn with the event clamped,
+        normalised (the reference's estimator, product of P(value | parents) over all nodes)."""
+        q, ev, codes = self.encode(query, event)
+        if any(c < 0 for c in codes):  # P.get(value, 0) == 0 for a label outside the domain: every likelihood is 0
+            raise ValueError("likelihood weighting: an event label is outside the variable's domain")
+        wsum, counts = self.engine.sampling_query(2, q, ev, codes, n_iterations, seed=seed)
+        mean = np.divide(wsum, counts, out=np.zeros_like(wsum), where=counts > 0)
+        s = mean.sum()
+        return self._cells_series(query, mean / s if s > 0 else mean, counts > 0)
+
+    def forward_samples(self, n, init, seed=0):
+        """bayes_net.py:518-575: n joint samples as a DataFrame of labels (columns in variable-id = `nodes` order)."""
+        f = self.flat
+        iv = [self.var_id(k) for k in init]
+        ic = [f.code_of(v, lab) for v, lab in zip(iv, init.values())]
+        if any(c < 0 for c in ic):
+            raise ValueError("sample: an init label is outside the variable's domain")
+        codes = self.engine.sample(n, iv, ic, seed=seed)
+        return pd.DataFrame({name: np.asarray(f.dom_index[v])[codes[:, v]] for v, name in enumerate(f.names)})
+
 
 class BayesNet:
     """Bayesian network with an MI355X exact-inference backend.
@@ -308,6 +353,28 @@ class BayesNet:
         return self.backend.gibbs_sampling(*query, event=event, n_iterations=n_iterations,
                                            n_chains=n_chains, seed=self.seed or 0)
 
+    def _next_seed(self):
+        """The reference advances one `random.Random(seed)` per object (bayes_net.py:289): successive sampling
+        calls see different streams, the same sequence of calls on an equally seeded object repeats."""
+        self._draws = getattr(self, "_draws", 0) + 1
+        return ((self.seed or 0) * 0x9E3779B97F4A7C15 + self._draws) & (2**64 - 1)
+
+    def _rejection_sampling(self, *query, event, n_iterations):
+        return self.backend.rejection_sampling(*query, event=event, n_iterations=n_iterations, seed=self._next_seed())
+
+    def _llh_weighting(self, *query, event, n_iterations):
+        return self.backend.likelihood_weighting(*query, event=event, n_iterations=n_iterations, seed=self._next_seed())
+
+    def sample(self, n=1, init: dict = None, method="forward"):
+        """Forward (ancestral) samples, bayes_net.py:550-575: a Series for n == 1, else a DataFrame with sorted
+        columns; `init` forces variables to given values."""
+        if method != "forward":
+            raise ValueError("Unknown method, must be one of: forward")
+        df = self.backend.forward_samples(max(1, n), init or {}, seed=self._next_seed())
+        if n > 1:
+            return df.sort_index(axis="columns")
+        return df.iloc[0].rename(None)
+
     # ---- public API (bayes_net.py:796-908) ------------------------------------------------------
     @staticmethod
     def _check_request(query, event):
@@ -328,9 +395,9 @@ class BayesNet:
     def query(self, *query, event: dict, algorithm="exact", n_iterations=100, n_chains=1) -> pd.Series:
         """Answer a probabilistic query; same contract as the reference (bayes_net.py:796-875).
 
-        `algorithm`: "exact" (variable elimination on the GPU) or "gibbs" (GPU chains; `n_chains` is
-        an extension, default 1 like the reference).  "likelihood" and "rejection" are not part of
-        this backend and raise NotImplementedError; anything else raises the reference's ValueError.
+        `algorithm`: "exact" (variable elimination on the GPU), "gibbs" (GPU chains; `n_chains` is an
+        extension, default 1 like the reference), "rejection" or "likelihood" (GPU forward sampling, one sample
+        per lane); anything else raises the reference's ValueError.
         """
         self._check_request(query, event)
         if algorithm == "exact":
@@ -338,10 +405,10 @@ class BayesNet:
         elif algorithm == "gibbs":
             answer = self._gibbs_sampling(*query, event=event, n_iterations=n_iterations,
                                           n_chains=n_chains)
-        elif algorithm in ("likelihood", "rejection"):
-            raise NotImplementedError(
-                f"algorithm={algorithm!r} is outside the MI355X hot path (SURVEY.md section 8f); "
-                "use the reference implementation for it")
+        elif algorithm == "rejection":
+            answer = self._rejection_sampling(*query, event=event, n_iterations=n_iterations)
+        elif algorithm == "likelihood":
+            answer = self._llh_weighting(*query, event=event, n_iterations=n_iterations)
         else:
             raise ValueError("Unknown algorithm, must be one of: exact, gibbs, likelihood, "
                              + "rejection")
@@ -412,7 +479,7 @@ class BayesNet:
         raise NotImplementedError("outside the MI355X hot path (SURVEY.md section 8f); "
                                   "use the reference implementation")
 
-    fit = partial_fit = sample = _out_of_scope
+    fit = partial_fit = _out_of_scope
 
 
 def accelerate(bn, device=None):

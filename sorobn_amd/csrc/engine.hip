@@ -15,6 +15,7 @@
 
 #include "../../include/mibn.h"
 #include "gibbs_kernel.hip.h"
+#include "sample_kernel.hip.h"
 #include "planner.h"
 #include "ve_kernel.hip.h"
 
@@ -633,4 +634,42 @@ extern "C" int mibn_gibbs(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t
     HIP_TRY(h, hipSetDevice(h->device));
     return gibbs_run(h->net, h->d_pool, h->stream, n_q, q_vars, n_e, e_vars, e_codes, cycle, n_chains, n_iterations, seed,
                      counts, h->err, h->stats.kernel_ms);
+}
+
+extern "C" int mibn_sample(mibn_t *h, int64_t n_samples, int32_t n_init, const int32_t *init_vars, const int32_t *init_codes,
+                           uint64_t seed, uint8_t *states) {
+    if (!h || n_samples < 0 || !states || (n_init && (!init_vars || !init_codes))) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    if (n_samples == 0) return MIBN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return sample_run(h->net, h->d_pool, h->stream, kSampleMode, 0, nullptr, n_init, init_vars, init_codes, 0, nullptr, nullptr,
+                      n_samples, seed, states, nullptr, nullptr, h->err);
+}
+
+extern "C" int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                                   const int32_t *e_codes, int64_t n_samples, uint64_t seed, double *weight_sum, int64_t *counts) {
+    if (!h || !q_vars || !counts || n_samples < 0 || (mode != MIBN_REJECTION && mode != MIBN_LIKELIHOOD)) return MIBN_E_ARG;
+    if (mode == MIBN_LIKELIHOOD && !weight_sum) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    Request rq;
+    rq.nq = n_q; rq.qvars = q_vars; rq.ne = n_e; rq.evars = e_vars;
+    std::string e = validate_request(h->net, rq);
+    if (!e.empty()) { h->err = e; return MIBN_E_ARG; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (mode == MIBN_LIKELIHOOD)  // the event is clamped (bayes_net.py:646)
+        return sample_run(h->net, h->d_pool, h->stream, kLikelihoodMode, n_q, q_vars, n_e, e_vars, e_codes, 0, nullptr, nullptr,
+                          n_samples, seed, nullptr, weight_sum, counts, h->err);
+    // rejection: nothing is clamped, samples that disagree with the event are dropped (bayes_net.py:604-612);
+    // a label outside the domain can never be drawn
+    for (int i = 0; i < n_e; ++i)
+        if (e_codes[i] < 0 || e_codes[i] >= h->net.card[e_vars[i]]) {
+            int64_t cells = 1;
+            for (int k = 0; k < n_q; ++k) cells *= h->net.card[q_vars[k]];
+            for (int64_t c = 0; c < cells; ++c) counts[c] = 0;
+            return MIBN_OK;
+        }
+    return sample_run(h->net, h->d_pool, h->stream, kRejectionMode, n_q, q_vars, 0, nullptr, nullptr, n_e, e_vars, e_codes, n_samples,
+                      seed, nullptr, nullptr, counts, h->err);
 }

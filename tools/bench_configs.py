@@ -72,6 +72,20 @@ out["8f_grid10x10_predict_proba_3_columns_100k_rows"] = {
     "alg_MB": grid.backend.engine.stats()["alg_bytes"] / 1e6,
     "note": "the reference would need the 4^100-row full joint; here the 97 unobserved variables are eliminated on the device"}
 
+# ---- forward sampling, rejection sampling, likelihood weighting (Asia)
+for nsamp in (1_000_000, 16_000_000):
+    t0 = time.perf_counter()
+    codes = eng.sample(nsamp, seed=3)
+    out[f"8f_asia_sample_{nsamp}"] = {"ms": (time.perf_counter() - t0) * 1e3, "samples_per_s": nsamp / (time.perf_counter() - t0)}
+del codes
+for alg in ("rejection", "likelihood"):
+    bn.query("Lung cancer", event={"Smoker": True, "Dispnea": True}, algorithm=alg, n_iterations=1000)
+    t0 = time.perf_counter()
+    a = bn.query("Lung cancer", event={"Smoker": True, "Dispnea": True}, algorithm=alg, n_iterations=16_000_000)
+    out[f"8f_asia_{alg}_16M_samples"] = {"ms": (time.perf_counter() - t0) * 1e3, "samples_per_s": 16e6 / (time.perf_counter() - t0),
+                                       "answer": a.to_numpy().tolist()}
+out["8f_asia_exact_for_comparison"] = bn.query("Lung cancer", event={"Smoker": True, "Dispnea": True}).to_numpy().tolist()
+
 # ---- C5: Gibbs
 spec5 = netspec.grid_spec(5, 10, 8, seed=0)
 bn5 = netspec.build(spec5, sorobn_amd.BayesNet)
