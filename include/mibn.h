@@ -176,6 +176,19 @@ int mibn_sample(mibn_t *h, int64_t n_samples, int32_t n_init, const int32_t *ini
 int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
                         const int32_t *e_codes, int64_t n_samples, uint64_t seed, double *weight_sum, int64_t *counts);
 
+/*
+ * Grouped counting of label codes: the `X.groupby([*parents, node]).size()` of
+ * BayesNet.partial_fit (bayes_net.py:467-510) and the pairwise `X.groupby([u, v]).size()` of structure.chow_liu
+ * (structure.py:33-45).  No network needed.
+ *   codes[n_cols * n_rows]    column-major label codes (codes[col * n_rows + row]), code < card[col] <= 256
+ *   scope_off[n_tables + 1], scope_cols[]   CSR: the columns of table t
+ *   counts_off[n_tables + 1], counts[]      dense C-order contingency table of every table (last column fastest);
+ *                             a table may have at most 16384 cells
+ */
+int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, const int32_t *card,
+                      int32_t n_tables, const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off,
+                      int64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

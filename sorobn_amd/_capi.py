@@ -17,7 +17,7 @@ SYMBOLS = [
     "mibn_set_network", "mibn_set_order_hints", "mibn_query_batch", "mibn_last_stats",
     "mibn_plan_stats", "mibn_create_planner", "mibn_set_option", "mibn_gibbs",
     "mibn_last_kernel_stats", "mibn_submit_batch", "mibn_wait", "mibn_drain", "mibn_total_stats",
-    "mibn_total_kernel_stats", "mibn_sample", "mibn_sampling_query",
+    "mibn_total_kernel_stats", "mibn_sample", "mibn_sampling_query", "mibn_count_tables",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
@@ -75,6 +75,7 @@ def lib():
         L.mibn_total_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_sample.argtypes = [vp, C.c_int64, C.c_int32, i32p, i32p, C.c_uint64, C.POINTER(C.c_uint8)]
         L.mibn_sampling_query.argtypes = [vp, C.c_int32, C.c_int32, i32p, C.c_int32, i32p, i32p, C.c_int64, C.c_uint64, f64p, i64p]
+        L.mibn_count_tables.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_uint8), i32p, C.c_int32, i64p, i32p, i64p, i64p]
         L.mibn_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mibn_last_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_plan_stats.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, C.POINTER(Stats)]
@@ -292,3 +293,20 @@ class Engine:
                                                 _p(c_, C.c_int32), int(n_samples), int(seed) & (2**64 - 1),
                                                 _p(wsum, C.c_double), _p(counts, C.c_int64)))
         return wsum, counts
+
+    def count_tables(self, codes, card, tables):
+        """codes: uint8 [n_rows, n_cols] (any layout; sent column-major); tables: list of column-index tuples ->
+        list of dense int64 contingency tables shaped by the cards of their columns."""
+        codes = np.asfortranarray(np.asarray(codes, dtype=np.uint8))
+        n_rows, n_cols = codes.shape
+        card = _i32(card)
+        scope_off = np.concatenate([[0], np.cumsum([len(t) for t in tables])]).astype(np.int64)
+        scope_cols = _i32([c for t in tables for c in t]) if len(tables) else np.zeros(0, np.int32)
+        cells = [int(np.prod(card[list(t)].astype(np.int64))) for t in tables]
+        counts_off = np.concatenate([[0], np.cumsum(cells)]).astype(np.int64)
+        counts = np.zeros(max(1, int(counts_off[-1])), np.int64)
+        sc = scope_cols if len(scope_cols) else np.zeros(1, np.int32)
+        self._check(self._L.mibn_count_tables(
+            self._h, n_rows, n_cols, codes.ctypes.data_as(C.POINTER(C.c_uint8)), _p(card if len(card) else np.zeros(1, np.int32), C.c_int32),
+            len(tables), _p(scope_off, C.c_int64), _p(sc, C.c_int32), _p(counts_off, C.c_int64), _p(counts, C.c_int64)))
+        return [counts[a:b].reshape([int(card[c]) for c in t]) for t, a, b in zip(tables, counts_off[:-1], counts_off[1:])]

@@ -15,8 +15,10 @@ rest - so it also works where the reference's full joint would not fit).
 `sample`, `query(algorithm="rejection" / "likelihood")` (bayes_net.py:518-663; section 8f rank 2) run on a forward-
 sampling kernel (one sample per lane); like Gibbs their parity is statistical (the reference's stream needs `vose`).
 
-Out of scope here (use the reference for them): fit/partial_fit, Chow-Liu, graph
-drawing.
+`fit` / `partial_fit` (467-516; rank 3) and `sorobn_amd.structure.chow_liu` (structure.py:9-52; rank 4) count their
+contingency tables with one launch of the count kernel (learning.py).
+
+Out of scope: graph drawing, GUI, CLI.
 
 `accelerate(bn)` attaches the same backend to an *existing reference object* by replacing the two
 methods `query` dispatches to (bayes_net.py:848, 851-853); see INTEGRATION.md.
@@ -474,12 +476,14 @@ class BayesNet:
         """bayes_net.py:964-973."""
         return np.log(self.predict_proba(X))
 
-    # ---- out of scope ---------------------------------------------------------------------------
-    def _out_of_scope(self, *a, **k):
-        raise NotImplementedError("outside the MI355X hot path (SURVEY.md section 8f); "
-                                  "use the reference implementation")
+    # ---- SURVEY.md section 8f rank 3: parameter learning (bayes_net.py:467-516) ----------------------------------
+    def partial_fit(self, X: pd.DataFrame):
+        from . import learning
+        return learning.partial_fit(self, X)
 
-    fit = partial_fit = _out_of_scope
+    def fit(self, X: pd.DataFrame):
+        from . import learning
+        return learning.fit(self, X)
 
 
 def accelerate(bn, device=None):

@@ -1,0 +1,149 @@
+// Grouped counting of label codes on gfx950 - the arithmetic under the parameter- and structure-learning rows of
+// `X.groupby([*parents, node]).size()` of BayesNet.partial_fit (sorobn/bayes_net.py:467-510,
+// rank 3) and the pairwise `X.groupby([u, v]).size()` / `value_counts` of structure.chow_liu (structure.py:33-45,
+// rank 4).  Input: a column-major matrix of label codes (uint8, codes[col * n_rows + row]) and a list of *tables*,
+// each a tuple of columns; output: for every table the dense C-order contingency table (last column fastest).
+//
+// The tables are packed into groups whose cells fit one workgroup's LDS histogram (64 KiB of uint32).  A workgroup
+// (group g, row block b) walks its rows - consecutive lanes read consecutive rows of a column, 256 B per wave load,
+// the columns stay in L1 across the tables of the group - adds into LDS with ds_add_u32, and flushes its non-zero
+// cells with one 64-bit global atomic each.  Bound by LDS atomics (one per row and table), not by HBM: the code
+// matrix is read once per group.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mibn.h"
+
+namespace mibn {
+
+constexpr int kCountLdsCells = 16384;  // 64 KiB of uint32 per workgroup
+
+struct CountArgs {
+    const uint8_t *codes;        // [n_cols][n_rows]
+    const int32_t *tbl_begin;    // per table: first entry in tbl_col / tbl_stride
+    const int32_t *tbl_col;      // flattened scopes
+    const int32_t *tbl_stride;   // C-order strides (cells) of every scope entry
+    const int32_t *tbl_lds;      // per table: offset inside its group's LDS histogram
+    const int64_t *tbl_out;      // per table: offset in `counts`
+    const int32_t *grp_begin;    // per group: [first table, last table)
+    unsigned long long *counts;
+    int64_t n_rows;
+    int32_t n_groups;
+};
+
+__global__ __launch_bounds__(256) void count_kernel(const CountArgs A) {
+    __shared__ unsigned int hist[kCountLdsCells];
+    const int g = blockIdx.y;
+    const int t0 = A.grp_begin[g], t1 = A.grp_begin[g + 1];
+    const int cells = A.tbl_lds[t1] - A.tbl_lds[t0];  // (tbl_lds has one entry past the last table, cumulative per group)
+    for (int i = threadIdx.x; i < cells; i += 256) hist[i] = 0u;
+    __syncthreads();
+    const int base = A.tbl_lds[t0];
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < A.n_rows; row += (int64_t)gridDim.x * 256) {
+        for (int t = t0; t < t1; ++t) {
+            int cell = A.tbl_lds[t] - base;
+            for (int k = A.tbl_begin[t]; k < A.tbl_begin[t + 1]; ++k)
+                cell += (int)A.codes[(int64_t)A.tbl_col[k] * A.n_rows + row] * A.tbl_stride[k];
+            atomicAdd(&hist[cell], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int lo = A.tbl_lds[t] - base, n = A.tbl_lds[t + 1] - A.tbl_lds[t];
+        for (int i = threadIdx.x; i < n; i += 256)
+            if (hist[lo + i]) atomicAdd(&A.counts[A.tbl_out[t] + i], (unsigned long long)hist[lo + i]);
+    }
+}
+
+// host driver; returns MIBN_* code.  scope_off[n_tables + 1] / scope_cols: CSR list of the tables' columns;
+// counts_off[n_tables + 1]: offsets of the dense tables in `counts` (must equal the running product of cards).
+inline int count_run(hipStream_t stream, int64_t n_rows, int32_t n_cols, const uint8_t *codes, const int32_t *card, int32_t n_tables,
+                     const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off, int64_t *counts,
+                     std::string &err) {
+    std::vector<int32_t> tbl_begin(n_tables + 1), tbl_col, tbl_stride, tbl_lds(n_tables + 1), grp_begin{0};
+    std::vector<int64_t> tbl_out(n_tables);
+    int32_t in_group = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        tbl_begin[t] = (int32_t)tbl_col.size();
+        int64_t cells = 1;
+        const int64_t a = scope_off[t], b = scope_off[t + 1];
+        std::vector<int32_t> strides((size_t)(b - a));
+        for (int64_t k = b - 1; k >= a; --k) {
+            const int c = scope_cols[k];
+            if (c < 0 || c >= n_cols) { err = "count: unknown column"; return MIBN_E_ARG; }
+            if (card[c] < 1 || card[c] > 256) { err = "count: cardinality outside 1..256"; return MIBN_E_LIMIT; }
+            strides[(size_t)(k - a)] = (int32_t)cells;
+            cells *= card[c];
+            if (cells > kCountLdsCells) { err = "count: a table has more than " + std::to_string(kCountLdsCells) + " cells"; return MIBN_E_LIMIT; }
+        }
+        if (counts_off[t + 1] - counts_off[t] != cells) { err = "count: counts_off does not match the table sizes"; return MIBN_E_ARG; }
+        for (int64_t k = a; k < b; ++k) { tbl_col.push_back(scope_cols[k]); tbl_stride.push_back(strides[(size_t)(k - a)]); }
+        if (in_group + cells > kCountLdsCells) { grp_begin.push_back(t); in_group = 0; }
+        in_group += (int32_t)cells;
+        tbl_out[t] = counts_off[t];
+    }
+    tbl_begin[n_tables] = (int32_t)tbl_col.size();
+    grp_begin.push_back(n_tables);
+    // cumulative LDS offsets: tbl_lds[t] grows monotonically across groups so that tbl_lds[t + 1] - tbl_lds[t] is
+    // always the table's size; a group's base is the offset of its first table
+    {
+        int64_t run = 0;
+        for (int t = 0; t < n_tables; ++t) {
+            const int64_t cells = counts_off[t + 1] - counts_off[t];
+            tbl_lds[t] = (int32_t)run;
+            run += cells;
+            if (run >= (1ll << 31)) { err = "count: too many cells in total"; return MIBN_E_LIMIT; }
+        }
+        tbl_lds[n_tables] = (int32_t)run;
+    }
+    const int n_groups = (int)grp_begin.size() - 1;
+    const int64_t total = counts_off[n_tables] - counts_off[0];
+    uint8_t *d_codes = nullptr;
+    int32_t *d_i32 = nullptr;
+    int64_t *d_i64 = nullptr;
+    unsigned long long *d_counts = nullptr;
+    std::vector<int32_t> pack;
+    auto put = [&](const std::vector<int32_t> &a) { size_t o = pack.size(); pack.insert(pack.end(), a.begin(), a.end()); return o; };
+    const size_t o_tb = put(tbl_begin), o_tc = put(tbl_col), o_ts = put(tbl_stride), o_tl = put(tbl_lds), o_gb = put(grp_begin);
+    auto fail = [&](hipError_t e) { err = std::string("count: ") + hipGetErrorString(e); hipFree(d_codes); hipFree(d_i32); hipFree(d_i64); hipFree(d_counts); return MIBN_E_HIP; };
+    hipError_t e;
+    const size_t code_bytes = (size_t)n_rows * (size_t)n_cols;
+    if ((e = hipMalloc(&d_codes, std::max<size_t>(16, code_bytes))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_i32, 4 * std::max<size_t>(1, pack.size()))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_i64, 8 * std::max<size_t>(1, tbl_out.size()))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_counts, 8 * std::max<int64_t>(1, total))) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(d_codes, codes, code_bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(d_i32, pack.data(), 4 * pack.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(d_i64, tbl_out.data(), 8 * tbl_out.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemsetAsync(d_counts, 0, 8 * std::max<int64_t>(1, total), stream)) != hipSuccess) return fail(e);
+    CountArgs A;
+    A.codes = d_codes;
+    A.tbl_begin = d_i32 + o_tb;
+    A.tbl_col = d_i32 + o_tc;
+    A.tbl_stride = d_i32 + o_ts;
+    A.tbl_lds = d_i32 + o_tl;
+    A.tbl_out = d_i64;
+    A.grp_begin = d_i32 + o_gb;
+    A.counts = d_counts - counts_off[0];
+    A.n_rows = n_rows;
+    A.n_groups = n_groups;
+    if (n_rows > 0 && n_tables > 0) {
+        const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_rows + 255) / 256, std::max(1, 256 * 8 / std::max(1, n_groups))));
+        hipLaunchKernelGGL(count_kernel, dim3(bx, (unsigned)n_groups), dim3(256), 0, stream, A);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+    }
+    std::vector<unsigned long long> host((size_t)std::max<int64_t>(1, total));
+    if ((e = hipMemcpyAsync(host.data(), d_counts, 8 * (size_t)std::max<int64_t>(1, total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
+    for (int64_t i = 0; i < total; ++i) counts[i] = (int64_t)host[(size_t)i];
+    hipFree(d_codes);
+    hipFree(d_i32);
+    hipFree(d_i64);
+    hipFree(d_counts);
+    return MIBN_OK;
+}
+
+}  // namespace mibn

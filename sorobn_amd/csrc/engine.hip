@@ -16,6 +16,7 @@
 #include "../../include/mibn.h"
 #include "gibbs_kernel.hip.h"
 #include "sample_kernel.hip.h"
+#include "count_kernel.hip.h"
 #include "planner.h"
 #include "ve_kernel.hip.h"
 
@@ -672,4 +673,15 @@ extern "C" int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const i
         }
     return sample_run(h->net, h->d_pool, h->stream, kRejectionMode, n_q, q_vars, 0, nullptr, nullptr, n_e, e_vars, e_codes, n_samples,
                       seed, nullptr, nullptr, counts, h->err);
+}
+
+extern "C" int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, const int32_t *card,
+                                 int32_t n_tables, const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off,
+                                 int64_t *counts) {
+    if (!h || n_rows < 0 || n_cols < 0 || n_tables < 0 || (n_rows && n_cols && !codes) || !card || !scope_off || !scope_cols ||
+        !counts_off || !counts)
+        return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return count_run(h->stream, n_rows, n_cols, codes, card, n_tables, scope_off, scope_cols, counts_off, counts, h->err);
 }

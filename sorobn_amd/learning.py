@@ -1,0 +1,153 @@
+"""Parameter and structure learning on grouped counts.
+
+The reference learns CPTs with `X.groupby([*parents, node]).size()` per node (sorobn/bayes_net.py:467-516) and a
+Chow-Liu tree from the pairwise `X.groupby([u, v]).size()` (sorobn/structure.py:9-63).  Here the label columns are
+factorised once on the host (sorted label domains -> uint8 codes) and *all* contingency tables of a call are counted
+by one launch of the count kernel (csrc/count_kernel.hip.h, `mibn_count_tables`); the small tables that come back are
+turned into the same pandas objects on the host.  No CPU fallback: counting needs a gfx950 device.
+"""
+import itertools
+
+import numpy as np
+import pandas as pd
+
+from . import _capi
+
+_engines = {}
+
+
+def counting_engine(device=None):
+    """One engine per device, used only for `count_tables` (no network attached)."""
+    from .bayes_net import _default_device
+    d = _default_device() if device is None else device
+    if d not in _engines:
+        _engines[d] = _capi.Engine(d)
+    return _engines[d]
+
+
+def encode_columns(X, columns):
+    """Label columns -> (uint8 codes [n_rows, n_cols], sorted label domains).  More than 256 labels per column is
+    outside what the count kernel (and any CPT one would learn) handles."""
+    codes = np.empty((len(X), len(columns)), np.uint8)
+    domains = []
+    for j, c in enumerate(columns):
+        dom = pd.Index(np.sort(pd.unique(X[c].to_numpy())))
+        if len(dom) > 256:
+            raise ValueError(f"column {c!r} has {len(dom)} distinct labels (max 256)")
+        codes[:, j] = dom.get_indexer(X[c].to_numpy())
+        domains.append(dom.rename(c))
+    return codes, domains
+
+
+def count_series(counts, domains, names):
+    """Dense contingency table -> the Series `groupby(names).size()` returns: one row per observed combination."""
+    flat = counts.reshape(-1)
+    keep = np.flatnonzero(flat)
+    if len(names) == 1:
+        return pd.Series(flat[keep], index=domains[0][keep].rename(names[0]))
+    codes = np.unravel_index(keep, counts.shape)
+    idx = pd.MultiIndex(levels=[d.rename(n) for d, n in zip(domains, names)], codes=list(codes), names=list(names),
+                        verify_integrity=False)
+    return pd.Series(flat[keep], index=idx)
+
+
+def grouped_counts(X, tables, device=None):
+    """`tables`: list of column-name tuples -> list of `X.groupby(list(t)).size()`-like Series, one GPU launch."""
+    columns = sorted({c for t in tables for c in t}, key=list(X.columns).index)
+    codes, domains = encode_columns(X, columns)
+    pos = {c: j for j, c in enumerate(columns)}
+    card = [len(d) for d in domains]
+    dense = counting_engine(device).count_tables(codes, card, [tuple(pos[c] for c in t) for t in tables])
+    return [count_series(d, [domains[pos[c]] for c in t], list(t)) for d, t in zip(dense, tables)]
+
+
+# ------------------------------------------------------------------------------------------------ rank 3: fit
+def partial_fit(bn, X):
+    """BayesNet.partial_fit (bayes_net.py:467-510): update every CPT with the rows of X.  Exact integer counts are
+    kept per node (`bn._counts`), so fitting in chunks gives bit-identical CPTs to fitting at once."""
+    if not hasattr(bn, "_counts") or bn._counts is None:
+        bn._counts = {}
+    tables = [tuple([*bn.parents[c], c]) for c in bn.parents] + [(r,) for r in bn.roots]
+    fresh = grouped_counts(X, tables, device=getattr(bn, "_device", None))
+    for names, new in zip(tables, fresh):
+        node = names[-1]
+        new = new.astype(np.float64)
+        if node in bn._counts:
+            counts = bn._counts[node].add(new, fill_value=0.0)
+        else:
+            counts = new
+            if bn.prior_count and len(names) > 1:
+                # the reference adds ONE pseudo-count for every combination of the values seen in this chunk, whatever
+                # prior_count is (bayes_net.py:480-488)
+                combos = pd.MultiIndex.from_tuples(list(itertools.product(*[X[v].unique() for v in names])), names=list(names))
+                counts = counts.add(pd.Series(1.0, combos), fill_value=0.0)
+        bn._counts[node] = counts
+        if len(names) > 1:
+            bn.P[node] = counts / counts.groupby(level=list(names[:-1])).transform("sum")
+        else:
+            bn.P[node] = counts / counts.sum()
+    bn.prepare()
+    return bn
+
+
+def fit(bn, X):
+    """BayesNet.fit (bayes_net.py:512-516)."""
+    bn.P = {}
+    bn._counts = {}
+    return partial_fit(bn, X)
+
+
+# ------------------------------------------------------------------------------------------- rank 4: Chow-Liu
+def mutual_information(X, device=None):
+    """All pairwise mutual informations (structure.py:33-45, 55-63) from one counting launch: {(u, v): mi} for u < v."""
+    cols = sorted(X.columns)
+    codes, domains = encode_columns(X, cols)
+    card = [len(d) for d in domains]
+    pairs = list(itertools.combinations(range(len(cols)), 2))
+    dense = counting_engine(device).count_tables(codes, card, [(j,) for j in range(len(cols))] + pairs)
+    n = float(len(X))
+    marg = [d / n for d in dense[:len(cols)]]
+    out = {}
+    for (i, j), c in zip(pairs, dense[len(cols):]):
+        puv = c / n
+        nz = puv > 0
+        ratio = puv[nz] / (marg[j][None, :].repeat(len(marg[i]), 0)[nz] * marg[i][:, None].repeat(len(marg[j]), 1)[nz])
+        out[(cols[i], cols[j])] = float((puv[nz] * np.log(ratio)).sum())
+    return out
+
+
+def chow_liu(X, root=None, device=None):
+    """structure.chow_liu (structure.py:9-52): maximum spanning tree of the mutual-information graph (Kruskal with a
+    union-find over the edges in descending MI order, ties in sorted-pair order like the reference's stable sort),
+    oriented away from `root` (default: the first column).  Returns (parent, child) tuples."""
+    mi = mutual_information(X, device=device)
+    ranked = sorted(mi, key=lambda e: mi[e], reverse=True)  # stable: equal MI keeps combinations() order
+    leader = {v: v for v in X.columns}
+
+    def find(v):
+        while leader[v] != v:
+            leader[v] = leader[leader[v]]
+            v = leader[v]
+        return v
+
+    size = {v: 1 for v in X.columns}
+    adj = {v: [] for v in X.columns}
+    for u, v in ranked:
+        a, b = find(u), find(v)
+        if a != b:
+            adj[u].append(v)
+            adj[v].append(u)
+            if size[a] < size[b]:
+                a, b = b, a
+            leader[b] = a
+            size[a] += size[b]
+    root = X.columns[0] if root is None else root
+    edges, stack, seen = [], [root], {root}
+    while stack:
+        u = stack.pop()
+        for v in adj[u]:
+            if v not in seen:
+                seen.add(v)
+                edges.append((u, v))
+                stack.append(v)
+    return edges

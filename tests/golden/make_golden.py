@@ -212,6 +212,40 @@ def joint_fixture():
     netspec.save(os.path.join(HERE, "joint.json"), out)
 
 
+def learn_fixture():
+    """fit / partial_fit (bayes_net.py:467-516) and structure.chow_liu
+    (structure.py:9-63) on fixed data sets (forward samples of the example networks drawn with numpy)."""
+    out = []
+    for name, fn in {"alarm": sorobn.examples.alarm, "asia": sorobn.examples.asia, "grades": sorobn.examples.grades}.items():
+        bn = fn()
+        spec = netspec.dump(bn, name)
+        fjd = bn.full_joint_dist()
+        rng = np.random.default_rng(21)
+        rows = fjd.index.to_frame(index=False).iloc[rng.choice(len(fjd), size=400, p=fjd.to_numpy())].reset_index(drop=True)
+        rows.columns = [str(c) for c in fjd.index.names]
+        entry = {"spec": spec, "columns": list(rows.columns), "rows": [[netspec._py(v) for v in r] for r in rows.values.tolist()]}
+        for prior in (None, 1):
+            b = fn()
+            b.prior_count = prior
+            b.fit(rows)
+            entry[f"fit_prior_{prior}"] = {n: series_to_json(b.P[n].sort_index()) for n in b.P}
+        b = fn()
+        b.P = {}
+        b._P_sizes = {}
+        for chunk in np.array_split(rows, 5):
+            b.partial_fit(chunk)
+        entry["partial_fit_5"] = {n: series_to_json(b.P[n].sort_index()) for n in b.P}
+        edges = sorobn.structure.chow_liu(rows)
+        entry["chow_liu"] = [[str(u), str(v)] for u, v in edges]
+        entry["chow_liu_root_last"] = [[str(u), str(v)] for u, v in sorobn.structure.chow_liu(rows, root=rows.columns[-1])]
+        marg = {v: rows[v].value_counts(normalize=True) for v in rows.columns}
+        entry["mutual_info"] = [[u, v, float(sorobn.structure.mutual_info(rows.groupby([u, v]).size() / len(rows), marg[u], marg[v])).hex()]
+                                for u, v in itertools.combinations(sorted(rows.columns), 2)]
+        out.append(entry)
+        print("learn", name, len(rows), flush=True)
+    netspec.save(os.path.join(HERE, "learn.json"), out)
+
+
 def dags_fixture():
     nets = []
     for seed in range(24):
@@ -315,7 +349,7 @@ if __name__ == "__main__":
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide", "many", "joint"]
+    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide", "many", "joint", "learn"]
     if "examples" in todo:
         examples_fixture()
     if "impute" in todo:
@@ -330,3 +364,5 @@ if __name__ == "__main__":
         many_nodes_fixture()
     if "joint" in todo:
         joint_fixture()
+    if "learn" in todo:
+        learn_fixture()

@@ -257,8 +257,6 @@ def test_query_errors_follow_reference(asia):
         asia.query("Smoker", event={"Nope": True})
     with pytest.raises(TypeError):
         asia.query("Smoker")  # `event` is keyword-only and required (bayes_net.py:796-802)
-    with pytest.raises(NotImplementedError):
-        asia.fit(None)  # not part of this backend
 
 
 def test_result_conventions(asia):

@@ -86,6 +86,36 @@ for alg in ("rejection", "likelihood"):
                                        "answer": a.to_numpy().tolist()}
 out["8f_asia_exact_for_comparison"] = bn.query("Lung cancer", event={"Smoker": True, "Dispnea": True}).to_numpy().tolist()
 
+# ---- counting (fit, Chow-Liu) on 1M rows x 100 columns of the grid network's forward samples
+from sorobn_amd import learning  # noqa: E402
+codes = grid.backend.engine.sample(1_000_000, seed=5)           # uint8 codes in variable-id order
+names = list(grid.backend.flat.names)
+card = grid.backend.flat.card
+ce = learning.counting_engine()
+tabs = [tuple(grid.backend.flat.scope[v]) for v in range(len(names))]
+ce.count_tables(codes[:1000], card, tabs)
+t0 = time.perf_counter()
+cnt = ce.count_tables(codes, card, tabs)
+dt = time.perf_counter() - t0
+out["8f_fit_counts_1M_rows_100_cpts"] = {"ms": dt * 1e3, "rows_per_s": 1e6 / dt, "cells_counted_per_s": 1e6 * len(tabs) / dt}
+import itertools as _it  # noqa: E402
+pairs = [(j,) for j in range(100)] + list(_it.combinations(range(100), 2))
+t0 = time.perf_counter()
+cnt = ce.count_tables(codes, card, pairs)
+dt = time.perf_counter() - t0
+out["8f_chow_liu_counts_1M_rows_4950_pairs"] = {"ms": dt * 1e3, "rows_per_s": 1e6 / dt, "cells_counted_per_s": 1e6 * len(pairs) / dt,
+                                               "note": "includes the 100 MB host->device copy of the code matrix"}
+Xs = pd.DataFrame({n: codes[:200_000, v] for v, n in enumerate(names)})
+t0 = time.perf_counter()
+tree = sorobn_amd.structure.chow_liu(Xs)
+out["8f_chow_liu_200k_rows_100_columns_end_to_end"] = {"ms": (time.perf_counter() - t0) * 1e3, "edges": len(tree)}
+learner = netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet)
+t0 = time.perf_counter()
+learner.fit(Xs)
+out["8f_fit_200k_rows_100_nodes_end_to_end"] = {"ms": (time.perf_counter() - t0) * 1e3,
+                                               "max_abs_err_vs_true_cpt": float(max(np.max(np.abs((learner.P[n] - grid.P[n]).fillna(0).to_numpy())) for n in names))}
+del codes, cnt
+
 # ---- C5: Gibbs
 spec5 = netspec.grid_spec(5, 10, 8, seed=0)
 bn5 = netspec.build(spec5, sorobn_amd.BayesNet)
