@@ -84,7 +84,6 @@ struct mibn_ctx {
     // options
     double arena_gb = 96.0;
     int threads = 0;
-    int wg_per_cu = 8;
     int trace = 0;        // debug: one stderr line per launch
     int split_kinds = 0;  // profiling: one launch per (level, class of work) instead of one per level
     int64_t chunk = 16384;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
@@ -181,7 +180,6 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     std::string n(name);
     if (n == "arena_gb") h->arena_gb = value;
     else if (n == "threads") h->threads = (int)value;
-    else if (n == "wg_per_cu") h->wg_per_cu = std::max(1, std::min(8, (int)value));
     else if (n == "chunk") h->chunk = std::max<int64_t>(1, (int64_t)value);
     else if (n == "big_iters") h->net.big_iters = std::max<int64_t>(1, (int64_t)value);  // test hooks: force tiling
     else if (n == "tile_h") h->net.tile_h = std::max(0, std::min(kTileMax, (int)value));  // 0 = sized by traffic

@@ -1303,14 +1303,14 @@ const char *kernel_name(int kid) {
     static std::string names[kNumKernels];
     static bool init = false;
     if (!init) {
-        names[kKidSeg] = "seg_kernel";
+        names[kKidSeg] = "segments";
         static const char *cxn[3] = {"cx4", "cx16", "cxN"}, *ncn[6] = {"nc1", "nc4", "nc16", "ncN", "nc16-mfma", "outer-mfma"};
         for (int nb = 1; nb <= 2; ++nb)
             for (int c = 0; c < 3; ++c)
                 for (int n = 0; n < 6; ++n)
                     names[kKidFiber0 + (nb - 1) * 18 + c * 6 + n] =
-                        "fiber_tile_kernel<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
-        for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic_tile_kernel<" + std::to_string(j + 1) + ">";
+                        "fiber<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
+        for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic<" + std::to_string(j + 1) + ">";
         init = true;
     }
     return kid >= 0 && kid < kNumKernels ? names[kid].c_str() : "?";

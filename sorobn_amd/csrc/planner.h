@@ -3,7 +3,7 @@
 // Replaces the bookkeeping half of BayesNet._variable_elimination (sorobn/bayes_net.py:763-789):
 // relevance pruning to ancestors (763-765, `ancestors` 373-378), the hidden set (766), evidence
 // slicing of the CPTs (768-776) and the elimination loop's factor selection (779-786) - but instead
-// of executing pandas joins it emits a *step program* for the HIP interpreter (ve_kernel.hip):
+// of executing pandas joins it emits a *step program* for the level kernel (ve_kernel.hip.h):
 // every step is one fused  psi[out] = sum_x prod_j phi_j[idx_j(out, x)]  over dense strided tables.
 //
 // Where the reference's elimination order is the iteration order of a Python set (766, 779), the
