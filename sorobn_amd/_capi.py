@@ -182,6 +182,8 @@ class Engine:
     def query_fixed(self, qvars, evars, ecodes):
         """Fixed-shape batch: qvars[B, nq], evars[B, ne], ecodes[B, ne] -> posteriors[B, cells]
         (all requests must have the same query-table size)."""
+        if len(qvars) == 0:
+            return np.zeros((0, 0), np.float64)
         qvars = _i32(qvars).reshape(len(qvars), -1)
         B, nq = qvars.shape
         evars = _i32(evars).reshape(B, -1)

@@ -187,3 +187,52 @@ def test_config5_gibbs_50_nodes_8_states(amd):
     got = bn.query("025", event=ev, algorithm="gibbs", n_iterations=20000, n_chains=128)
     assert got.index.equals(exact.index)
     assert float(np.max(np.abs(got.to_numpy() - exact.to_numpy()))) < 0.01
+
+
+def test_async_submit_wait_matches_the_blocking_call(amd):
+    """mibn_submit_batch / mibn_wait (two calls in flight) against mibn_query_batch, bit for bit, incl. the misuse
+    errors: a third submit before a wait, a blocking call while tickets are open."""
+    from sorobn_amd import _capi
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    eng = bn.backend.engine
+    q, ev, ec = netspec.c3_requests(100, 4, 3 * 3000, 4, seed=7)
+    to_var = np.array([bn.backend.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    parts = [(to_var[q[k * 3000:(k + 1) * 3000]][:, None], to_var[ev[k * 3000:(k + 1) * 3000]], ec[k * 3000:(k + 1) * 3000])
+             for k in range(3)]
+    want = [eng.query_fixed(*p).copy() for p in parts]
+    t0 = eng.total_stats()
+    h0 = eng.submit_fixed(*parts[0])
+    h1 = eng.submit_fixed(*parts[1])
+    with pytest.raises(_capi.MibnError, match="already in flight"):
+        eng.submit_fixed(*parts[2])
+    with pytest.raises(_capi.MibnError, match="asynchronous calls in flight"):
+        eng.query_fixed(*parts[2])
+    got0 = eng.wait(h0).copy()
+    h2 = eng.submit_fixed(*parts[2])
+    got1 = eng.wait(h1).copy()
+    got2 = eng.wait(h2).copy()
+    eng.drain()
+    for g, w in zip((got0, got1, got2), want):
+        assert np.array_equal(g, w)
+    t1 = eng.total_stats()
+    assert t1["n_launches"] > t0["n_launches"] and t1["alg_bytes"] > t0["alg_bytes"] and t1["kernel_ms"] > t0["kernel_ms"]
+    assert eng.query_fixed(*parts[0]).shape == (3000, 4)  # the blocking call works again once everything is collected
+
+
+def test_engine_argument_errors(amd):
+    from sorobn_amd import _capi
+    spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "asia")["spec"]
+    bn = netspec.build(spec, amd.BayesNet)
+    eng = bn.backend.engine
+    with pytest.raises(_capi.MibnError, match="cannot be part of the event"):
+        eng.query_fixed([[0]], [[0]], [[0]])
+    with pytest.raises((IndexError, _capi.MibnError)):  # the binding sizes the result from card[q] before the call
+        eng.query_fixed([[99]], [[0]], [[0]])
+    with pytest.raises(_capi.MibnError, match="unknown evidence variable"):
+        eng.query_fixed([[0]], [[99]], [[0]])
+    with pytest.raises(_capi.MibnError, match="unknown option"):
+        eng.set_option("no-such-option", 1)
+    with pytest.raises(_capi.MibnError, match="more than"):  # a 5-column table of 8-state columns: 32768 cells > 16384
+        eng.count_tables(np.zeros((4, 5), np.uint8), [8] * 5, [(0, 1, 2, 3, 4)])
+    assert eng.query_fixed(np.zeros((0, 1), np.int32), np.zeros((0, 1), np.int32), np.zeros((0, 1), np.int32)).shape[0] == 0
