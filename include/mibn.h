@@ -180,12 +180,14 @@ int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_v
  * Grouped counting of label codes: the `X.groupby([*parents, node]).size()` of
  * BayesNet.partial_fit (bayes_net.py:467-510) and the pairwise `X.groupby([u, v]).size()` of structure.chow_liu
  * (structure.py:33-45).  No network needed.
- *   codes[n_cols * n_rows]    column-major label codes (codes[col * n_rows + row]), code < card[col] <= 256
+ *   codes[n_cols * n_rows]    label codes, code < card[col] <= 256; row_major = 0: codes[col * n_rows + row],
+ *                             row_major = 1: codes[row * n_cols + col] (what DataFrame.to_numpy() gives; transposed on
+ *                             the device)
  *   scope_off[n_tables + 1], scope_cols[]   CSR: the columns of table t
  *   counts_off[n_tables + 1], counts[]      dense C-order contingency table of every table (last column fastest);
  *                             a table may have at most 16384 cells
  */
-int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, const int32_t *card,
+int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, int32_t row_major, const int32_t *card,
                       int32_t n_tables, const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off,
                       int64_t *counts);
 

@@ -75,7 +75,7 @@ def lib():
         L.mibn_total_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_sample.argtypes = [vp, C.c_int64, C.c_int32, i32p, i32p, C.c_uint64, C.POINTER(C.c_uint8)]
         L.mibn_sampling_query.argtypes = [vp, C.c_int32, C.c_int32, i32p, C.c_int32, i32p, i32p, C.c_int64, C.c_uint64, f64p, i64p]
-        L.mibn_count_tables.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_uint8), i32p, C.c_int32, i64p, i32p, i64p, i64p]
+        L.mibn_count_tables.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_uint8), C.c_int32, i32p, C.c_int32, i64p, i32p, i64p, i64p]
         L.mibn_last_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mibn_last_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_plan_stats.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, C.POINTER(Stats)]
@@ -297,9 +297,14 @@ class Engine:
         return wsum, counts
 
     def count_tables(self, codes, card, tables):
-        """codes: uint8 [n_rows, n_cols] (any layout; sent column-major); tables: list of column-index tuples ->
-        list of dense int64 contingency tables shaped by the cards of their columns."""
-        codes = np.asfortranarray(np.asarray(codes, dtype=np.uint8))
+        """codes: uint8 [n_rows, n_cols] (row- or column-major, sent as it is); tables: list of column-index tuples
+        -> list of dense int64 contingency tables shaped by the cards of their columns."""
+        codes = np.asarray(codes, dtype=np.uint8)
+        if codes.ndim != 2:
+            raise ValueError("codes must be a [n_rows, n_cols] matrix")
+        if not (codes.flags.f_contiguous or codes.flags.c_contiguous):
+            codes = np.ascontiguousarray(codes)
+        row_major = 0 if codes.flags.f_contiguous else 1
         n_rows, n_cols = codes.shape
         card = _i32(card)
         scope_off = np.concatenate([[0], np.cumsum([len(t) for t in tables])]).astype(np.int64)
@@ -309,6 +314,6 @@ class Engine:
         counts = np.zeros(max(1, int(counts_off[-1])), np.int64)
         sc = scope_cols if len(scope_cols) else np.zeros(1, np.int32)
         self._check(self._L.mibn_count_tables(
-            self._h, n_rows, n_cols, codes.ctypes.data_as(C.POINTER(C.c_uint8)), _p(card if len(card) else np.zeros(1, np.int32), C.c_int32),
+            self._h, n_rows, n_cols, codes.ctypes.data_as(C.POINTER(C.c_uint8)), row_major, _p(card if len(card) else np.zeros(1, np.int32), C.c_int32),
             len(tables), _p(scope_off, C.c_int64), _p(sc, C.c_int32), _p(counts_off, C.c_int64), _p(counts, C.c_int64)))
         return [counts[a:b].reshape([int(card[c]) for c in t]) for t, a, b in zip(tables, counts_off[:-1], counts_off[1:])]

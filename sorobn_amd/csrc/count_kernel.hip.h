@@ -58,9 +58,27 @@ __global__ __launch_bounds__(256) void count_kernel(const CountArgs A) {
     }
 }
 
-// host driver; returns MIBN_* code.  scope_off[n_tables + 1] / scope_cols: CSR list of the tables' columns;
+// row-major code matrix [n_rows][n_cols] -> the column-major one the count kernel reads, 64 x 64 tiles through LDS
+// (a DataFrame's to_numpy() is row-major: transposing 100 MB here takes microseconds, on the host ~0.1 s)
+__global__ __launch_bounds__(256) void transpose_codes_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int64_t n_rows,
+                                                              int32_t n_cols) {
+    __shared__ uint8_t tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (r0 + r < n_rows && c0 + c < n_cols) tile[r][c] = in[(r0 + r) * n_cols + c0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r0 + r < n_rows && c0 + c < n_cols) out[(int64_t)(c0 + c) * n_rows + r0 + r] = tile[r][c];
+    }
+}
+
+// host driver; returns MIBN_* code.  row_major: codes[row * n_cols + col] instead of codes[col * n_rows + row].  scope_off[n_tables + 1] / scope_cols: CSR list of the tables' columns;
 // counts_off[n_tables + 1]: offsets of the dense tables in `counts` (must equal the running product of cards).
-inline int count_run(hipStream_t stream, int64_t n_rows, int32_t n_cols, const uint8_t *codes, const int32_t *card, int32_t n_tables,
+inline int count_run(hipStream_t stream, int64_t n_rows, int32_t n_cols, const uint8_t *codes, bool row_major, const int32_t *card, int32_t n_tables,
                      const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off, int64_t *counts,
                      std::string &err) {
     std::vector<int32_t> tbl_begin(n_tables + 1), tbl_col, tbl_stride, tbl_lds(n_tables + 1), grp_begin{0};
@@ -101,21 +119,29 @@ inline int count_run(hipStream_t stream, int64_t n_rows, int32_t n_cols, const u
     }
     const int n_groups = (int)grp_begin.size() - 1;
     const int64_t total = counts_off[n_tables] - counts_off[0];
-    uint8_t *d_codes = nullptr;
+    uint8_t *d_codes = nullptr, *d_rows = nullptr;
     int32_t *d_i32 = nullptr;
     int64_t *d_i64 = nullptr;
     unsigned long long *d_counts = nullptr;
     std::vector<int32_t> pack;
     auto put = [&](const std::vector<int32_t> &a) { size_t o = pack.size(); pack.insert(pack.end(), a.begin(), a.end()); return o; };
     const size_t o_tb = put(tbl_begin), o_tc = put(tbl_col), o_ts = put(tbl_stride), o_tl = put(tbl_lds), o_gb = put(grp_begin);
-    auto fail = [&](hipError_t e) { err = std::string("count: ") + hipGetErrorString(e); hipFree(d_codes); hipFree(d_i32); hipFree(d_i64); hipFree(d_counts); return MIBN_E_HIP; };
+    auto fail = [&](hipError_t e) { err = std::string("count: ") + hipGetErrorString(e); hipFree(d_codes); hipFree(d_rows); hipFree(d_i32); hipFree(d_i64); hipFree(d_counts); return MIBN_E_HIP; };
     hipError_t e;
     const size_t code_bytes = (size_t)n_rows * (size_t)n_cols;
     if ((e = hipMalloc(&d_codes, std::max<size_t>(16, code_bytes))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&d_i32, 4 * std::max<size_t>(1, pack.size()))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&d_i64, 8 * std::max<size_t>(1, tbl_out.size()))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&d_counts, 8 * std::max<int64_t>(1, total))) != hipSuccess) return fail(e);
-    if ((e = hipMemcpyAsync(d_codes, codes, code_bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+    if (row_major && code_bytes) {
+        if ((e = hipMalloc(&d_rows, code_bytes)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(d_rows, codes, code_bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(transpose_codes_kernel, dim3((unsigned)((n_rows + 63) / 64), (unsigned)((n_cols + 63) / 64)), dim3(256), 0, stream,
+                           d_rows, d_codes, n_rows, n_cols);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+    } else if ((e = hipMemcpyAsync(d_codes, codes, code_bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) {
+        return fail(e);
+    }
     if ((e = hipMemcpyAsync(d_i32, pack.data(), 4 * pack.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
     if ((e = hipMemcpyAsync(d_i64, tbl_out.data(), 8 * tbl_out.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
     if ((e = hipMemsetAsync(d_counts, 0, 8 * std::max<int64_t>(1, total), stream)) != hipSuccess) return fail(e);
@@ -140,6 +166,7 @@ inline int count_run(hipStream_t stream, int64_t n_rows, int32_t n_cols, const u
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
     for (int64_t i = 0; i < total; ++i) counts[i] = (int64_t)host[(size_t)i];
     hipFree(d_codes);
+    hipFree(d_rows);
     hipFree(d_i32);
     hipFree(d_i64);
     hipFree(d_counts);

@@ -673,13 +673,13 @@ extern "C" int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const i
                       seed, nullptr, nullptr, counts, h->err);
 }
 
-extern "C" int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, const int32_t *card,
+extern "C" int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, int32_t row_major, const int32_t *card,
                                  int32_t n_tables, const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off,
                                  int64_t *counts) {
     if (!h || n_rows < 0 || n_cols < 0 || n_tables < 0 || (n_rows && n_cols && !codes) || !card || !scope_off || !scope_cols ||
-        !counts_off || !counts)
+        !counts_off || !counts || (row_major != 0 && row_major != 1))
         return MIBN_E_ARG;
     if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
     HIP_TRY(h, hipSetDevice(h->device));
-    return count_run(h->stream, n_rows, n_cols, codes, card, n_tables, scope_off, scope_cols, counts_off, counts, h->err);
+    return count_run(h->stream, n_rows, n_cols, codes, row_major != 0, card, n_tables, scope_off, scope_cols, counts_off, counts, h->err);
 }

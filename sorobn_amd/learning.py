@@ -28,15 +28,28 @@ def counting_engine(device=None):
 def encode_columns(X, columns):
     """Label columns -> (uint8 codes [n_rows, n_cols], sorted label domains).  More than 256 labels per column is
     outside what the count kernel (and any CPT one would learn) handles."""
-    codes = np.empty((len(X), len(columns)), np.uint8)
+    codes = np.empty((len(columns), len(X)), np.uint8)  # filled column by column: column-major, as the count kernel reads it
     domains = []
     for j, c in enumerate(columns):
-        dom = pd.Index(np.sort(pd.unique(X[c].to_numpy())))
+        v = X[c].to_numpy()
+        col = dom = None
+        if v.dtype.kind in "iub" and len(v):  # small integer range: a lookup table instead of hashing
+            iv = v.view(np.uint8) if v.dtype.kind == "b" else v
+            lo, hi = int(iv.min()), int(iv.max())
+            if hi - lo < (1 << 16):
+                shifted = iv - iv.dtype.type(lo) if lo else iv
+                present = np.zeros(hi - lo + 1, bool)
+                present[shifted] = True
+                dom = (np.flatnonzero(present) + lo).astype(v.dtype)
+                if len(dom) <= 256:
+                    col = (np.cumsum(present) - 1).astype(np.uint8)[shifted]
+        if col is None:
+            col, dom = pd.factorize(v, sort=True, use_na_sentinel=False)  # one hash pass per column
         if len(dom) > 256:
             raise ValueError(f"column {c!r} has {len(dom)} distinct labels (max 256)")
-        codes[:, j] = dom.get_indexer(X[c].to_numpy())
-        domains.append(dom.rename(c))
-    return codes, domains
+        codes[j] = col
+        domains.append(pd.Index(dom, name=c))
+    return codes.T, domains
 
 
 def count_series(counts, domains, names):
@@ -108,11 +121,33 @@ def mutual_information(X, device=None):
     n = float(len(X))
     marg = [d / n for d in dense[:len(cols)]]
     out = {}
-    for (i, j), c in zip(pairs, dense[len(cols):]):
+
+    def one(i, j, c):
         puv = c / n
         nz = puv > 0
         ratio = puv[nz] / (marg[j][None, :].repeat(len(marg[i]), 0)[nz] * marg[i][:, None].repeat(len(marg[j]), 1)[nz])
-        out[(cols[i], cols[j])] = float((puv[nz] * np.log(ratio)).sum())
+        return float((puv[nz] * np.log(ratio)).sum())
+
+    # pairs whose table has no empty cell (the usual case with many rows) are evaluated together, shape by shape -
+    # the same elementwise arithmetic and the same row sums as `one`, bit for bit; the others go through `one`
+    by_shape = {}
+    for k, (i, j) in enumerate(pairs):
+        by_shape.setdefault(dense[len(cols) + k].shape, []).append(k)
+    mi = np.empty(len(pairs), np.float64)
+    for shape, ks in by_shape.items():
+        c = np.stack([dense[len(cols) + k] for k in ks])
+        full = (c > 0).reshape(len(ks), -1).all(axis=1)
+        if full.any():
+            sel = np.flatnonzero(full)
+            pi = np.stack([marg[pairs[ks[t]][0]] for t in sel])[:, :, None]
+            pj = np.stack([marg[pairs[ks[t]][1]] for t in sel])[:, None, :]
+            puv = c[sel] / n
+            mi[np.asarray(ks)[sel]] = (puv * np.log(puv / (pj * pi))).reshape(len(sel), -1).sum(axis=1)
+        for t in np.flatnonzero(~full):
+            k = ks[t]
+            mi[k] = one(pairs[k][0], pairs[k][1], dense[len(cols) + k])
+    for k, (i, j) in enumerate(pairs):
+        out[(cols[i], cols[j])] = float(mi[k])
     return out
 
 
