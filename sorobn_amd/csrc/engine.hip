@@ -86,6 +86,7 @@ struct mibn_ctx {
     int threads = 0;
     int trace = 0;        // debug: one stderr line per launch
     int split_kinds = 0;  // profiling: one launch per (level, class of work) instead of one per level
+    int gibbs_lds = 1;    // Gibbs: keep the CPTs in LDS when they fit (0: always read them through L2)
     int64_t chunk = 16384;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
 };
 
@@ -185,6 +186,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "tile_h") h->net.tile_h = std::max(0, std::min(kTileMax, (int)value));  // 0 = sized by traffic
     else if (n == "trace") h->trace = (int)value;
     else if (n == "split_kinds") h->split_kinds = value != 0;
+    else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
     else if (n == "fuse") h->net.fuse = value != 0;
     else if (n == "outer") h->net.outer = value != 0;
     else if (n == "prune") h->net.prune = value != 0;  // 0: multiply every CPT (full_joint_dist / predict_proba semantics)  // OUTER (MFMA) form for products of two big tables  // joint elimination of two variables per pass
@@ -631,7 +633,7 @@ extern "C" int mibn_gibbs(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t
     std::string e = validate_request(h->net, rq);
     if (!e.empty()) { h->err = e; return MIBN_E_ARG; }
     HIP_TRY(h, hipSetDevice(h->device));
-    return gibbs_run(h->net, h->d_pool, h->stream, n_q, q_vars, n_e, e_vars, e_codes, cycle, n_chains, n_iterations, seed,
+    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds != 0, n_q, q_vars, n_e, e_vars, e_codes, cycle, n_chains, n_iterations, seed,
                      counts, h->err, h->stats.kernel_ms);
 }
 

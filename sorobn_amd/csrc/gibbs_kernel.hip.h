@@ -2,7 +2,7 @@
 // the same iteration (the reference cycles deterministically through the non-evidence variables,
 // sorobn/bayes_net.py:697,718-722), so there is no divergence; the Markov-blanket conditional
 //     P(v | mb(v))  ~  P(v | pa(v)) * prod_{c in children(v)} P(c | pa(c))      (bayes_net.py:700-710)
-// is evaluated on the fly from the dense CPTs (L1/L2 resident) instead of materialising the
+// is evaluated on the fly from the dense CPTs (LDS resident when they fit, else L1/L2) instead of materialising the
 // reference's per-node posterior tables (8^7 rows = 16 MiB per interior node in config 5).
 // Chain state lives in LDS as state[var][lane] bytes.  Every cycle position has a precompiled *update program*
 // (wave-uniform words -> scalar loads): the factors mentioning the variable (its CPT and its children's), for each
@@ -60,6 +60,7 @@ struct GibbsArgs {
     const int32_t *qstride;       // stride of each query variable in the joint histogram
     unsigned long long *counts;   // global histogram
     int32_t n_vars, n_cycle, n_q, hist_cells;
+    int32_t pool_cells;           // doubles in `pool` (the LDS-resident variant copies them all)
     int64_t n_chains, n_iterations;
     uint64_t seed;
 };
@@ -67,13 +68,14 @@ struct GibbsArgs {
 constexpr int kGibbsWaves = 1;  // waves per workgroup (each wave = 64 independent chains)
 
 // weight of value x of variable v given the rest of the lane's state
-__device__ __forceinline__ double gibbs_weight(const GibbsArgs &A, const GibbsVar &V, int v, int x,
+template <typename PoolPtr>
+__device__ __forceinline__ double gibbs_weight(const GibbsArgs &A, PoolPtr pool, const GibbsVar &V, int v, int x,
                                                const uint8_t *st /* state[var*64 + lane] */, int lane) {
     // own CPT: scope = [*parents, v], v last with stride 1
     int off = V.table_off + x;
     for (int k = 0; k + 1 < V.scope_len; ++k)
         off += (int)st[A.scope_var[V.scope_begin + k] * 64 + lane] * A.scope_stride[V.scope_begin + k];
-    double w = A.pool[off];
+    double w = pool[off];
     for (int ci = 0; ci < V.child_len; ++ci) {
         const int c = A.children[V.child_begin + ci];
         const GibbsVar C = A.vars[c];
@@ -83,16 +85,23 @@ __device__ __forceinline__ double gibbs_weight(const GibbsArgs &A, const GibbsVa
             const int s = A.scope_stride[C.scope_begin + k];
             o += (u == v ? x : (int)st[u * 64 + lane]) * s;
         }
-        w *= A.pool[o];
+        w *= pool[o];
     }
     return w;
 }
 
+// POOL_LDS: every CPT is copied into LDS first (config 5: 154 KB of tables + 3 KB of chain state in the 160 KB of a
+// CU), so the card x n_factors table reads of an update are ds_read_b64 instead of L2 round trips - the update chain is
+// latency-bound and few chains (config 5: 2 waves per GPU) cannot hide it with occupancy.
+template <bool POOL_LDS>
 __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     uint8_t *st = smem;                                        // n_vars * 64 bytes
     unsigned int *hist = (unsigned int *)(smem + ((A.n_vars * 64 + 15) & ~15));  // hist_cells
+    double *lds_pool = (double *)(smem + ((((A.n_vars * 64 + 15) & ~15) + A.hist_cells * 4 + 15) & ~15));
+    if (POOL_LDS)
+        for (int i = threadIdx.x; i < A.pool_cells; i += blockDim.x) lds_pool[i] = A.pool[i];
     const int64_t chain = (int64_t)blockIdx.x * 64 + lane;
     const bool active = chain < A.n_chains;
     for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x) hist[i] = 0;
@@ -138,10 +147,13 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
                 int base = up[0];
                 for (int k = 0; k < no; ++k) base += (int)st[up[3 + 2 * k] * 64 + lane] * up[4 + 2 * k];
                 up += 3 + 2 * no;
-                const double *__restrict__ tp = A.pool + base;
+                double tv[kRegCard];
 #pragma unroll
                 for (int x = 0; x < kRegCard; ++x)
-                    if (x < card) w[x] *= tp[x * sv];
+                    if (x < card) tv[x] = POOL_LDS ? lds_pool[base + x * sv] : A.pool[base + x * sv];
+#pragma unroll
+                for (int x = 0; x < kRegCard; ++x)
+                    if (x < card) w[x] *= tv[x];
             }
             double total = 0;
 #pragma unroll
@@ -163,13 +175,13 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
         } else {
             const GibbsVar V = A.vars[v];
             double total = 0;
-            for (int x = 0; x < V.card; ++x) total += gibbs_weight(A, V, v, x, st, lane);
+            for (int x = 0; x < V.card; ++x) total += POOL_LDS ? gibbs_weight(A, lds_pool, V, v, x, st, lane) : gibbs_weight(A, A.pool, V, v, x, st, lane);
             if (total > 0) {
                 const double u = philox_uniform((uint64_t)it, 0u, k0, k1) * total;
                 double acc = 0;
                 int val = -1, last = 0;
                 for (int x = 0; x < V.card; ++x) {
-                    const double w = gibbs_weight(A, V, v, x, st, lane);
+                    const double w = POOL_LDS ? gibbs_weight(A, lds_pool, V, v, x, st, lane) : gibbs_weight(A, A.pool, V, v, x, st, lane);
                     if (w > 0) last = x;
                     acc += w;
                     if (val < 0 && u < acc) val = x;
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
 }
 
 // host driver; returns MIBN_* code
-inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t stream, int32_t n_q, const int32_t *q_vars,
+inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t stream, bool allow_lds, int32_t n_q, const int32_t *q_vars,
                      int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle_in, int64_t n_chains,
                      int64_t n_iterations, uint64_t seed, int64_t *counts, std::string &err, double &kernel_ms) {
     const int n = net.n_vars;
@@ -268,8 +280,13 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     std::vector<int32_t> qstride(n_q);
     int64_t cells = 1;
     for (int i = n_q - 1; i >= 0; --i) { qstride[i] = (int32_t)cells; cells *= net.card[q_vars[i]]; }
-    const size_t lds = ((size_t)n * 64 + 15) / 16 * 16 + (size_t)cells * 4;
+    size_t lds = ((size_t)n * 64 + 15) / 16 * 16 + (size_t)cells * 4;
     if (lds > 150 * 1024) { err = "gibbs: network/query too large for the LDS-resident chain state"; return MIBN_E_LIMIT; }
+    // tables in LDS too when they fit beside the state and the launch is small enough for one workgroup per CU
+    const size_t pool_cells = net.pool.size();
+    const size_t lds_with_pool = (lds + 15) / 16 * 16 + pool_cells * 8;
+    const bool pool_lds = allow_lds && lds_with_pool <= 160 * 1024 && (n_chains + 63) / 64 <= 512;
+    if (pool_lds) lds = lds_with_pool;
 
     GibbsVar *d_vars = nullptr;
     int32_t *d_i32 = nullptr;
@@ -300,6 +317,7 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     A.qstride = d_i32 + o_qs;
     A.counts = d_counts;
     A.n_vars = n;
+    A.pool_cells = (int32_t)pool_cells;
     A.n_cycle = (int32_t)cycle.size();
     A.n_q = n_q;
     A.hist_cells = (int32_t)cells;
@@ -310,10 +328,12 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const unsigned blocks = (unsigned)((n_chains + 63) / 64);
-    if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void *)gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kernel = pool_lds ? gibbs_kernel<true> : gibbs_kernel<false>;
+    if (lds > 64 * 1024) {
+        if ((e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return fail(e);
+    }
     hipEventRecord(e0, stream);
-    hipLaunchKernelGGL(gibbs_kernel, dim3(blocks), dim3(64 * kGibbsWaves), lds, stream, A);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * kGibbsWaves), lds, stream, A);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e);
     hipEventRecord(e1, stream);
     std::vector<unsigned long long> hc((size_t)cells);

@@ -98,6 +98,32 @@ def test_c3_fused_vs_single_variable_passes(amd):
     assert float(np.max(np.abs(fused - single))) <= 1e-13
 
 
+def test_c3_bayes_rule_and_marginalisation_at_full_size(amd):
+    """Size-independent properties on the BASELINE C3 stream, whole-grid requests included (no CPU oracle finishes
+    those): (i) P(q | e1..e4) equals the slice e4 = v of the two-variable posterior P(q, e4 | e1..e3), renormalised
+    - a different request, different relevant set, different elimination order and different kernels for the same
+    number; (ii) summing that two-variable posterior over e4 gives the one-variable posterior P(q | e1..e3)."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    B = 8192
+    q, ev, ec = netspec.c3_requests(100, 4, B, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    Q, E = to_var[q], to_var[ev]
+    cond = be.engine.query_fixed(Q[:, None], E, ec)                                   # P(q | e1..e4)
+    joint = be.engine.query_fixed(np.stack([Q, E[:, 3]], 1), E[:, :3], ec[:, :3])     # P(q, e4 | e1..e3), e4 fastest
+    prior = be.engine.query_fixed(Q[:, None], E[:, :3], ec[:, :3])                    # P(q | e1..e3)
+    joint = joint.reshape(B, 4, 4)
+    assert np.allclose(joint.sum((1, 2)), 1.0, atol=1e-12)
+    assert float(np.max(np.abs(joint.sum(2) - prior))) <= 1e-12
+    sl = joint[np.arange(B), :, ec[:, 3]]
+    pe = sl.sum(1)                                                                    # P(e4 = v | e1..e3) > 0: CPTs are positive
+    assert pe.min() > 0
+    err = np.abs(sl / pe[:, None] - cond)
+    assert float(np.max(err * np.minimum(1.0, pe[:, None] * 1e3))) <= 1e-12          # (conditioning on a 1e-6 event amplifies rounding)
+    assert float(np.max(err)) <= 1e-9
+
+
 def test_single_query_api_alarm(amd):
     """README.md:225-229 (config C1): 0.715828 / 0.284172."""
     spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "alarm")["spec"]
@@ -161,6 +187,11 @@ def test_gibbs_matches_exact_posterior(amd):
     b = be.gibbs_sampling("012", event=ev, n_iterations=500, n_chains=64, seed=1)
     c = be.gibbs_sampling("012", event=ev, n_iterations=500, n_chains=64, seed=2)
     assert a.equals(b) and not a.equals(c)
+    # the LDS-resident tables (default when they fit) and the L2 path run the same arithmetic on the same streams
+    be.engine.set_option("gibbs_lds", 0)
+    d = be.gibbs_sampling("012", event=ev, n_iterations=500, n_chains=64, seed=1)
+    be.engine.set_option("gibbs_lds", 1)
+    assert a.equals(d)
 
 
 def test_gibbs_through_query_api(amd):

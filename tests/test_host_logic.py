@@ -224,6 +224,24 @@ def test_order_choice_never_worse_than_row_major():
     assert ours.mean() < 0.5 * rm.mean()
 
 
+def test_c3_bayes_rule_and_marginalisation_on_the_simulator():
+    """CPU twin of the GPU test of the same name: P(q | e1..e4) against the renormalised slice of P(q, e4 | e1..e3)
+    and the marginal of that joint against P(q | e1..e3), planner programs executed by the simulator."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    f = flatten(netspec.build(spec, sorobn_amd.BayesNet))
+    eng = simengine.SimEngine(f)
+    B = 16
+    q, ev, ec = netspec.c3_requests(100, 4, B, 4, seed=1)
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
+    Q, E = to_var[q], to_var[ev]
+    cond = eng.query_fixed(Q[:, None], E, ec)
+    joint = eng.query_fixed(np.stack([Q, E[:, 3]], 1), E[:, :3], ec[:, :3]).reshape(B, 4, 4)
+    prior = eng.query_fixed(Q[:, None], E[:, :3], ec[:, :3])
+    assert float(np.max(np.abs(joint.sum(2) - prior))) <= 1e-12
+    sl = joint[np.arange(B), :, ec[:, 3]]
+    assert float(np.max(np.abs(sl / sl.sum(1, keepdims=True) - cond))) <= 1e-11
+
+
 # ------------------------------------------------------------------------------------ API behaviour
 
 @pytest.fixture()
