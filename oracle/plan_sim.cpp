@@ -23,10 +23,11 @@
 using namespace mibn;
 
 static std::string g_err;
-static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1;
+static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1, g_chain = 0;
 extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
 extern "C" void plan_sim_set_tiling(int big_iters, int tile_h) { g_big_iters = big_iters; g_tile_h = tile_h; }
 extern "C" void plan_sim_set_fuse(int fuse) { g_fuse = fuse; }
+extern "C" void plan_sim_set_chain(int chain) { g_chain = chain; }
 extern "C" void plan_sim_set_prune(int prune) { g_prune = prune; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
@@ -83,6 +84,126 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
     const int c1 = (int)(p[8] >> 16);
     if (c1 < 1 || cx % c1) { g_err = "fiber step: c1 does not divide cx"; return -9; }
     const int nT = nN + nctrl;
+    if ((p[1] >> 16) & kFlagChain) {
+        // CHAIN (planner.h): out[r, n12, n3] = sum_x3 T3[..] * sum_x12 F[r, x12, x3] * T12[n12, x12, ctrl12(r), x3]
+        const uint32_t *q = p + kHdrWords;
+        if (nb != 2 || NC != 16 || cx != 16 || c1 != 4 || nN != 2 || !((p[1] >> 16) & kFlagContig)) { g_err = "malformed CHAIN step"; return -9; }
+        const double *F = table((uint64_t)q[0] | ((uint64_t)q[1] << 32));
+        const int fx1 = (int)q[2], fx2 = (int)q[3];
+        const int T12 = (int)q[4], T3 = (int)q[5], fx3 = (int)q[6], t12x3 = (int)q[7];
+        q += 8;
+        if (T12 != T || T12 + T3 > kMaxT || (t12x3 != 0 && t12x3 * 4 != T12)) { g_err = "CHAIN step: bad table sizes"; return -9; }
+        const double *sm[kMaxSmall];
+        int sxs1[kMaxSmall], sxs2[kMaxSmall];
+        const int32_t *sts[kMaxSmall];
+        for (int j = 0; j < ns; ++j) {
+            sm[j] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32));
+            sxs1[j] = (int)q[2];
+            sxs2[j] = (int)q[3];
+            sts[j] = (const int32_t *)(q + 4);
+            q += 4 + nT;
+        }
+        const uint32_t *tcard = q; q += nT;
+        const uint32_t *nout = q; q += 16;
+        for (int n = 0; n < 16; ++n)
+            if (nout[n] != (uint32_t)n) { g_err = "CHAIN step with scattered N offsets"; return -9; }
+        const int n3s = (int)q[0], nd3 = (int)(q[1] & 0xff);
+        const bool n12dep = (q[1] >> 8) & 1;
+        q += 2;
+        const uint32_t *tcard3 = q; q += nd3;
+        if (n3s < 1 || n3s > 2 || nd3 < 2 || tcard3[0] != 4 || tcard3[1] != 4) { g_err = "CHAIN step: bad third-variable table"; return -9; }
+        const double *sm3[2];
+        const int32_t *sts3[2];
+        for (int j = 0; j < n3s; ++j) { sm3[j] = table((uint64_t)q[0] | ((uint64_t)q[1] << 32)); sts3[j] = (const int32_t *)(q + 2); q += 2 + nd3; }
+        const uint32_t *rax = q; q += 3 * na;
+        const int32_t *bst = (const int32_t *)q;  // [0][a] = F, [1][a] = T3 strides
+        {
+            int64_t c = 1;
+            for (int k = 0; k < nd3; ++k) c *= tcard3[k];
+            if (c != T3) { g_err = "CHAIN step: T3 size does not match its dimensions"; return -9; }
+            c = 256;
+            for (int k = 2; k < nT; ++k) c *= tcard[k];
+            if (c != T12) { g_err = "CHAIN step: T12 size does not match its dimensions"; return -9; }
+            const int nlo_m = (p[0] >> 24) & 0xff;
+            int64_t expect = 64;
+            for (int a = 0; a < nlo_m; ++a) {
+                if ((int64_t)rax[3 * a + 1] != expect) { g_err = "CHAIN step whose lane block is not contiguous"; return -9; }
+                expect *= rax[3 * a];
+            }
+            // the kernel reads n12-dependent T3 entries at 16 * lane-column: dimensions 2 and 3 must then be (n1, n2)
+            const int rs = (p[1] >> kRowStrideShift) & 0xff;
+            if (rs != 1 && rs != 4 && rs != 16) { g_err = "bad MFMA row stride"; return -9; }
+            auto lo_t = [&](int64_t cell, int which) {
+                int64_t r = cell, to = 0;
+                for (int a = 0; a < nlo_m; ++a) { to += (r % rax[3 * a]) * (which ? (int64_t)bst[na + a] : (int64_t)rax[3 * a + 2]); r /= rax[3 * a]; }
+                return to;
+            };
+            for (int64_t w0 = 0; w0 < lo; w0 += 64)
+                for (int rb = 0; rb < 4; ++rb)
+                    for (int i = 0; i < 16; ++i) {
+                        const int64_t c0 = w0 + rs * rb, cc = w0 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+                        if (cc < lo && c0 < lo && (lo_t(cc, 0) != lo_t(c0, 0) || lo_t(cc, 1) != lo_t(c0, 1))) { g_err = "CHAIN row block mixes table slices"; return -9; }
+                    }
+        }
+        std::vector<double> Tt((size_t)T12), T3t((size_t)T3);
+        for (int t = 0; t < T12; ++t) {
+            int r = t;
+            const int n = r % 16; r /= 16;
+            const int x = r % 16; r /= 16;
+            double v = 1.0;
+            for (int j = 0; j < ns; ++j) {
+                int64_t off = (int64_t)(x % 4) * sxs1[j] + (int64_t)(x / 4) * sxs2[j] + (int64_t)(n % 4) * sts[j][0] + (int64_t)(n / 4) * sts[j][1];
+                int c = r;
+                for (int k = 2; k < nT; ++k) { off += (int64_t)(c % tcard[k]) * sts[j][k]; c /= tcard[k]; }
+                v *= sm[j][off];
+            }
+            Tt[(size_t)t] = v;
+        }
+        for (int t = 0; t < T3; ++t) {
+            double v = 1.0;
+            for (int j = 0; j < n3s; ++j) {
+                int64_t off = 0;
+                int c = t;
+                for (int k = 0; k < nd3; ++k) { off += (int64_t)(c % tcard3[k]) * sts3[j][k]; c /= tcard3[k]; }
+                v *= sm3[j][off];
+            }
+            T3t[(size_t)t] = v;
+        }
+        if (n12dep && (nd3 < 4 || tcard3[2] != 4 || tcard3[3] != 4)) { g_err = "CHAIN step: n12-dependent T3 without (n1, n2) dimensions"; return -9; }
+        const int64_t total_cells = (int64_t)p[2] * (int64_t)p[3] * 64;
+        if ((int64_t)out_off + total_cells > arena_cells) { g_err = "chain step writes outside its arena"; return -7; }
+        std::vector<std::pair<int64_t, double>> writes;
+        writes.reserve((size_t)((it1 - it0) * 64));
+        for (int64_t rr = it0; rr < it1; ++rr) {
+            int64_t r = rr, oo = 0, to = 0, fo = 0, t3o = 0;
+            for (int a = 0; a < na; ++a) {
+                const int64_t d = r % rax[3 * a];
+                r /= rax[3 * a];
+                oo += d * rax[3 * a + 1];
+                to += d * rax[3 * a + 2];
+                fo += d * bst[a];
+                t3o += d * bst[na + a];
+            }
+            for (int n = 0; n < 16; ++n) {
+                double g[4];
+                for (int x3 = 0; x3 < 4; ++x3) {
+                    double acc = 0.0;
+                    for (int x = 0; x < 16; ++x)
+                        acc += F[fo + (int64_t)(x % 4) * fx1 + (int64_t)(x / 4) * fx2 + (int64_t)x3 * fx3] * Tt[(size_t)(to + (int64_t)x3 * t12x3 + x * 16 + n)];
+                    g[x3] = acc;
+                }
+                for (int n3 = 0; n3 < 4; ++n3) {
+                    double acc = 0.0;
+                    for (int x3 = 0; x3 < 4; ++x3) acc += g[x3] * T3t[(size_t)(t3o + (n12dep ? 16 * n : 0) + 4 * n3 + x3)];
+                    const int64_t o = oo + n + 16 * n3;
+                    if (o < 0 || o >= total_cells) { g_err = "chain output offset out of range"; return -8; }
+                    writes.emplace_back(o, acc);
+                }
+            }
+        }
+        for (auto &w : writes) outp[w.first] = w.second;
+        return 0;
+    }
     const uint32_t *q = p + kHdrWords;
     const double *big[2];
     int bxs1[2], bxs2[2];
@@ -184,6 +305,7 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     net.big_iters = g_big_iters;
     net.tile_h = g_tile_h;
     net.fuse = g_fuse;
+    net.chain = g_chain;
     net.prune = g_prune;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
@@ -279,6 +401,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     net.big_iters = g_big_iters;
     net.tile_h = g_tile_h;
     net.fuse = g_fuse;
+    net.chain = g_chain;
     net.prune = g_prune;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
@@ -301,6 +424,7 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     Network net;
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
+    net.chain = g_chain;
     for (int i = 0; i < n_hints; ++i)
         net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);

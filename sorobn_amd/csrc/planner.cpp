@@ -484,7 +484,7 @@ struct Emitter {
     }
 
     using Strides = int64_t[kMaxIn][kRawAxes];
-    using XStrides = int64_t[kMaxIn][2];
+    using XStrides = int64_t[kMaxIn][3];
 
     // GENERIC encoding: iteration space = output cells
     void emit_generic(const PF *const *ins, int n_in, const Strides &s, const int64_t *xs, const PF &out, int64_t cells,
@@ -815,6 +815,201 @@ struct Emitter {
         return true;
     }
 
+    // CHAIN form (planner.h): three 4-state variables, one big input.  Any of the three may be the one summed out in
+    // registers (its own small inputs must not depend on the other two).
+    bool emit_chain(const PF *const *ins, int n_in, const Strides &s, const XStrides &xs_in, PF &out) {
+        static const int kPerm[3][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}};
+        for (int pi = 0; pi < 3; ++pi) {
+            XStrides xs;
+            for (int j = 0; j < n_in; ++j)
+                for (int k = 0; k < 3; ++k) xs[j][k] = xs_in[j][kPerm[pi][k]];
+            if (emit_chain_as(ins, n_in, s, xs, out)) return true;
+        }
+        return false;
+    }
+
+    bool emit_chain_as(const PF *const *ins, int n_in, const Strides &s_in, const XStrides &xs, PF &out) {
+        int big = -1, g12[kMaxIn], g3[kMaxIn], n12 = 0, n3s = 0;
+        bool x3dep = false;
+        for (int j = 0; j < n_in; ++j) {
+            if (ins[j]->cells > net.small_cells) {
+                if (big >= 0) return false;
+                big = j;
+            } else if (xs[j][2] != 0 && xs[j][0] == 0 && xs[j][1] == 0) {
+                g3[n3s++] = j;
+            } else {
+                g12[n12++] = j;
+                x3dep = x3dep || xs[j][2] != 0;
+            }
+        }
+        if (big < 0 || xs[big][0] == 0 || xs[big][1] == 0 || xs[big][2] == 0) return false;
+        if (n12 > kMaxSmall || n3s < 1 || n3s > 2) return false;
+        const int na = out.n;
+        if (na < 3) return false;
+        // the three new axes: two of the pair tables, one of the third variable's; they must be the three fastest
+        int nax12[2], nn12 = 0, nax3 = -1;
+        bool n12dep = false;
+        for (int a = 0; a < na; ++a) {
+            if (s_in[big][a] != 0) continue;
+            bool dep12 = false, dep3 = false;
+            for (int k = 0; k < n12; ++k) dep12 = dep12 || s_in[g12[k]][a] != 0;
+            for (int k = 0; k < n3s; ++k) dep3 = dep3 || s_in[g3[k]][a] != 0;
+            if (a > 2 || net.card[out.vars[a]] != 4) return false;
+            if (dep12) {
+                if (nn12 >= 2) return false;
+                nax12[nn12++] = a;
+                n12dep = n12dep || dep3;
+            } else if (dep3) {
+                if (nax3 >= 0) return false;
+                nax3 = a;
+            } else {
+                return false;
+            }
+        }
+        if (nn12 != 2 || nax3 < 0) return false;
+        // re-order the three fastest output axes: n12 at strides 1 and 4, n3 at 16 (their cards are equal, the strides of
+        // the other axes do not change)
+        int ord[kRawAxes];
+        ord[0] = nax12[0]; ord[1] = nax12[1]; ord[2] = nax3;
+        for (int a = 3; a < na; ++a) ord[a] = a;
+        int64_t s[kMaxIn][kRawAxes];
+        for (int j = 0; j < n_in; ++j)
+            for (int a = 0; a < na; ++a) s[j][a] = s_in[j][ord[a]];
+        int32_t vars2[3] = {out.vars[ord[0]], out.vars[ord[1]], out.vars[ord[2]]};
+        // R axes; ctrl axes of T12 / of T3 = R axes a pair-group / third-group small input depends on
+        int64_t rcard[kRawAxes], rost[kRawAxes], rt12[kRawAxes], rt3[kRawAxes], rbig[kRawAxes];
+        int c12[kRawAxes], c3[kRawAxes], nc12 = 0, nc3 = 0, nr = 0;
+        int64_t T12 = 256, T3 = n12dep ? 256 : 16;
+        for (int a = 3; a < na; ++a) {
+            rcard[nr] = net.card[out.vars[a]];
+            rost[nr] = out.strides[a];
+            rbig[nr] = s[big][a];
+            bool dep12 = false, dep3 = false;
+            for (int k = 0; k < n12; ++k) dep12 = dep12 || s[g12[k]][a] != 0;
+            for (int k = 0; k < n3s; ++k) dep3 = dep3 || s[g3[k]][a] != 0;
+            rt12[nr] = rt3[nr] = 0;
+            if (dep12) {
+                if (nc12 >= 10) return false;
+                c12[nc12++] = a;
+                rt12[nr] = T12;
+                T12 *= rcard[nr];
+            }
+            if (dep3) {
+                if (nc3 >= 10) return false;
+                c3[nc3++] = a;
+                rt3[nr] = T3;
+                T3 *= rcard[nr];
+            }
+            if (T12 * (x3dep ? 4 : 1) + T3 > kMaxT) return false;
+            ++nr;
+        }
+        const int64_t t12x3 = x3dep ? T12 : 0;
+        if (x3dep) T12 *= 4;
+        int nlo = 0;
+        int64_t lo = 1;
+        while (nlo < nr && lo < kLoTarget && lo * rcard[nlo] <= kFiberLoMax) lo *= rcard[nlo++];
+        int64_t rcells = 1;
+        for (int i = 0; i < nr; ++i) rcells *= rcard[i];
+        if (rcells * 64 < net.big_iters) return false;
+        {   // the lane-varying block is contiguous in the output: cell l at 64*l
+            int64_t expect = 64;
+            for (int i = 0; i < nlo; ++i) { if (rost[i] != expect) return false; expect *= rcard[i]; }
+        }
+        // row stride (rule of emit_fiber, over the ctrl axes of both tables)
+        int row_stride = 16, inside = 0;
+        {
+            bool ok = true;
+            int64_t cs = 1;
+            for (int i = 0; i < nlo; ++i) {
+                if (rt12[i] != 0 || rt3[i] != 0) {
+                    if (cs < 64) {
+                        ++inside;
+                        if (rcard[i] == 4 && (cs == 1 || cs == 4 || cs == 16)) row_stride = (int)cs;
+                        else ok = false;
+                    } else if (cs % 64 != 0) {
+                        ok = false;
+                    }
+                }
+                cs *= rcard[i];
+            }
+            if (inside > 1 || !ok) return false;
+        }
+        int64_t mc[kRawAxes], mo[kRawAxes], m12[kRawAxes], m3[kRawAxes], mb[kRawAxes];
+        int ma = 0, mlo = 0;
+        for (int i = 0; i < nr; ++i) {
+            const bool merge = ma > 0 && i != nlo && mo[ma - 1] * mc[ma - 1] == rost[i] && m12[ma - 1] * mc[ma - 1] == rt12[i] &&
+                               m3[ma - 1] * mc[ma - 1] == rt3[i] && mb[ma - 1] * mc[ma - 1] == rbig[i] && mc[ma - 1] * rcard[i] < (1 << 30);
+            if (merge) {
+                mc[ma - 1] *= rcard[i];
+            } else {
+                mc[ma] = rcard[i];
+                mo[ma] = rost[i];
+                m12[ma] = rt12[i];
+                m3[ma] = rt3[i];
+                mb[ma] = rbig[i];
+                ++ma;
+                if (i < nlo) ++mlo;
+            }
+        }
+        if (ma > kMaxAxes || ma < 1) return false;
+        const int nT = 2 + nc12 + (x3dep ? 1 : 0);
+        const int nd3 = 2 + (n12dep ? 2 : 0) + nc3;
+        const int words = kHdrWords + 8 + n12 * (4 + nT) + nT + 16 + 2 + nd3 + n3s * (2 + nd3) + 3 * ma + 2 * ma;
+        if (words > kMaxStepWords) return false;
+        // commit the axis order of the output
+        for (int a = 0; a < 3; ++a) out.vars[a] = vars2[a];
+        uint32_t *w = prog.extend(words);
+        header(w, kKindFiber, n_in, ma, mlo, 16, false, lo, rcells / lo, out.off, words);
+        w[1] |= (kFlagChain | kFlagContig) << 16;
+        w[1] |= (uint32_t)row_stride << kRowStrideShift;
+        w[7] = 2u | ((uint32_t)n12 << 4) | (2u << 8) | ((uint32_t)(nT - 2) << 12) | (16u << 16);
+        w[8] = (uint32_t)T12 | (4u << 16);
+        uint32_t *p = w + kHdrWords;
+        *p++ = (uint32_t)(ins[big]->off & 0xffffffffu);
+        *p++ = (uint32_t)(ins[big]->off >> 32);
+        *p++ = (uint32_t)(int32_t)xs[big][0];
+        *p++ = (uint32_t)(int32_t)xs[big][1];
+        *p++ = (uint32_t)T12;
+        *p++ = (uint32_t)T3;
+        *p++ = (uint32_t)(int32_t)xs[big][2];
+        *p++ = (uint32_t)t12x3;
+        for (int k = 0; k < n12; ++k) {
+            const int j = g12[k];
+            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j]->off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[j][0];
+            *p++ = (uint32_t)(int32_t)xs[j][1];
+            *p++ = (uint32_t)(int32_t)s[j][0];
+            *p++ = (uint32_t)(int32_t)s[j][1];
+            for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)(int32_t)s[j][c12[i]];
+            if (x3dep) *p++ = (uint32_t)(int32_t)xs[j][2];
+        }
+        *p++ = 4;
+        *p++ = 4;
+        for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)net.card[out.vars[c12[i]]];
+        if (x3dep) *p++ = 4;
+        for (int n = 0; n < 16; ++n) *p++ = (uint32_t)n;
+        *p++ = (uint32_t)n3s;
+        *p++ = (uint32_t)nd3 | (n12dep ? 256u : 0u);
+        *p++ = 4;  // x3
+        *p++ = 4;  // n3
+        if (n12dep) { *p++ = 4; *p++ = 4; }
+        for (int i = 0; i < nc3; ++i) *p++ = (uint32_t)net.card[out.vars[c3[i]]];
+        for (int k = 0; k < n3s; ++k) {
+            const int j = g3[k];
+            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
+            *p++ = (uint32_t)(ins[j]->off >> 32);
+            *p++ = (uint32_t)(int32_t)xs[j][2];
+            *p++ = (uint32_t)(int32_t)s[j][2];
+            if (n12dep) { *p++ = (uint32_t)(int32_t)s[j][0]; *p++ = (uint32_t)(int32_t)s[j][1]; }
+            for (int i = 0; i < nc3; ++i) *p++ = (uint32_t)(int32_t)s[j][c3[i]];
+        }
+        for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = (uint32_t)m12[a]; }
+        for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)mb[a];
+        for (int a = 0; a < ma; ++a) *p++ = (uint32_t)(int32_t)m3[a];
+        return true;
+    }
+
     // Emit one step: multiply `ins`, sum out the nx (0..2) variables X (nx = 0: product only); the new factor is
     // written to `out`.  fiber_only: emit nothing and return false unless the step fits the FIBER form (used to try
     // the joint elimination of two variables).
@@ -850,11 +1045,12 @@ struct Emitter {
         double in_cells = 0;
         for (int j = 0; j < n_in; ++j) {
             for (int a = 0; a < na; ++a) s[j][a] = 0;
-            xs[j][0] = xs[j][1] = 0;
+            xs[j][0] = xs[j][1] = xs[j][2] = 0;
             for (int k = 0; k < ins[j]->n; ++k) {
                 const int v = ins[j]->vars[k];
                 if (nx > 0 && v == X[0]) xs[j][0] = ins[j]->strides[k];
                 else if (nx > 1 && v == X[1]) xs[j][1] = ins[j]->strides[k];
+                else if (nx > 2 && v == X[2]) xs[j][2] = ins[j]->strides[k];
                 else s[j][pos[v]] = ins[j]->strides[k];
             }
             in_cells += (double)ins[j]->cells;
@@ -870,7 +1066,8 @@ struct Emitter {
             out.alloc = cells;
         }
         const size_t step_base = prog.size;
-        const bool fiber = !final_ && ((net.outer && nx > 0 && emit_outer(ins, n_in, s, xs, out, cx, c1)) || emit_fiber(ins, n_in, s, xs, out, cx, c1));
+        const bool fiber = nx == 3 ? (!final_ && emit_chain(ins, n_in, s, xs, out))
+                                   : !final_ && ((net.outer && nx > 0 && emit_outer(ins, n_in, s, xs, out, cx, c1)) || emit_fiber(ins, n_in, s, xs, out, cx, c1));
         if (!fiber) {
             if (fiber_only) {
                 if (out.alloc) arena.release((int64_t)out.off, out.alloc);
@@ -1028,6 +1225,41 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
         live.resize(k);
         // Joint elimination: if the factor this step creates is a big table that the very next step consumes, both
         // variables are summed out in one pass over the inputs and the intermediate never touches HBM.
+        // CHAIN: three consecutive 4-state variables of one big table in a single pass (planner.h)
+        if (net.fuse && net.chain && i + 2 < best.size() && n_in < kMaxIn && pool.size() + 1 <= pool.capacity() &&
+            net.card[x] == 4 && net.card[best[i + 1]] == 4 && net.card[best[i + 2]] == 4) {
+            const int32_t x2 = best[i + 1], x3 = best[i + 2];
+            int nbig = 0;
+            const PF *bigf = nullptr;
+            for (int j = 0; j < n_in; ++j)
+                if (ins[j]->cells > net.small_cells) { ++nbig; bigf = ins[j]; }
+            if (nbig == 1 && bigf->scope.test(x2) && bigf->scope.test(x3) && bigf->cells >= 16 * (int64_t)net.big_iters) {
+                int n3 = n_in;
+                bool fits = true;
+                for (size_t l = 0; l < live.size() && fits; ++l) {
+                    const PF &f = pool[live[l]];
+                    if (f.scope.test(x2) || f.scope.test(x3)) {
+                        if (n3 >= kMaxIn || f.cells > net.small_cells) fits = false;
+                        else ins[n3++] = &f;
+                    }
+                }
+                if (fits) {
+                    const int X[3] = {x, x2, x3};
+                    pool.emplace_back();
+                    if (em.emit(ins, n3, X, 3, false, 0, pool.back(), true)) {
+                        k = 0;
+                        for (size_t l = 0; l < live.size(); ++l)
+                            if (!pool[live[l]].scope.test(x2) && !pool[live[l]].scope.test(x3)) live[k++] = live[l];
+                        live.resize(k);
+                        live.push_back((int)pool.size() - 1);
+                        i += 2;
+                        continue;
+                    }
+                    pool.pop_back();
+                    if (!em.err.empty()) return em.err;
+                }
+            }
+        }
         if (net.fuse && i + 1 < best.size() && n_in < kMaxIn && pool.size() + 1 <= pool.capacity()) {
             const int32_t x2 = best[i + 1];
             bool link = false;
@@ -1310,6 +1542,7 @@ const char *kernel_name(int kid) {
                 for (int n = 0; n < 6; ++n)
                     names[kKidFiber0 + (nb - 1) * 18 + c * 6 + n] =
                         "fiber<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
+        names[kKidChain] = "fiber<1,cx64,chain-mfma>";  // (the slot of the impossible class <2,cxN,outer-mfma>)
         for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic<" + std::to_string(j + 1) + ">";
         init = true;
     }
@@ -1338,6 +1571,7 @@ int kernel_id_of_step(const uint32_t *w) {
     const uint32_t kind = w[0] & 0xff;
     if (kind == kKindFiber) {
         const int nb = w[7] & 0xf;
+        if ((w[1] >> 16) & kFlagChain) return kKidChain;
         return kKidFiber0 + (nb - 1) * 18 + fiber_cx_class(w) * 6 + fiber_nc_class(w);
     }
     const int n_in = (w[0] >> 8) & 0xff;

@@ -62,6 +62,7 @@ struct Network {
     int prune = 1;           // restrict a request to the ancestors of its query / evidence variables (bayes_net.py:763-765)
     int outer = 1;           // OUTER form (fp64 MFMA) for products of two big tables
     int fuse = 1;            // eliminate two consecutive variables in one FIBER step when the first result would be a big table
+    int chain = 0;           // CHAIN form: a third variable eliminated in the registers of the same pass (experimental)
 
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
@@ -123,7 +124,17 @@ struct PlanStats {
 //      4 row blocks of 16 cells that share one T[., ., ctrl] slice - block rb = cells (i % s) + s*rb + 4*s*(i / s),
 //      i < 16 - so that per block the step is a dense [16 x cx] x [cx x 16] product.  s = 16 when no ctrl axis lies
 //      inside a wave's 64 cells, s = 1 / 4 / 16 = the cell stride of the single 4-state ctrl axis that does.
-constexpr uint32_t kFlagFinal = 1, kFlagContig = 2, kFlagOuter = 4;
+//      flag CHAIN (one big input F, three 4-state variables x1, x2, x3 eliminated in one pass):
+//           out[r, n12, n3] = sum_x3 T3[x3, n3, n12?, ctrl3(r)] * sum_x12 F[r, x12, x3] * T12[n12, x12, ctrl12(r), x3?]
+//      - the pair (x1, x2) goes through the fp64-MFMA row-block product of the plain form, once per value of x3,
+//      and x3 is summed out of the four accumulators in registers.  T12 = product of the small inputs that depend on
+//      x1 or x2 (x3, if they depend on it, is its last ctrl dimension), T3 = product of those that depend on x3 only,
+//      tabulated after T12 in LDS over (x3, n3, [n1, n2,] ctrl3 axes).  The three new variables are the three fastest
+//      output axes (n12 at strides 1 and 4, n3 at 16).  Encoded with n_big = 2: big record 1 is (T12 cells = offset
+//      of T3, T3 cells, stride of x3 in F, stride of x3 in T12) and bstride[1][.] are the T3 strides of the R axes.
+//      After nout[]: n_small3, n_dims3 | (T3 depends on n12) << 8, tcard3[n_dims3], then per small-3 input: off lo,
+//      off hi, stride[n_dims3].
+constexpr uint32_t kFlagFinal = 1, kFlagContig = 2, kFlagOuter = 4, kFlagChain = 8;
 constexpr int kRowStrideShift = 20;  // w1 bits 20..27
 constexpr int kHdrWords = 10;
 constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;
@@ -218,6 +229,7 @@ struct Launch {
 };
 constexpr int kKidSeg = 0;         // segments of small GENERIC steps
 constexpr int kKidFiber0 = 1;      // 36 FIBER tile classes: 1 + (n_big-1)*18 + cx_class*6 + nc_class
+constexpr int kKidChain = 36;      // CHAIN steps (takes the id of the impossible FIBER class <2, cxN, outer-mfma>)
 constexpr int kKidGeneric0 = 37;   // 6 GENERIC tile classes: 37 + (n_in - 1)
 constexpr int kNumKernels = 43;
 const char *kernel_name(int kid);

@@ -30,6 +30,7 @@ def lib():
         L.plan_sim_set_small_cells.argtypes = [C.c_int]
         L.plan_sim_set_tiling.argtypes = [C.c_int, C.c_int]
         L.plan_sim_set_fuse.argtypes = [C.c_int]
+        L.plan_sim_set_chain.argtypes = [C.c_int]
         L.plan_sim_set_prune.argtypes = [C.c_int]
         _lib = L
     return _lib
@@ -43,6 +44,7 @@ class SimEngine:
         self.tiling = tiling            # (big_iters, tile_h): lower them to force tiled levels on small networks
         self.fuse = fuse                # joint elimination of two variables per FIBER step
         self.prune = 1                  # 0: multiply every CPT (full_joint_dist / predict_proba)
+        self.chain = 0                  # CHAIN form (three variables per pass)
         self.f = flat
         self.card = flat.card
         self.last_stats = None
@@ -63,6 +65,7 @@ class SimEngine:
         L.plan_sim_set_tiling(int(self.tiling[0]), int(self.tiling[1]))
         L.plan_sim_set_fuse(int(self.fuse))
         L.plan_sim_set_prune(int(self.prune))
+        L.plan_sim_set_chain(int(self.chain))
         rc = L.plan_sim_query(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64),
                               p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
                               p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
@@ -76,6 +79,8 @@ class SimEngine:
     def set_option(self, name, value):
         if name == "prune":
             self.prune = int(value)
+        elif name == "chain":
+            self.chain = int(value)
         else:
             raise KeyError(name)
 
