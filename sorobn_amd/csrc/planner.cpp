@@ -867,10 +867,11 @@ struct Emitter {
             }
         }
         if (nn12 != 2 || nax3 < 0) return false;
-        // re-order the three fastest output axes: n12 at strides 1 and 4, n3 at 16 (their cards are equal, the strides of
-        // the other axes do not change)
+        // re-order the three fastest output axes: n3 at stride 1, n12 at strides 4 and 16 - a lane of the kernel owns the
+        // four n3 values of its (cell, n12): one 32-byte store (their cards are equal, the strides of the other axes
+        // do not change)
         int ord[kRawAxes];
-        ord[0] = nax12[0]; ord[1] = nax12[1]; ord[2] = nax3;
+        ord[0] = nax3; ord[1] = nax12[0]; ord[2] = nax12[1];
         for (int a = 3; a < na; ++a) ord[a] = a;
         int64_t s[kMaxIn][kRawAxes];
         for (int j = 0; j < n_in; ++j)
@@ -979,8 +980,8 @@ struct Emitter {
             *p++ = (uint32_t)(ins[j]->off >> 32);
             *p++ = (uint32_t)(int32_t)xs[j][0];
             *p++ = (uint32_t)(int32_t)xs[j][1];
-            *p++ = (uint32_t)(int32_t)s[j][0];
             *p++ = (uint32_t)(int32_t)s[j][1];
+            *p++ = (uint32_t)(int32_t)s[j][2];
             for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)(int32_t)s[j][c12[i]];
             if (x3dep) *p++ = (uint32_t)(int32_t)xs[j][2];
         }
@@ -988,7 +989,7 @@ struct Emitter {
         *p++ = 4;
         for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)net.card[out.vars[c12[i]]];
         if (x3dep) *p++ = 4;
-        for (int n = 0; n < 16; ++n) *p++ = (uint32_t)n;
+        for (int n = 0; n < 16; ++n) *p++ = (uint32_t)(4 * n);
         *p++ = (uint32_t)n3s;
         *p++ = (uint32_t)nd3 | (n12dep ? 256u : 0u);
         *p++ = 4;  // x3
@@ -1000,8 +1001,8 @@ struct Emitter {
             *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
             *p++ = (uint32_t)(ins[j]->off >> 32);
             *p++ = (uint32_t)(int32_t)xs[j][2];
-            *p++ = (uint32_t)(int32_t)s[j][2];
-            if (n12dep) { *p++ = (uint32_t)(int32_t)s[j][0]; *p++ = (uint32_t)(int32_t)s[j][1]; }
+            *p++ = (uint32_t)(int32_t)s[j][0];
+            if (n12dep) { *p++ = (uint32_t)(int32_t)s[j][1]; *p++ = (uint32_t)(int32_t)s[j][2]; }
             for (int i = 0; i < nc3; ++i) *p++ = (uint32_t)(int32_t)s[j][c3[i]];
         }
         for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = (uint32_t)m12[a]; }
@@ -1592,6 +1593,7 @@ int step_tile_h(const Network &net, const uint32_t *w) {
     // bytes one hi iteration moves = the step's section-8(d) traffic / hi (broadcast re-reads of a small "big" input
     // are cache hits, they do not count)
     const int64_t per_iter = std::max<int64_t>(1, step_cost_bytes(w) / std::max<int64_t>(1, (int64_t)w[3]));
+    // (CHAIN steps - 256 KiB per iteration - end up with one iteration per tile; 4 per tile measured 11 % slower)
     return (int)std::max<int64_t>(1, std::min<int64_t>(kTileMax, kTileBytes / per_iter));
 }
 

@@ -192,7 +192,7 @@ __device__ __forceinline__ void generic_dispatch(int n_in, const uint32_t *sw, i
 // Decoded layout of a FIBER step descriptor (LDS copy).
 struct FiberDesc {
     int na, nlo, cx, c1, lo_cells, ns, nN, nctrl, NC, T, nT, nb;
-    const uint32_t *bigs, *smalls, *tcard, *nout, *nB, *rax;
+    const uint32_t *bigs, *smalls, *tcard, *nout, *nB, *chain, *rax;
     const int *bst;
 };
 
@@ -221,6 +221,8 @@ __device__ __forceinline__ FiberDesc fiber_desc(const uint32_t *sw) {
     q += d.NC;
     d.nB = q;  // OUTER only: offset of N-combination n in the second big input
     if ((sw[1] >> 16) & kFlagOuter) q += d.NC;
+    d.chain = q;  // CHAIN only: n_small3, n_dims3 | n12dep << 8, tcard3[], then (off lo, off hi, stride[n_dims3]) per input
+    if ((sw[1] >> 16) & kFlagChain) { const int nd3 = (int)(q[1] & 0xff); q += 2 + nd3 + (int)q[0] * (2 + nd3); }
     d.rax = q;  // (card, ostride, tstride) per R axis
     q += 3 * d.na;
     d.bst = (const int *)q;  // bst[b * na + a]
@@ -653,6 +655,110 @@ __device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__re
     }
 }
 
+// CHAIN class (planner.h): three 4-state variables of one big table F per pass.  Per row block (16 cells sharing their
+// table slices) and value of x3 the pair (x1, x2) is the [16 x 16] x [16 x 16] fp64-MFMA product of fiber_mfma_call
+// against T12[., ., ctrl12, x3]; x3 is then summed out of the four accumulators in registers against T3 (16 values per
+// lane: its output column's [n3][x3] slice).  16 loads, 16 MFMAs, 64 FMAs and 8 16-byte stores per lane and row block;
+// the 64 outputs of a cell are contiguous with n3 fastest, so a lane stores 32 contiguous bytes per cell.
+__device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
+                                                uint32_t *__restrict__ shX, const double *__restrict__ pool,
+                                                double *__restrict__ slot, const int tid, const int h_begin, const int h_end) {
+    const LaneOff lane_off = fiber_prologue(sw, shT, sh_hoff, pool, slot, tid, h_begin, h_end);  // builds T12 (x3 = its last ctrl dimension)
+    const FiberDesc d = fiber_desc(sw);
+    const int T12 = (int)d.bigs[4], T3 = (int)d.bigs[5], fx3 = (int)d.bigs[6], t12x3 = (int)d.bigs[7];
+    {   // T3[x3 + 4*n3 (+ 16*n12) + ctrl3...] after T12
+        const int n3s = (int)d.chain[0], nd3 = (int)(d.chain[1] & 0xff);
+        const uint32_t *tcard3 = d.chain + 2, *recs = d.chain + 2 + nd3;
+        for (int t = tid; t < T3; t += kWG) {
+            double v = 1.0;
+            for (int j = 0; j < n3s; ++j) {
+                const uint32_t *rec = recs + j * (2 + nd3);
+                int off = 0, c = t;
+                for (int k = 0; k < nd3; ++k) { const int cd = (int)tcard3[k]; const int qq = c / cd; off += (c - qq * cd) * (int)rec[2 + k]; c = qq; }
+                v *= table_ptr(rec[0], rec[1], pool, slot)[off];
+            }
+            shT[T12 + t] = v;
+        }
+    }
+    const bool n12dep = ((d.chain[1] >> 8) & 1) != 0;
+    double *__restrict__ outp = slot + ((uint64_t)sw[4] | ((uint64_t)sw[5] << 32));
+    const double *__restrict__ F = table_ptr(d.bigs[0], d.bigs[1], pool, slot);
+    const int bxs1 = (int)d.bigs[2], bxs2 = (int)d.bigs[3];
+    int *sh_cell = reinterpret_cast<int *>(shX);  // [4][kWG]: F offset, T3 offset, T12 offset, output offset of every lane cell
+    sh_cell[tid] = lane_off.b0;
+    sh_cell[kWG + tid] = lane_off.b1;
+    sh_cell[2 * kWG + tid] = lane_off.t;
+    sh_cell[3 * kWG + tid] = lane_off.o;
+    __syncthreads();  // (also: T3 is complete)
+    const int nh = h_end - h_begin;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);
+    uint32_t la[4];
+    int tb[4], t3b[4], oc[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);
+        la[rb] = (uint32_t)(sh_cell[c] + lk * bxs1);
+        tb[rb] = sh_cell[2 * kWG + wave * 64 + rs * rb] + lrow + 16 * lk;
+        t3b[rb] = T12 + sh_cell[kWG + wave * 64 + rs * rb] + (n12dep ? 16 * lrow : 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = lk + 4 * v;
+            const int cell = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+            oc[rb][v] = cell < d.lo_cells ? sh_cell[3 * kWG + cell] + 4 * lrow : -1;
+        }
+    }
+    // two load buffers: the 16 loads of the next row block are issued before the MFMAs of the current one
+    double fa[4][4], fb[4][4];  // [x3][ks]
+    auto issue = [&](const int hh, const int rb, double (&dst)[4][4]) {
+#pragma unroll
+        for (int x3 = 0; x3 < 4; ++x3)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double *__restrict__ bk = F + (uni(sh_hoff[2][hh]) + ks * bxs2 + x3 * fx3);
+                dst[x3][ks] = bk[la[rb]];
+            }
+    };
+    auto finish = [&](const int hh, const int rb, const double (&a)[4][4]) {
+        const int ho = uni(sh_hoff[0][hh]), ht = uni(sh_hoff[1][hh]), ht3 = uni(sh_hoff[3][hh]);
+        v4d acc[4];
+#pragma unroll
+        for (int x3 = 0; x3 < 4; ++x3) acc[x3] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int x3 = 0; x3 < 4; ++x3)
+                acc[x3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x3][ks], shT[ht + tb[rb] + x3 * t12x3 + 64 * ks], acc[x3], 0, 0, 0);
+        const double *__restrict__ t3p = shT + (ht3 + t3b[rb]);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // the four n3 values of (cell, n12) are 32 contiguous bytes: two 16-byte stores
+            v4d o[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int n3 = 2 * half + e;
+                o[e] = acc[0] * t3p[4 * n3];
+#pragma unroll
+                for (int x3 = 1; x3 < 4; ++x3) o[e] += acc[x3] * t3p[4 * n3 + x3];
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (oc[rb][v] >= 0) reinterpret_cast<double2 *>(outp + (ho + oc[rb][v]))[half] = make_double2(o[0][v], o[1][v]);
+        }
+    };
+    issue(0, 0, fa);
+    for (int hh = 0; hh < nh; ++hh) {
+        issue(hh, 1, fb);
+        finish(hh, 0, fa);
+        issue(hh, 2, fa);
+        finish(hh, 1, fb);
+        issue(hh, 3, fb);
+        finish(hh, 2, fa);
+        if (hh + 1 < nh) issue(hh + 1, 0, fa);
+        finish(hh, 3, fb);
+    }
+}
+
 // posterior / posterior.sum()  (bayes_net.py:790); an all-zero table (zero-probability evidence) stays zero
 __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double *sh_red, int tid) {
     double s = 0.0;
@@ -711,7 +817,9 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
     __syncthreads();
     const int h0 = (int)((wg - it.b) * it.a);
     const int h1 = min((int)sh_step[3], h0 + (int)it.a);
-    if ((sh_step[0] & 0xff) == kKindFiber) {
+    if ((sh_step[0] & 0xff) == kKindFiber && ((sh_step[1] >> 16) & kFlagChain)) {
+        chain_mfma_call(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1);
+    } else if ((sh_step[0] & 0xff) == kKindFiber) {
         const int cx = (int)(sh_step[1] & 0xffff), c1 = (int)(sh_step[8] >> 16), NC = (int)(sh_step[7] >> 16);
         const bool contig = ((sh_step[1] >> 16) & kFlagContig) != 0;
         const int cxc = (cx == 4 && c1 == 4) ? 0 : ((cx == 16 && c1 == 4) ? 1 : 2);

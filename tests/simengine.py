@@ -44,7 +44,7 @@ class SimEngine:
         self.tiling = tiling            # (big_iters, tile_h): lower them to force tiled levels on small networks
         self.fuse = fuse                # joint elimination of two variables per FIBER step
         self.prune = 1                  # 0: multiply every CPT (full_joint_dist / predict_proba)
-        self.chain = 0                  # CHAIN form (three variables per pass)
+        self.chain = 1                  # CHAIN form (three variables per pass), on by default like the product
         self.f = flat
         self.card = flat.card
         self.last_stats = None

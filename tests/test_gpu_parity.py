@@ -98,6 +98,39 @@ def test_c3_fused_vs_single_variable_passes(amd):
     assert float(np.max(np.abs(fused - single))) <= 1e-13
 
 
+def test_c3_chain_form_vs_pair_form(amd):
+    """CHAIN steps (three variables per pass: pair MFMA + register epilogue, the default) against two-variable
+    passes only (option chain=0) on the C3 stream and on the golden 10x10 requests: a different contraction order of the same
+    numbers, fewer bytes."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 4096, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    be.engine.set_option("chain", 0)
+    pair = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    pair_bytes = be.engine.stats()["alg_bytes"]
+    be.engine.set_option("chain", 1)  # the default
+    be.engine.set_option("split_kinds", 1)
+    chain = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert be.engine.stats()["alg_bytes"] < 0.9 * pair_bytes
+    assert any("chain" in k["name"] for k in be.engine.kernel_stats()), [k["name"] for k in be.engine.kernel_stats()]
+    assert np.allclose(chain.sum(1), 1.0, atol=1e-12)
+    assert float(np.max(np.abs(chain - pair))) <= 1e-13
+    be.engine.set_option("split_kinds", 0)
+    entry = gu.load("grid10x10.json")
+    _check_requests(bn, entry["requests"], "grid10x10 chain")
+    for e in gu.load("grids_small.json"):
+        sp = gu.grid_spec_from_recipe(e)
+        for small_cells, tiling in [(3, (4, 1)), (20, (64, 2))]:
+            b = netspec.build(sp, amd.BayesNet)
+            b.backend.engine.set_option("chain", 1)
+            b.backend.engine.set_option("small_cells", small_cells)
+            b.backend.engine.set_option("big_iters", tiling[0])
+            b.backend.engine.set_option("tile_h", tiling[1])
+            _check_requests(b, e["requests"], sp["name"] + " chain")
+
+
 def test_c3_bayes_rule_and_marginalisation_at_full_size(amd):
     """Size-independent properties on the BASELINE C3 stream, whole-grid requests included (no CPU oracle finishes
     those): (i) P(q | e1..e4) equals the slice e4 = v of the two-variable posterior P(q, e4 | e1..e3), renormalised

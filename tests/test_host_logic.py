@@ -224,6 +224,31 @@ def test_order_choice_never_worse_than_row_major():
     assert ours.mean() < 0.5 * rm.mean()
 
 
+def test_chain_form_on_the_simulator():
+    """CHAIN steps (three variables per pass, option chain=1): the planner's programs, executed by the simulator,
+    reproduce the reference's answers on the 10x10 grid and move fewer bytes than the two-variable passes."""
+    entry = gu.load("grid10x10.json")
+    spec = gu.grid_spec_from_recipe(entry)
+    bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
+    assert bn.backend.engine.chain == 1  # the default, as in the product
+    _check_requests(bn, entry["requests"], spec["name"] + " chain")
+    bn.backend.engine.set_option("chain", 0)
+    _check_requests(bn, entry["requests"][-6:], spec["name"] + " pairs only")
+    f = flatten(netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet))
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
+    q, ev, ec = netspec.c3_requests(100, 4, 24, 4, seed=1)
+    plain, chain = simengine.SimEngine(f), simengine.SimEngine(f)
+    plain.set_option("chain", 0)
+    b0 = b1 = 0.0
+    for i in range(24):
+        a = plain._one([to_var[q[i]]], to_var[ev[i]], ec[i])
+        b0 += plain.last_stats[0]
+        b = chain._one([to_var[q[i]]], to_var[ev[i]], ec[i])
+        b1 += chain.last_stats[0]
+        assert float(np.max(np.abs(a - b))) <= 1e-14
+    assert b1 < 0.9 * b0
+
+
 def test_c3_bayes_rule_and_marginalisation_on_the_simulator():
     """CPU twin of the GPU test of the same name: P(q | e1..e4) against the renormalised slice of P(q, e4 | e1..e3)
     and the marginal of that joint against P(q | e1..e3), planner programs executed by the simulator."""

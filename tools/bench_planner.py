@@ -21,7 +21,7 @@ to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
 Q = np.ascontiguousarray(to_var[q]); E = np.ascontiguousarray(to_var[ev]); EC = np.ascontiguousarray(ec)
 L = simengine.lib()
 L.plan_sim_bench.restype = C.c_double
-L.plan_sim_set_chain(int(os.environ.get("CHAIN", "0")))
+L.plan_sim_set_chain(int(os.environ.get("CHAIN", "1")))
 p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
 hints = np.ascontiguousarray(np.stack(f.hints).reshape(-1), np.int32)
 for threads in [int(t) for t in (sys.argv[2:] or ["1", "8"])]:
