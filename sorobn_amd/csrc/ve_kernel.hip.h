@@ -411,17 +411,42 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (hh + u < nh) {
+                    // A table of a two-table step often lacks one of the two eliminated variables (a sweep meeting
+                    // another one): 4 distinct values then, not 16 - these steps are bound by L1 load issue, not by HBM.
+                    // (inactive lanes carry offset 0: they load a valid cell and never store)
+                    auto gather = [&](const int b, const int hrow, const uint32_t loff, const bool first) {
+                        const int s1 = bxs1[b], s2 = bxs2[b];
+                        const int hb = uni(sh_hoff[hrow][hh + u]);
+                        if (NBIG > 1 && CX == 16 && s1 == 0) {
 #pragma unroll
-                    for (int x = 0; x < (CX ? CX : 1); ++x) {
-                        const double *__restrict__ b0 = big[0] + (uni(sh_hoff[2][hh + u]) + (x & 3) * bxs1[0] + (x >> 2) * bxs2[0]);
-                        // (inactive lanes carry offset 0: they load a valid cell and never store)
-                        double p = b0[(uint32_t)lane_off[2]];
-                        if (NBIG > 1) {
-                            const double *__restrict__ b1 = big[NBIG - 1] + (uni(sh_hoff[3][hh + u]) + (x & 3) * bxs1[NBIG - 1] + (x >> 2) * bxs2[NBIG - 1]);
-                            p *= b1[(uint32_t)lane_off[3]];
+                            for (int x2 = 0; x2 < 4; ++x2) {
+                                const double v = (big[b] + (hb + x2 * s2))[loff];
+#pragma unroll
+                                for (int x1 = 0; x1 < 4; ++x1) {
+                                    double &t = dst[u][(x1 + 4 * x2) % (CX ? CX : 1)];
+                                    t = first ? v : t * v;
+                                }
+                            }
+                        } else if (NBIG > 1 && CX == 16 && s2 == 0) {
+#pragma unroll
+                            for (int x1 = 0; x1 < 4; ++x1) {
+                                const double v = (big[b] + (hb + x1 * s1))[loff];
+#pragma unroll
+                                for (int x2 = 0; x2 < 4; ++x2) {
+                                    double &t = dst[u][(x1 + 4 * x2) % (CX ? CX : 1)];
+                                    t = first ? v : t * v;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < (CX ? CX : 1); ++x) {
+                                const double v = (big[b] + (hb + (x & 3) * s1 + (x >> 2) * s2))[loff];
+                                dst[u][x] = first ? v : dst[u][x] * v;
+                            }
                         }
-                        dst[u][x] = p;
-                    }
+                    };
+                    gather(0, 2, (uint32_t)lane_off[2], true);
+                    if (NBIG > 1) gather(NBIG - 1, 3, (uint32_t)lane_off[3], false);
                 }
             }
         };
