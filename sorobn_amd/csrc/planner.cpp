@@ -846,7 +846,7 @@ struct Emitter {
         if (n12 > kMaxSmall || n3s < 1 || n3s > 2) return false;
         const int na = out.n;
         if (na < 3) return false;
-        // the three new axes: two of the pair tables, one of the third variable's; they must be the three fastest
+        // the three new axes: two of the pair tables, one of the third variable's
         int nax12[2], nn12 = 0, nax3 = -1;
         bool n12dep = false;
         for (int a = 0; a < na; ++a) {
@@ -854,7 +854,7 @@ struct Emitter {
             bool dep12 = false, dep3 = false;
             for (int k = 0; k < n12; ++k) dep12 = dep12 || s_in[g12[k]][a] != 0;
             for (int k = 0; k < n3s; ++k) dep3 = dep3 || s_in[g3[k]][a] != 0;
-            if (a > 2 || net.card[out.vars[a]] != 4) return false;
+            if (net.card[out.vars[a]] != 4) return false;
             if (dep12) {
                 if (nn12 >= 2) return false;
                 nax12[nn12++] = a;
@@ -867,23 +867,31 @@ struct Emitter {
             }
         }
         if (nn12 != 2 || nax3 < 0) return false;
-        // re-order the three fastest output axes: n3 at stride 1, n12 at strides 4 and 16 - a lane of the kernel owns the
-        // four n3 values of its (cell, n12): one 32-byte store (their cards are equal, the strides of the other axes
-        // do not change)
+        // the layout of the output is ours to choose: the three new axes become the fastest ones - n3 at stride 1, n12
+        // at strides 4 and 16, a lane of the kernel owns the four n3 values of its (cell, n12): one 32-byte store - and
+        // the other axes keep their order (longest-living first)
         int ord[kRawAxes];
         ord[0] = nax3; ord[1] = nax12[0]; ord[2] = nax12[1];
-        for (int a = 3; a < na; ++a) ord[a] = a;
-        int64_t s[kMaxIn][kRawAxes];
-        for (int j = 0; j < n_in; ++j)
-            for (int a = 0; a < na; ++a) s[j][a] = s_in[j][ord[a]];
-        int32_t vars2[3] = {out.vars[ord[0]], out.vars[ord[1]], out.vars[ord[2]]};
+        for (int a = 0, k = 3; a < na; ++a)
+            if (a != nax3 && a != nax12[0] && a != nax12[1]) ord[k++] = a;
+        int64_t s[kMaxIn][kRawAxes], ostr[kRawAxes];
+        int32_t vars2[kRawAxes];
+        {
+            int64_t cells = 1;
+            for (int a = 0; a < na; ++a) {
+                vars2[a] = out.vars[ord[a]];
+                ostr[a] = cells;
+                cells *= net.card[vars2[a]];
+                for (int j = 0; j < n_in; ++j) s[j][a] = s_in[j][ord[a]];
+            }
+        }
         // R axes; ctrl axes of T12 / of T3 = R axes a pair-group / third-group small input depends on
         int64_t rcard[kRawAxes], rost[kRawAxes], rt12[kRawAxes], rt3[kRawAxes], rbig[kRawAxes];
         int c12[kRawAxes], c3[kRawAxes], nc12 = 0, nc3 = 0, nr = 0;
         int64_t T12 = 256, T3 = n12dep ? 256 : 16;
         for (int a = 3; a < na; ++a) {
-            rcard[nr] = net.card[out.vars[a]];
-            rost[nr] = out.strides[a];
+            rcard[nr] = net.card[vars2[a]];
+            rost[nr] = ostr[a];
             rbig[nr] = s[big][a];
             bool dep12 = false, dep3 = false;
             for (int k = 0; k < n12; ++k) dep12 = dep12 || s[g12[k]][a] != 0;
@@ -958,7 +966,7 @@ struct Emitter {
         const int words = kHdrWords + 8 + n12 * (4 + nT) + nT + 16 + 2 + nd3 + n3s * (2 + nd3) + 3 * ma + 2 * ma;
         if (words > kMaxStepWords) return false;
         // commit the axis order of the output
-        for (int a = 0; a < 3; ++a) out.vars[a] = vars2[a];
+        for (int a = 0; a < na; ++a) { out.vars[a] = vars2[a]; out.strides[a] = ostr[a]; }
         uint32_t *w = prog.extend(words);
         header(w, kKindFiber, n_in, ma, mlo, 16, false, lo, rcells / lo, out.off, words);
         w[1] |= (kFlagChain | kFlagContig) << 16;
@@ -987,7 +995,7 @@ struct Emitter {
         }
         *p++ = 4;
         *p++ = 4;
-        for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)net.card[out.vars[c12[i]]];
+        for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)net.card[vars2[c12[i]]];
         if (x3dep) *p++ = 4;
         for (int n = 0; n < 16; ++n) *p++ = (uint32_t)(4 * n);
         *p++ = (uint32_t)n3s;
@@ -995,7 +1003,7 @@ struct Emitter {
         *p++ = 4;  // x3
         *p++ = 4;  // n3
         if (n12dep) { *p++ = 4; *p++ = 4; }
-        for (int i = 0; i < nc3; ++i) *p++ = (uint32_t)net.card[out.vars[c3[i]]];
+        for (int i = 0; i < nc3; ++i) *p++ = (uint32_t)net.card[vars2[c3[i]]];
         for (int k = 0; k < n3s; ++k) {
             const int j = g3[k];
             *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
