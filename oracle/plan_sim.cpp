@@ -106,7 +106,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
         const uint32_t *tcard = q; q += nT;
         const uint32_t *nout = q; q += 16;
         for (int n = 0; n < 16; ++n)
-            if (nout[n] != (uint32_t)(4 * n)) { g_err = "CHAIN step with scattered N offsets"; return -9; }
+            if (nout[n] != (uint32_t)n) { g_err = "CHAIN step with scattered N offsets"; return -9; }
         const int n3s = (int)q[0], nd3 = (int)(q[1] & 0xff);
         const bool n12dep = (q[1] >> 8) & 1;
         q += 2;
@@ -195,7 +195,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
                 for (int n3 = 0; n3 < 4; ++n3) {
                     double acc = 0.0;
                     for (int x3 = 0; x3 < 4; ++x3) acc += g[x3] * T3t[(size_t)(t3o + (n12dep ? 16 * n : 0) + 4 * n3 + x3)];
-                    const int64_t o = oo + 4 * n + n3;
+                    const int64_t o = oo + n + 16 * n3;
                     if (o < 0 || o >= total_cells) { g_err = "chain output offset out of range"; return -8; }
                     writes.emplace_back(o, acc);
                 }

@@ -867,13 +867,24 @@ struct Emitter {
             }
         }
         if (nn12 != 2 || nax3 < 0) return false;
-        // the layout of the output is ours to choose: the three new axes become the fastest ones - n3 at stride 1, n12
-        // at strides 4 and 16, a lane of the kernel owns the four n3 values of its (cell, n12): one 32-byte store - and
-        // the other axes keep their order (longest-living first)
+        // the layout of the output is ours to choose: the three new axes become the fastest ones - n12 at strides 1 and
+        // 4 (16 lanes of the kernel write one full 128-byte line), n3 at 16 - and the other axes follow ...  (n3 fastest + 16-byte stores was tried: the half-written lines made L2 fetch the
+        // output before overwriting it, +19 % HBM reads.)
         int ord[kRawAxes];
-        ord[0] = nax3; ord[1] = nax12[0]; ord[2] = nax12[1];
-        for (int a = 0, k = 3; a < na; ++a)
-            if (a != nax3 && a != nax12[0] && a != nax12[1]) ord[k++] = a;
+        ord[0] = nax12[0]; ord[1] = nax12[1]; ord[2] = nax3;
+        {   // ... in the order F stores them: a wave's 64 cells are then 512 contiguous bytes of every F slice too (with
+            // the output's own order the lanes of a row block gathered 32-byte pieces of four lines, and the four row
+            // blocks - loaded at different times - fetched every line of F 1.5 times from HBM)
+            int k = 3;
+            for (int a = 0; a < na; ++a)
+                if (a != nax3 && a != nax12[0] && a != nax12[1]) ord[k++] = a;
+            for (int i = 4; i < na; ++i) {
+                const int a = ord[i];
+                int j = i - 1;
+                while (j >= 3 && s_in[big][ord[j]] > s_in[big][a]) { ord[j + 1] = ord[j]; --j; }
+                ord[j + 1] = a;
+            }
+        }
         int64_t s[kMaxIn][kRawAxes], ostr[kRawAxes];
         int32_t vars2[kRawAxes];
         {
@@ -988,8 +999,8 @@ struct Emitter {
             *p++ = (uint32_t)(ins[j]->off >> 32);
             *p++ = (uint32_t)(int32_t)xs[j][0];
             *p++ = (uint32_t)(int32_t)xs[j][1];
+            *p++ = (uint32_t)(int32_t)s[j][0];
             *p++ = (uint32_t)(int32_t)s[j][1];
-            *p++ = (uint32_t)(int32_t)s[j][2];
             for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)(int32_t)s[j][c12[i]];
             if (x3dep) *p++ = (uint32_t)(int32_t)xs[j][2];
         }
@@ -997,7 +1008,7 @@ struct Emitter {
         *p++ = 4;
         for (int i = 0; i < nc12; ++i) *p++ = (uint32_t)net.card[vars2[c12[i]]];
         if (x3dep) *p++ = 4;
-        for (int n = 0; n < 16; ++n) *p++ = (uint32_t)(4 * n);
+        for (int n = 0; n < 16; ++n) *p++ = (uint32_t)n;
         *p++ = (uint32_t)n3s;
         *p++ = (uint32_t)nd3 | (n12dep ? 256u : 0u);
         *p++ = 4;  // x3
@@ -1009,8 +1020,8 @@ struct Emitter {
             *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
             *p++ = (uint32_t)(ins[j]->off >> 32);
             *p++ = (uint32_t)(int32_t)xs[j][2];
-            *p++ = (uint32_t)(int32_t)s[j][0];
-            if (n12dep) { *p++ = (uint32_t)(int32_t)s[j][1]; *p++ = (uint32_t)(int32_t)s[j][2]; }
+            *p++ = (uint32_t)(int32_t)s[j][2];
+            if (n12dep) { *p++ = (uint32_t)(int32_t)s[j][0]; *p++ = (uint32_t)(int32_t)s[j][1]; }
             for (int i = 0; i < nc3; ++i) *p++ = (uint32_t)(int32_t)s[j][c3[i]];
         }
         for (int a = 0; a < ma; ++a) { *p++ = (uint32_t)mc[a]; *p++ = (uint32_t)mo[a]; *p++ = (uint32_t)m12[a]; }

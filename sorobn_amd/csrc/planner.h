@@ -130,7 +130,7 @@ struct PlanStats {
 //      and x3 is summed out of the four accumulators in registers.  T12 = product of the small inputs that depend on
 //      x1 or x2 (x3, if they depend on it, is its last ctrl dimension), T3 = product of those that depend on x3 only,
 //      tabulated after T12 in LDS over (x3, n3, [n1, n2,] ctrl3 axes).  The three new variables are the three fastest
-//      output axes (n3 at stride 1, n12 at strides 4 and 16: nout[n] = 4*n).  Encoded with n_big = 2: big record 1 is (T12 cells = offset
+//      output axes (n12 at strides 1 and 4, n3 at 16).  Encoded with n_big = 2: big record 1 is (T12 cells = offset
 //      of T3, T3 cells, stride of x3 in F, stride of x3 in T12) and bstride[1][.] are the T3 strides of the R axes.
 //      After nout[]: n_small3, n_dims3 | (T3 depends on n12) << 8, tcard3[n_dims3], then per small-3 input: off lo,
 //      off hi, stride[n_dims3].

@@ -683,8 +683,8 @@ __device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__re
 // CHAIN class (planner.h): three 4-state variables of one big table F per pass.  Per row block (16 cells sharing their
 // table slices) and value of x3 the pair (x1, x2) is the [16 x 16] x [16 x 16] fp64-MFMA product of fiber_mfma_call
 // against T12[., ., ctrl12, x3]; x3 is then summed out of the four accumulators in registers against T3 (16 values per
-// lane: its output column's [n3][x3] slice).  16 loads, 16 MFMAs, 64 FMAs and 8 16-byte stores per lane and row block;
-// the 64 outputs of a cell are contiguous with n3 fastest, so a lane stores 32 contiguous bytes per cell.
+// lane: its output column's [n3][x3] slice).  16 loads, 16 MFMAs, 64 FMAs and 16 stores per lane and row block; the 64
+// outputs of a cell are contiguous (n12 fastest), every store instruction writes four full 128-byte lines.
 __device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
                                                 uint32_t *__restrict__ shX, const double *__restrict__ pool,
                                                 double *__restrict__ slot, const int tid, const int h_begin, const int h_end) {
@@ -731,7 +731,7 @@ __device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__re
         for (int v = 0; v < 4; ++v) {
             const int i = lk + 4 * v;
             const int cell = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
-            oc[rb][v] = cell < d.lo_cells ? sh_cell[3 * kWG + cell] + 4 * lrow : -1;
+            oc[rb][v] = cell < d.lo_cells ? sh_cell[3 * kWG + cell] + lrow : -1;
         }
     }
     // two load buffers: the 16 loads of the next row block are issued before the MFMAs of the current one
@@ -757,7 +757,7 @@ __device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__re
                 acc[x3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x3][ks], shT[ht + tb[rb] + x3 * t12x3 + 64 * ks], acc[x3], 0, 0, 0);
         const double *__restrict__ t3p = shT + (ht3 + t3b[rb]);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {  // the four n3 values of (cell, n12) are 32 contiguous bytes: two 16-byte stores
+        for (int half = 0; half < 2; ++half) {  // two n3 values at a time (register budget)
             v4d o[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -767,8 +767,10 @@ __device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__re
                 for (int x3 = 1; x3 < 4; ++x3) o[e] += acc[x3] * t3p[4 * n3 + x3];
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (oc[rb][v] >= 0) reinterpret_cast<double2 *>(outp + (ho + oc[rb][v]))[half] = make_double2(o[0][v], o[1][v]);
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (oc[rb][v] >= 0) outp[ho + oc[rb][v] + 16 * (2 * half + e)] = o[e][v];  // 16 lanes = one full 128-byte line
         }
     };
     issue(0, 0, fa);

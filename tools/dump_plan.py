@@ -57,8 +57,16 @@ def decode(w):
             d["tcard"] = [int(x) for x in w[q:q + nT]]; q += nT
             d["nout"] = [int(x) for x in w[q:q + NC]]; q += NC
             d["outer"] = (int(w[p + 1]) >> 18) & 1
+            d["chain"] = (int(w[p + 1]) >> 19) & 1
             if d["outer"]:
                 d["nB"] = [int(x) for x in w[q:q + NC]]; q += NC
+            if d["chain"]:  # big record 1 = (T12 cells, T3 cells, x3 stride in F, x3 stride in T12); bst[1] = T3 strides
+                n3s, nd3 = int(w[q]), int(w[q + 1]) & 0xff
+                d["chain3"] = dict(T12=int(w[p + 14]), T3=int(w[p + 15]), fx3=I(p + 16), t12x3=I(p + 17), n12dep=(int(w[q + 1]) >> 8) & 1,
+                                   tcard3=[int(x) for x in w[q + 2:q + 2 + nd3]],
+                                   small3=[("C" if int(w[q + 2 + nd3 + k * (2 + nd3) + 1]) >> 31 else "A",
+                                            [I(q + 2 + nd3 + k * (2 + nd3) + 2 + t) for t in range(nd3)]) for k in range(n3s)])
+                q += 2 + nd3 + n3s * (2 + nd3)
             d["rax"] = [(int(w[q + 3 * a]), I(q + 3 * a + 1), I(q + 3 * a + 2)) for a in range(na)]; q += 3 * na
             d["bst"] = [[I(q + b * na + a) for a in range(na)] for b in range(nb)]
         steps.append(d)
@@ -82,5 +90,7 @@ if __name__ == "__main__":
         if s["kind"] == "GENERIC":
             print(head, f"n_in={s['n_in']} card={s['card']} ins={s['ins']} strides={s['strides']}", "FINAL" if s["fin"] else "")
         else:
+            if s.get("chain"):
+                head += f" CHAIN {s['chain3']}"
             print(head, f"nb={s['nb']} ns={s['ns']} c1={s['c1']} NC={s['NC']} contig={s['contig']} outer={s['outer']} rs={(s['w1'] >> 20) & 0xff} nctrl={s['nctrl']} T={s['T']} big={s['big']} small={[(t, x) for t, x, _ in s['small']]} "
                         f"tcard={s['tcard']} nout={s['nout']} rax(card,ost,tst)={s['rax']} bst={s['bst']}")

@@ -30,6 +30,6 @@ for opts in os.environ.get("PROBE_SETS", "tile_h=128").split(";"):
         s = eng.stats()
     print(f"[{opts}] wall {dt*1e3:8.1f} ms kernel {s['kernel_ms']:8.2f} plan {s['plan_ms']:7.1f} h2d {s['h2d_ms']:6.1f} launches {s['n_launches']:.0f} "
           f"bytes {s['alg_bytes']/1e9:8.2f} GB -> {s['alg_bytes']/s['kernel_ms']/1e6:8.1f} GB/s wgs {s['n_workgroups']:.0f}", flush=True)
-    for k in sorted(eng.kernel_stats(), key=lambda k: -k["ms"])[:5]:
+    for k in sorted(eng.kernel_stats(), key=lambda k: -k["ms"])[:14]:
         print(f"      {k['name']:28s} launches {k['launches']:5.0f} items {k['items']:9.0f} ms {k['ms']:8.2f} "
               f"bytes {k['alg_bytes']/1e9:8.2f} GB -> {k['alg_bytes']/max(k['ms'],1e-9)/1e6:8.1f} GB/s")
