@@ -578,6 +578,18 @@ struct Emitter {
             int64_t expect = NC;
             for (int i = 0; i < nlo; ++i) { contig = contig && rost[i] == expect; expect *= rcard[i]; }
         }
+        if (nb == 2) {
+            // two tables: the wave-uniform (hi) axes only one of them depends on run fastest, the other table's values
+            // stay in the kernel's registers over those iterations (fiber_call<2, ...>)
+            int64_t tc[kRawAxes], to[kRawAxes], tt[kRawAxes], tb0[kRawAxes], tb1[kRawAxes];
+            int k = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int i = nlo; i < nr; ++i) {
+                    const bool single = (rb[0][i] == 0) != (rb[1][i] == 0);
+                    if (single == (pass == 0)) { tc[k] = rcard[i]; to[k] = rost[i]; tt[k] = rtst[i]; tb0[k] = rb[0][i]; tb1[k] = rb[1][i]; ++k; }
+                }
+            for (int i = 0; i < k; ++i) { rcard[nlo + i] = tc[i]; rost[nlo + i] = to[i]; rtst[nlo + i] = tt[i]; rb[0][nlo + i] = tb0[i]; rb[1][nlo + i] = tb1[i]; }
+        }
         // merge adjacent R axes contiguous in the output, in T and in every big input
         int64_t mc[kRawAxes], mo[kRawAxes], mt[kRawAxes], mb[2][kRawAxes];
         int ma = 0, mlo = 0;
@@ -758,6 +770,18 @@ struct Emitter {
         {
             int64_t expect = 16;
             for (int i = 0; i < nlo; ++i) { contig = contig && rost[i] == expect; expect *= rcard[i]; }
+        }
+        // iteration order of the wave-uniform (hi) axes: those only one of the two tables depends on run fastest, so that
+        // the other table's operand stays in the kernel's registers over consecutive iterations (outer_mfma_call)
+        {
+            int64_t tc[kRawAxes], to[kRawAxes], tt[kRawAxes], tb0[kRawAxes], tb1[kRawAxes];
+            int k = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int i = nlo; i < nr; ++i) {
+                    const bool single = (rb[0][i] == 0) != (rb[1][i] == 0);
+                    if (single == (pass == 0)) { tc[k] = rcard[i]; to[k] = rost[i]; tt[k] = rtst[i]; tb0[k] = rb[0][i]; tb1[k] = rb[1][i]; ++k; }
+                }
+            for (int i = 0; i < k; ++i) { rcard[nlo + i] = tc[i]; rost[nlo + i] = to[i]; rtst[nlo + i] = tt[i]; rb[0][nlo + i] = tb0[i]; rb[1][nlo + i] = tb1[i]; }
         }
         // merge adjacent R axes contiguous in the output, in T and in both inputs
         int64_t mc[kRawAxes], mo[kRawAxes], mt[kRawAxes], mb[2][kRawAxes];

@@ -460,7 +460,7 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
                 }
             }
         };
-        if (NBIG == 1 && MIBN_PIPELINE) {
+        if constexpr (NBIG == 1 && MIBN_PIPELINE) {
             // software pipeline: the next trip's loads are in flight while this trip is reduced and stored
             double fa[U][CX ? CX : 1], fb[U][CX ? CX : 1];
             issue(0, fa);
@@ -471,6 +471,42 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
                     if (hh + 2 * U < nh) issue(hh + 2 * U, fa);
                     finish(hh + U, fb);
                 }
+            }
+        } else if constexpr (NBIG == 2 && CX == 16) {
+            // two tables: a table whose wave-uniform offset did not change since the previous iteration (the planner makes
+            // the axes only the other table depends on run fastest) stays in registers - these steps are bound by L1 load
+            // issue, a reused table saves 4-16 of their 8-32 loads per output cell
+            double av[16], bv[16];
+            int prev_a = 0, prev_b = 0;
+            auto fetch = [&](const int b, const int hb, const uint32_t loff, double (&dst)[16]) {
+                const int s1 = bxs1[b], s2 = bxs2[b];
+                if (s1 == 0) {
+#pragma unroll
+                    for (int x2 = 0; x2 < 4; ++x2) {
+                        const double v = (big[b] + (hb + x2 * s2))[loff];
+#pragma unroll
+                        for (int x1 = 0; x1 < 4; ++x1) dst[x1 + 4 * x2] = v;
+                    }
+                } else if (s2 == 0) {
+#pragma unroll
+                    for (int x1 = 0; x1 < 4; ++x1) {
+                        const double v = (big[b] + (hb + x1 * s1))[loff];
+#pragma unroll
+                        for (int x2 = 0; x2 < 4; ++x2) dst[x1 + 4 * x2] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) dst[x] = (big[b] + (hb + (x & 3) * s1 + (x >> 2) * s2))[loff];
+                }
+            };
+            for (int hh = 0; hh < nh; ++hh) {
+                const int ha = uni(sh_hoff[2][hh]), hb = uni(sh_hoff[3][hh]);
+                if (hh == 0 || ha != prev_a) { fetch(0, ha, (uint32_t)lane_off[2], av); prev_a = ha; }
+                if (hh == 0 || hb != prev_b) { fetch(NBIG - 1, hb, (uint32_t)lane_off[3], bv); prev_b = hb; }
+                double f[1][CX ? CX : 1];
+#pragma unroll
+                for (int x = 0; x < 16; ++x) f[0][x % (CX ? CX : 1)] = av[x] * bv[x];
+                finish(hh, f);
             }
         } else {
             double fa[U][CX ? CX : 1];
@@ -649,30 +685,39 @@ __device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__re
             oc[rb][v] = oc_cell < d.lo_cells ? sh_cell[2 * kWG + oc_cell] + (int)d.nout[lrow] : -1;
         }
     }
+    // An operand whose wave-uniform offset did not change since the previous iteration (the iteration moved along an
+    // axis only the other table depends on) stays in registers: these steps multiply two tables over the union of
+    // their axes, every element of A feeds all the cells of B that share its batch axes and vice versa.
+    double a[4][KS], braw[4][KS];
+    int prev_a = 0, prev_b = 0;
     for (int hh = 0; hh < nh; ++hh) {
         const int ho = uni(sh_hoff[0][hh]);
-        const double *__restrict__ a0 = bigA + uni(sh_hoff[2][hh]);
-        const double *__restrict__ b0 = bigB + uni(sh_hoff[3][hh]);
-        double a[4][KS], b[4][KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                a[rb][ks] = a0[la[rb] + (uint32_t)(ks * axs2)];
-                b[rb][ks] = b0[lb[rb] + (uint32_t)(ks * bxs2)];
-            }
-        if (has_t) {
-            const int ht = uni(sh_hoff[1][hh]);
+        const int ha = uni(sh_hoff[2][hh]), hb = uni(sh_hoff[3][hh]);
+        if (hh == 0 || ha != prev_a) {
+            const double *__restrict__ a0 = bigA + ha;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) b[rb][ks] *= shT[ht + tb[rb] + 64 * ks];
+                for (int rb = 0; rb < 4; ++rb) a[rb][ks] = a0[la[rb] + (uint32_t)(ks * axs2)];
+            prev_a = ha;
         }
+        if (hh == 0 || hb != prev_b) {
+            const double *__restrict__ b0 = bigB + hb;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) braw[rb][ks] = b0[lb[rb] + (uint32_t)(ks * bxs2)];
+            prev_b = hb;
+        }
+        const int ht = has_t ? uni(sh_hoff[1][hh]) : 0;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][ks], b[rb][ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+                const double bo = has_t ? braw[rb][ks] * shT[ht + tb[rb] + 64 * ks] : braw[rb][ks];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][ks], bo, acc, 0, 0, 0);
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v)
                 if (oc[rb][v] >= 0) outp[ho + oc[rb][v]] = acc[v];
