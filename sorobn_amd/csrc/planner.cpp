@@ -1287,6 +1287,12 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
                         else ins[n3++] = &f;
                     }
                 }
+                if (fits) {  // exactly three new variables (the frontier keeps its width), cheap to check before any layout work
+                    Bits u;
+                    u.nw = net.nw;
+                    for (int j = 0; j < n3; ++j) u.or_(ins[j]->scope);
+                    fits = u.count() - bigf->scope.count() == 3;
+                }
                 if (fits) {
                     const int X[3] = {x, x2, x3};
                     pool.emplace_back();
