@@ -118,6 +118,13 @@ def test_c3_chain_form_vs_pair_form(amd):
     assert np.allclose(chain.sum(1), 1.0, atol=1e-12)
     assert float(np.max(np.abs(chain - pair))) <= 1e-13
     be.engine.set_option("split_kinds", 0)
+    # several iterations per tile and CHAIN steps on tables of a few thousand cells (partially filled lane blocks)
+    be.engine.set_option("tile_h", 3)
+    be.engine.set_option("big_iters", 64)
+    small = be.engine.query_fixed(to_var[q[:1024]][:, None], to_var[ev[:1024]], ec[:1024])
+    assert float(np.max(np.abs(small - pair[:1024]))) <= 1e-13
+    be.engine.set_option("tile_h", 0)
+    be.engine.set_option("big_iters", 4096)
     entry = gu.load("grid10x10.json")
     _check_requests(bn, entry["requests"], "grid10x10 chain")
     for e in gu.load("grids_small.json"):

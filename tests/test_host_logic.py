@@ -247,6 +247,9 @@ def test_chain_form_on_the_simulator():
         b1 += chain.last_stats[0]
         assert float(np.max(np.abs(a - b))) <= 1e-14
     assert b1 < 0.9 * b0
+    tiled = simengine.SimEngine(f, tiling=(64, 3))  # several iterations per tile, CHAIN steps on small tables
+    for i in range(8):
+        assert float(np.max(np.abs(tiled._one([to_var[q[i]]], to_var[ev[i]], ec[i]) - plain._one([to_var[q[i]]], to_var[ev[i]], ec[i])))) <= 1e-14
 
 
 def test_c3_bayes_rule_and_marginalisation_on_the_simulator():
