@@ -113,17 +113,24 @@ def main():
     import torch  # plumbing only: barrier / synchronize / RCCL gather
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    # MIBN_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 path run on a box with fewer GPUs than ranks (ranks then
+    # share devices and the collectives run on host tensors); the measured configuration is always nccl (= RCCL)
+    backend = os.environ.get("MIBN_BENCH_BACKEND", "nccl")
+    device = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    coll_dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import netspec
     import sorobn_amd
 
     spec = netspec.grid_spec(10, 10, 4, seed=0)
-    bn = netspec.build(spec, sorobn_amd.BayesNet).use_device(local_rank)
+    bn = netspec.build(spec, sorobn_amd.BayesNet).use_device(device)
     be = bn.backend  # flatten + upload: network resident in HBM from here on
     eng = be.engine
     if a.threads:
@@ -149,7 +156,7 @@ def main():
 
     gathered = None
     if world > 1:
-        gathered = torch.empty((world, a.batch, 4), dtype=torch.float64, device="cuda")
+        gathered = torch.empty((world, a.batch, 4), dtype=torch.float64, device=coll_dev)
 
     # The K timed steps are pipelined two deep (mibn_submit_batch / mibn_wait): the host plans step s+1 while the
     # GPU runs step s, as a server streaming batches would.  Every step is complete - posteriors on the host and,
@@ -162,7 +169,7 @@ def main():
         handle, lo = pending
         post = eng.wait(handle)
         if world > 1:  # final gather of the posteriors over xGMI (RCCL)
-            mine = torch.from_numpy(post).to("cuda", non_blocking=False)
+            mine = torch.from_numpy(post).to(coll_dev, non_blocking=False)
             dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
         return post, lo
 
@@ -196,7 +203,7 @@ def main():
     kagg = {n: {f: ks1[n][f] - ks0.get(n, {}).get(f, 0.0) for f in ks1[n]} for n in ks1}
     kagg = {n: d for n, d in kagg.items() if d["launches"] > 0}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

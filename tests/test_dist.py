@@ -27,3 +27,32 @@ def test_two_rank_gloo_gather(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ok.read_text() == "ok 2"
+
+
+import json  # noqa: E402
+import socket  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_launch_path():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process), on however
+    many GPUs the box has: with the MIBN_BENCH_BACKEND=gloo test hook the ranks may share a device and the barrier /
+    gather / max-over-ranks run on host tensors - everything but the RCCL transport itself."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MIBN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4096"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["requests_per_step_per_gpu"] == 4096
+    assert abs(out["value"] - 2 * 2 * 4096 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
