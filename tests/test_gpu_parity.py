@@ -164,6 +164,27 @@ def test_c3_bayes_rule_and_marginalisation_at_full_size(amd):
     assert float(np.max(err)) <= 1e-9
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fresh_random_dags_vs_oracle(amd, seed):
+    """New random DAGs (not in the golden files: mixed cardinalities, exact zeros, missing rows), HIP vs the C oracle."""
+    from oracle.oracle import OracleNet
+    from test_host_logic import _fresh_dag_requests, _oracle_series
+    spec, reqs = _fresh_dag_requests(seed)
+    on = OracleNet(spec)
+    for small_cells, tiling in [(1024, (4096, 0)), (2, (4, 2))]:
+        bn = netspec.build(spec, amd.BayesNet)
+        bn.backend.engine.set_option("small_cells", small_cells)
+        bn.backend.engine.set_option("big_iters", tiling[0])
+        bn.backend.engine.set_option("tile_h", tiling[1])
+        for (q, ev), ans in zip(reqs, bn.query_many(reqs)):
+            qs, labels, vals = _oracle_series(on, q, ev)
+            assert list(ans.index.names) == qs, (q, ev)
+            got = [t if isinstance(t, tuple) else (t,) for t in ans.index.tolist()]
+            assert got == labels, (q, ev)
+            if len(vals):
+                assert float(np.max(np.abs(ans.to_numpy() - vals))) <= gu.TOL, (q, ev)
+
+
 def test_single_query_api_alarm(amd):
     """README.md:225-229 (config C1): 0.715828 / 0.284172."""
     spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "alarm")["spec"]

@@ -270,6 +270,45 @@ def test_c3_bayes_rule_and_marginalisation_on_the_simulator():
     assert float(np.max(np.abs(sl / sl.sum(1, keepdims=True) - cond))) <= 1e-11
 
 
+def _fresh_dag_requests(seed):
+    """A random DAG the golden files do not contain and a few random requests (label level)."""
+    spec = netspec.random_dag_spec(1000 + seed, n_nodes=8 + seed % 7, cards=(2, 3, 4, 5) if seed % 2 else (4,), p_zero=0.1)
+    rng = np.random.default_rng(seed)
+    dom = netspec.domains(spec)
+    reqs = []
+    for _ in range(12):
+        names = list(rng.permutation(spec["nodes"]))
+        nq, ne = int(rng.integers(1, 3)), int(rng.integers(0, 4))
+        q = names[:nq]
+        ev = {n: dom[n][int(rng.integers(0, len(dom[n])))] for n in names[nq:nq + ne]}
+        reqs.append((tuple(q), ev))
+    return spec, reqs
+
+
+def _oracle_series(on, q, ev):
+    qs, labels, vals = on.query(list(q), ev)
+    keep = vals > 0
+    return qs, [l for l, k in zip(labels, keep) if k], vals[keep]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fresh_random_dags_simulator_vs_oracle(seed):
+    """Beyond the golden files: new random DAGs (mixed cardinalities, exact zeros, missing rows) every seed, the
+    planner's programs on the simulator against the C oracle (which the golden vectors pin to the reference)."""
+    from oracle.oracle import OracleNet
+    spec, reqs = _fresh_dag_requests(seed)
+    on = OracleNet(spec)
+    for small_cells, tiling in [(1024, (4096, 0)), (2, (4, 2))]:
+        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), small_cells, tiling, 1)
+        for (q, ev), ans in zip(reqs, bn.query_many(reqs)):
+            qs, labels, vals = _oracle_series(on, q, ev)
+            assert list(ans.index.names) == qs, (q, ev)
+            got = [t if isinstance(t, tuple) else (t,) for t in ans.index.tolist()]
+            assert got == labels, (q, ev)
+            if len(vals):
+                assert float(np.max(np.abs(ans.to_numpy() - vals))) <= gu.TOL, (q, ev)
+
+
 # ------------------------------------------------------------------------------------ API behaviour
 
 @pytest.fixture()
