@@ -185,6 +185,33 @@ def test_fresh_random_dags_vs_oracle(amd, seed):
                 assert float(np.max(np.abs(ans.to_numpy() - vals))) <= gu.TOL, (q, ev)
 
 
+@pytest.mark.parametrize("shape", [(8, 8), (9, 8), (8, 11)])
+def test_wide_grids_every_request_vs_oracle(amd, shape):
+    """Grids wide enough for the heavy step forms (CHAIN / pair MFMA / OUTER on 4^8..4^9-cell frontier tables) and
+    still small enough for the CPU oracle to answer every request: 96 requests each, all compared."""
+    from oracle.oracle import OracleNet
+    R, C = shape
+    n = R * C
+    spec = netspec.grid_spec(R, C, 4, seed=R * 100 + C)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    on = OracleNet(spec)
+    q, ev, ec = netspec.c3_requests(n, 4, 96, 3, seed=7)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(n)], np.int32)
+    oid = np.array([on.id[f"{i:03d}"] for i in range(n)], np.int32)
+    be.engine.set_option("split_kinds", 1)
+    post = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    names = {k["name"] for k in be.engine.kernel_stats()}
+    assert any("chain" in x for x in names) and any("nc16-mfma" in x for x in names), names
+    worst = 0.0
+    for i in range(96):
+        codes, vals = on.query_codes([int(oid[q[i]])], oid[ev[i]].tolist(), ec[i].tolist())
+        dense = np.zeros(4)
+        dense[codes[:, 0]] = vals
+        worst = max(worst, float(np.max(np.abs(dense - post[i]))))
+    assert worst <= gu.TOL, worst
+
+
 def test_single_query_api_alarm(amd):
     """README.md:225-229 (config C1): 0.715828 / 0.284172."""
     spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "alarm")["spec"]

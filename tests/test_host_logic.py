@@ -309,6 +309,24 @@ def test_fresh_random_dags_simulator_vs_oracle(seed):
                 assert float(np.max(np.abs(ans.to_numpy() - vals))) <= gu.TOL, (q, ev)
 
 
+def test_wide_grid_every_request_simulator_vs_oracle():
+    """CPU twin of the GPU test of (almost) the same name: a 8x8 four-state grid - wide enough for CHAIN / pair / OUTER
+    steps on 4^8-cell tables, small enough for the oracle - every request compared."""
+    from oracle.oracle import OracleNet
+    spec = netspec.grid_spec(8, 8, 4, seed=808)
+    on = OracleNet(spec)
+    f = flatten(netspec.build(spec, sorobn_amd.BayesNet))
+    q, ev, ec = netspec.c3_requests(64, 4, 24, 3, seed=7)
+    oid = np.array([on.id[f"{i:03d}"] for i in range(64)], np.int32)
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(64)], np.int32)
+    eng = simengine.SimEngine(f)
+    for i in range(24):
+        codes, vals = on.query_codes([int(oid[q[i]])], oid[ev[i]].tolist(), ec[i].tolist())
+        dense = np.zeros(4)
+        dense[codes[:, 0]] = vals
+        assert float(np.max(np.abs(eng._one([to_var[q[i]]], to_var[ev[i]], ec[i]) - dense))) <= gu.TOL
+
+
 # ------------------------------------------------------------------------------------ API behaviour
 
 @pytest.fixture()
