@@ -1646,6 +1646,27 @@ int step_tile_h(const Network &net, const uint32_t *w) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(kTileMax, kTileBytes / per_iter));
 }
 
+// Order of the classes of work inside a level's launch (workgroups are dispatched in this order): the classes whose
+// workgroups run long and move little - segments, GENERIC tiles, the two-table VALU forms: 80-170 us per workgroup -
+// go first, so that they finish under the streaming classes instead of forming the tail of every level.
+struct ClassOrder {
+    int rank_of[kNumKernels], kid_at[kNumKernels];
+    ClassOrder() {
+        std::vector<int> order;
+        auto add = [&](int kid) { if (std::find(order.begin(), order.end(), kid) == order.end()) order.push_back(kid); };
+        add(kKidSeg);
+        for (int j = 0; j < kMaxIn; ++j) add(kKidGeneric0 + j);
+        for (int n : {3, 1, 2, 0})  // two tables, VALU: ncN, nc4, nc16, nc1
+            for (int c = 2; c >= 0; --c) add(kKidFiber0 + 18 + c * 6 + n);
+        for (int c = 2; c >= 0; --c) add(kKidFiber0 + c * 6 + 3);                          // one table, ncN
+        for (int n = 0; n < 6; ++n) add(kKidFiber0 + 2 * 6 + n);                            // one table, runtime cx
+        for (int c = 0; c < 2; ++c) add(kKidFiber0 + 18 + c * 6 + 5);                       // OUTER
+        for (int kid = 0; kid < kNumKernels; ++kid) add(kid);                               // the streaming classes
+        for (int r = 0; r < kNumKernels; ++r) { kid_at[r] = order[(size_t)r]; rank_of[order[(size_t)r]] = r; }
+    }
+};
+static const ClassOrder kClassOrder;
+
 void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<ProgBuf> &bufs, int64_t r0, int64_t r1,
                     Schedule &out) {
     (void)net;
@@ -1679,7 +1700,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         const int64_t r = r0 + i;
         const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
         for (uint32_t k = 0; k < bp.tag_count[r]; ++k) {
-            const size_t bkt = (size_t)tg[k].level * kNumKernels + tg[k].kid;
+            const size_t bkt = (size_t)tg[k].level * kNumKernels + kClassOrder.rank_of[tg[k].kid];
             ++count[bkt + 1];
             bytes[bkt] += tg[k].bytes;
             n_wg += tg[k].wgs;
@@ -1693,7 +1714,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         const int64_t r = r0 + i;
         const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
         for (uint32_t k = 0; k < bp.tag_count[r]; ++k)
-            out.items[cur[(size_t)tg[k].level * kNumKernels + tg[k].kid]++] = Item{(uint32_t)i, tg[k].rel_off, tg[k].a, tg[k].wgs};
+            out.items[cur[(size_t)tg[k].level * kNumKernels + kClassOrder.rank_of[tg[k].kid]]++] = Item{(uint32_t)i, tg[k].rel_off, tg[k].a, tg[k].wgs};
     }
     // pass 3: workgroup -> item table, level by level
     out.wg_item.resize(n_wg);
@@ -1701,7 +1722,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
     int cur_level = -1;
     for (size_t k = 0; k < nb; ++k)
         if (count[k + 1] > count[k]) {
-            const int level = (int)(k / kNumKernels), kid = (int)(k % kNumKernels);
+            const int level = (int)(k / kNumKernels), kid = kClassOrder.kid_at[k % kNumKernels];
             if (level != cur_level) { cur_level = level; wg_level = wg; }
             if (kid == kKidSeg)  // longest segments first: they are the tail of their level
                 std::stable_sort(out.items.begin() + count[k], out.items.begin() + count[k + 1],
