@@ -25,6 +25,9 @@
 //    as two 16-byte vectors per lane; NC = 16 fibers (128 B per lane) are transposed through a wave-private LDS
 //    buffer so that every store instruction writes full 64-byte segments (direct 128-byte-strided stores
 //    reach only 3.8 TB/s against 5.2 TB/s transposed - tools/ubench/stream_variants.hip).
+//    The NC = 16 shapes whose cells split into row blocks of 16 sharing one T slice run as fp64 MFMA products
+//    instead (fiber_mfma_call: [16 cells x cx] x [cx x 16] per block; outer_mfma_call: the B operand from a second big
+//    table; chain_mfma_call: a third variable summed out of the accumulators in registers) - the bulk of the bytes.
 //  * GENERIC tiles <NIN> - big steps of any other shape, one output cell per lane-iteration.
 //  * segments - a run of small steps of one request (start / end of a program, the final normalised
 //    product) executed back to back by one workgroup; only `__syncthreads()` between steps (same CU).
