@@ -137,7 +137,8 @@ int mibn_plan_stats(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e,
 int mibn_create_planner(mibn_t **out); /* host-only context: set_network/plan_stats work, queries fail */
 
 /* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "chunk" (requests per planning /
- * launch chunk).  Test and profiling hooks: "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the
+ * launch chunk), "plan_cache" (0: plan every request, no plan templates for repeated request shapes).
+ * Test and profiling hooks: "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the
  * kernels' step forms onto small networks), "split_kinds" (one launch per class of work and level, so that
  * mibn_last_kernel_stats reports per-class rates), "trace" (one stderr line per launch), "gibbs_lds" (0: the Gibbs
  * kernel reads the CPTs through L2 even when they would fit in LDS). */

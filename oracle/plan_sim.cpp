@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -390,6 +391,59 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
 }
 
 // debugging aid: return the raw step program of one request (words copied into `out`, count returned)
+// Plan templates (planner.cpp, plan_batch): the same batch planned by one worker with and without the template cache
+// must give the same programs, word for word, the same items and the same statistics.  Returns the number of requests
+// answered from a template (>= 0), or < 0 with plan_sim_error() set.
+static double g_cache_ms[2];
+extern "C" void plan_sim_cache_times(double *out) { out[0] = g_cache_ms[0]; out[1] = g_cache_ms[1]; }
+extern "C" int64_t plan_sim_cache_check(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                                        const int64_t *value_off, const double *values, int64_t B, const int64_t *q_off,
+                                        const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes) {
+    Network net;
+    g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
+    if (!g_err.empty()) return -1;
+    net.small_cells = g_small_cells;
+    net.big_iters = g_big_iters;
+    net.tile_h = g_tile_h;
+    net.fuse = g_fuse;
+    net.chain = g_chain;
+    net.prune = g_prune;
+    std::vector<int64_t> out_off(B + 1, 0);
+    for (int64_t b = 0; b < B; ++b) {
+        int64_t cells = 1;
+        for (int64_t k = q_off[b]; k < q_off[b + 1]; ++k) cells *= card[q_vars[k]];
+        out_off[b + 1] = out_off[b] + cells;
+    }
+    const int n_threads = getenv("PLAN_SIM_THREADS") ? atoi(getenv("PLAN_SIM_THREADS")) : 1;  // (> 1: timing only, the comparison needs one worker)
+    ThreadPool pool(n_threads);
+    std::vector<ProgBuf> bufs[2];
+    BatchPlan bp[2];
+    for (int pass = 0; pass < 2; ++pass) {
+        net.plan_cache = pass;  // pass 0: every request planned; pass 1: templates
+        auto t0 = std::chrono::steady_clock::now();
+        plan_batch(net, pool, bufs[pass], 0, B, q_off, q_vars, e_off, e_vars, e_codes, out_off.data(), nullptr, bp[pass]);
+        g_cache_ms[pass] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (!bp[pass].err.empty()) { g_err = bp[pass].err; return -2; }
+    }
+    int64_t rc = 0;
+    if (n_threads > 1) { for (auto &v : bufs) for (auto &b : v) b.release(); return 0; }
+    if (bp[0].total_words != bp[1].total_words || std::memcmp(bufs[0][0].data, bufs[1][0].data, bp[0].total_words * 4) != 0) { g_err = "programs differ"; rc = -3; }
+    else if (bp[0].tags[0].size() != bp[1].tags[0].size() || std::memcmp(bp[0].tags[0].data(), bp[1].tags[0].data(), bp[0].tags[0].size() * sizeof(Tag)) != 0) { g_err = "items differ"; rc = -4; }
+    else if (bp[0].arena_need != bp[1].arena_need || bp[0].cost != bp[1].cost || bp[0].st.alg_bytes != bp[1].st.alg_bytes || bp[0].st.n_steps != bp[1].st.n_steps) { g_err = "statistics differ"; rc = -5; }
+    else {
+        // how many requests repeat an earlier shape (what the cache can answer from a template)
+        std::vector<std::string> seen;
+        for (int64_t b = 0; b < B; ++b) {
+            std::string key((const char *)(q_vars + q_off[b]), 4 * (size_t)(q_off[b + 1] - q_off[b]));
+            key.push_back('|');
+            key.append((const char *)(e_vars + e_off[b]), 4 * (size_t)(e_off[b + 1] - e_off[b]));
+            if (std::find(seen.begin(), seen.end(), key) != seen.end()) ++rc; else seen.push_back(key);
+        }
+    }
+    for (auto &v : bufs) for (auto &b : v) b.release();
+    return rc;
+}
+
 extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
                                     const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
                                     int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars, const int32_t *ecodes,

@@ -188,6 +188,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
     else if (n == "fuse") h->net.fuse = value != 0;
+    else if (n == "plan_cache") h->net.plan_cache = value != 0;  // plan templates for repeated request shapes
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
     else if (n == "outer") h->net.outer = value != 0;
     else if (n == "prune") h->net.prune = value != 0;  // 0: multiply every CPT (full_joint_dist / predict_proba semantics)  // OUTER (MFMA) form for products of two big tables  // joint elimination of two variables per pass

@@ -2,12 +2,14 @@
 #include "planner.h"
 
 #include <algorithm>
+#include <unordered_map>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <condition_variable>
 #include <mutex>
@@ -29,6 +31,8 @@ struct ProfT { int k; std::chrono::steady_clock::time_point t0; ProfT(int k_) : 
 std::string Network::set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
                          const int64_t *value_off, const double *values) {
     if (n < 0 || n > kMaxVars) return "n_vars out of range (max " + std::to_string(kMaxVars) + ")";
+    static std::atomic<uint64_t> versions{0};
+    version = ++versions;
     n_vars = n;
     nw = std::max(1, (n + 63) / 64);
     card.assign(card_, card_ + n);
@@ -125,6 +129,7 @@ struct PF {  // planning-time factor (plain data: no heap allocation on the plan
     uint64_t off = 0;            // arena offset, or pool offset | kConstFlag
     int64_t cells = 0;           // product of the free cardinalities
     int64_t alloc = 0;           // arena cells owned (0 for constants)
+    int32_t src = -1;            // initial factor: the variable whose CPT it slices (its offset depends on the evidence codes)
 };
 
 inline double scope_log2(const Network &net, const Bits &b) {
@@ -462,6 +467,13 @@ struct Arena {
     }
 };
 
+// Where a request's program depends on its evidence *codes* and on its position in the batch - and nowhere else: the
+// offsets of the evidence-sliced CPTs and the result offset of the final step (plan templates, plan_batch).
+struct PlanRecord {
+    std::vector<std::pair<uint32_t, int32_t>> consts;  // (word index of an (off lo, off hi) pair in the buffer, CPT variable)
+    std::vector<uint32_t> finals;                       // word index of the (out_off lo, out_off hi) pair of a FINAL step
+};
+
 struct Emitter {
     const Network &net;
     ProgBuf &prog;
@@ -470,6 +482,14 @@ struct Emitter {
     std::vector<double> &key;   // layout key per variable: larger = lives longer = faster axis
     std::vector<int32_t> &pos;  // variable -> output axis (scratch, -1 outside emit)
     std::string err;
+    PlanRecord *rec = nullptr;  // optional: where the program depends on evidence codes / batch position
+
+    // the (off lo, off hi) pair of input table f
+    void put_off(uint32_t *&p, const PF *f) {
+        if (rec && f->src >= 0) rec->consts.emplace_back((uint32_t)(p - prog.data), f->src);
+        *p++ = (uint32_t)(f->off & 0xffffffffu);
+        *p++ = (uint32_t)(f->off >> 32);
+    }
 
     void header(uint32_t *w, uint32_t kind, int n_in, int ma, int mlo, int cx, bool final_, int64_t lo, int64_t hi,
                 uint64_t out_off, int words) {
@@ -479,6 +499,7 @@ struct Emitter {
         w[3] = (uint32_t)hi;
         w[4] = (uint32_t)(out_off & 0xffffffffu);
         w[5] = (uint32_t)(out_off >> 32);
+        if (rec && final_) rec->finals.push_back((uint32_t)(w - prog.data) + 4);
         w[6] = (uint32_t)words;
         w[7] = w[8] = w[9] = 0;
     }
@@ -517,8 +538,7 @@ struct Emitter {
         header(w, kKindGeneric, n_in, ma, mlo, cx, final_, lo, cells / lo, out.off, words);
         uint32_t *p = w + kHdrWords;
         for (int j = 0; j < n_in; ++j) {
-            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j]->off >> 32);
+            put_off(p, ins[j]);
             *p++ = (uint32_t)(int32_t)xs[j];
         }
         for (int a = 0; a < ma; ++a) *p++ = mcard[a];
@@ -650,15 +670,13 @@ struct Emitter {
         w[8] = (uint32_t)T | ((uint32_t)c1 << 16);
         uint32_t *p = w + kHdrWords;
         for (int b = 0; b < nb; ++b) {
-            *p++ = (uint32_t)(ins[big[b]]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[big[b]]->off >> 32);
+            put_off(p, ins[big[b]]);
             *p++ = (uint32_t)(int32_t)xs[big[b]][0];
             *p++ = (uint32_t)(int32_t)xs[big[b]][1];
         }
         for (int k = 0; k < ns; ++k) {
             const int j = small[k];
-            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j]->off >> 32);
+            put_off(p, ins[j]);
             *p++ = (uint32_t)(int32_t)xs[j][0];
             *p++ = (uint32_t)(int32_t)xs[j][1];
             for (int i = 0; i < nN; ++i) *p++ = (uint32_t)(int32_t)s[j][naxes[i]];
@@ -813,15 +831,13 @@ struct Emitter {
         w[8] = (uint32_t)T | ((uint32_t)c1 << 16);
         uint32_t *p = w + kHdrWords;
         for (int b = 0; b < 2; ++b) {
-            *p++ = (uint32_t)(ins[big[b]]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[big[b]]->off >> 32);
+            put_off(p, ins[big[b]]);
             *p++ = (uint32_t)(int32_t)xs[big[b]][0];
             *p++ = (uint32_t)(int32_t)xs[big[b]][1];
         }
         for (int k = 0; k < ns; ++k) {
             const int j = small[k];
-            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j]->off >> 32);
+            put_off(p, ins[j]);
             *p++ = (uint32_t)(int32_t)xs[j][0];
             *p++ = (uint32_t)(int32_t)xs[j][1];
             *p++ = (uint32_t)(int32_t)s[j][nax[0]];
@@ -1009,8 +1025,7 @@ struct Emitter {
         w[7] = 2u | ((uint32_t)n12 << 4) | (2u << 8) | ((uint32_t)(nT - 2) << 12) | (16u << 16);
         w[8] = (uint32_t)T12 | (4u << 16);
         uint32_t *p = w + kHdrWords;
-        *p++ = (uint32_t)(ins[big]->off & 0xffffffffu);
-        *p++ = (uint32_t)(ins[big]->off >> 32);
+        put_off(p, ins[big]);
         *p++ = (uint32_t)(int32_t)xs[big][0];
         *p++ = (uint32_t)(int32_t)xs[big][1];
         *p++ = (uint32_t)T12;
@@ -1019,8 +1034,7 @@ struct Emitter {
         *p++ = (uint32_t)t12x3;
         for (int k = 0; k < n12; ++k) {
             const int j = g12[k];
-            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j]->off >> 32);
+            put_off(p, ins[j]);
             *p++ = (uint32_t)(int32_t)xs[j][0];
             *p++ = (uint32_t)(int32_t)xs[j][1];
             *p++ = (uint32_t)(int32_t)s[j][0];
@@ -1041,8 +1055,7 @@ struct Emitter {
         for (int i = 0; i < nc3; ++i) *p++ = (uint32_t)net.card[vars2[c3[i]]];
         for (int k = 0; k < n3s; ++k) {
             const int j = g3[k];
-            *p++ = (uint32_t)(ins[j]->off & 0xffffffffu);
-            *p++ = (uint32_t)(ins[j]->off >> 32);
+            put_off(p, ins[j]);
             *p++ = (uint32_t)(int32_t)xs[j][2];
             *p++ = (uint32_t)(int32_t)s[j][2];
             if (n12dep) { *p++ = (uint32_t)(int32_t)s[j][0]; *p++ = (uint32_t)(int32_t)s[j][1]; }
@@ -1136,7 +1149,7 @@ struct Emitter {
 
 }  // namespace
 
-std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, PlanStats &st) {
+static std::string plan_request_rec(const Network &net, const Request &rq, ProgBuf &prog, PlanStats &st, PlanRecord *rec) {
     PROF(0);
     Scratch &S = scratch();
     // relevant = query | event | ancestors(...)  (bayes_net.py:763-765); hidden = relevant - query - event (766)
@@ -1187,6 +1200,7 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
             }
         }
         f.off = off | kConstFlag;
+        f.src = v;
         f.cells = cells;
         live.push_back((int)pool.size() - 1);
         scopes.push_back(f.scope);
@@ -1232,7 +1246,7 @@ std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, P
     PROF(4);
     S.key.assign(net.n_vars, 0.0);
     S.pos.assign(net.n_vars, -1);
-    Emitter em{net, prog, st, Arena{}, S.key, S.pos, ""};
+    Emitter em{net, prog, st, Arena{}, S.key, S.pos, "", rec};
     for (size_t i = 0; i < best.size(); ++i) S.key[best[i]] = (double)i;
     for (int i = 0; i < rq.nq; ++i) S.key[rq.qvars[i]] = 1e9 + i;
 
@@ -1398,6 +1412,10 @@ void ProgBuf::release() {
     size = cap = 0;
 }
 
+std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, PlanStats &st) {
+    return plan_request_rec(net, rq, prog, st, nullptr);
+}
+
 std::string plan_request(const Network &net, const Request &rq, std::vector<uint32_t> &prog, PlanStats &st) {
     ProgBuf b;
     std::string e = plan_request(net, rq, b, st);
@@ -1499,6 +1517,91 @@ static uint32_t tag_request(const Network &net, const uint32_t *prog, std::vecto
     return (uint32_t)(out.size() - first);
 }
 
+// ------------------------------------------------------------------------------------ plan templates
+// The program of a request depends on its *shape* - the query variables (in order) and the evidence variables (in
+// order) - and, through the offsets of the evidence-sliced CPTs and the result offset of its final step only, on the
+// evidence codes and the request's position.  Workloads repeat shapes (BayesNet.predict_proba: one shape for every row;
+// the 100 k Asia requests of BASELINE config 2: 504 shapes), so every planning worker keeps the programs it planned as
+// templates and instantiates a repeated shape by copying and patching.  Random shapes (the C3 stream: 3.8e8 of them)
+// never repeat: the cache probes the first requests of every window and stays off for the rest when they miss.
+namespace {
+
+struct PlanTemplate {
+    std::vector<uint32_t> words;
+    struct Patch { uint32_t pos; uint32_t first, count; uint64_t base; };  // off = base + sum stride[k] * code[slot[k]]
+    std::vector<Patch> patches;
+    std::vector<uint32_t> slot;
+    std::vector<int64_t> stride;
+    std::vector<uint32_t> finals;
+    std::vector<Tag> tags;
+    PlanStats st;
+};
+
+// Shared by the planning workers of one network: 64 shards, each a mutex + a map; templates are immutable once
+// published and are only freed at the start of a plan_batch call (no worker is running then), so a worker holds a
+// shard's lock for the lookup only and copies from the template without it.
+struct TemplateStore {
+    struct Shard {
+        std::mutex m;
+        std::unordered_map<std::string, std::unique_ptr<PlanTemplate>> map;
+    };
+    static constexpr int kShards = 64;
+    static constexpr size_t kMaxWords = 64u << 20;  // 256 MB of templates per network: cleared at the next batch
+    Shard shard[kShards];
+    std::atomic<size_t> words{0};
+    uint64_t version = 0, opt_sig = 0;
+    void clear() {
+        for (auto &sh : shard) sh.map.clear();
+        words = 0;
+    }
+};
+
+// per planning worker: the probe state (is the stream repeating shapes?) and scratch
+struct PlanCache {
+    const TemplateStore *store = nullptr;
+    uint64_t version = 0;
+    uint64_t seen = 0, probe_hits = 0;
+    bool on = true;
+    static constexpr uint64_t kWindow = 32768, kProbe = 512;
+    PlanRecord rec;
+    std::string key;
+};
+
+uint64_t option_signature(const Network &net) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
+    mix((uint64_t)net.chain); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.hints.size());
+    return h;
+}
+
+// called by plan_batch before its workers start
+TemplateStore *template_store(const Network &net) {
+    if (!net.templates) net.templates = std::make_shared<TemplateStore>();
+    TemplateStore *ts = static_cast<TemplateStore *>(net.templates.get());
+    const uint64_t sig = option_signature(net);
+    if (ts->version != net.version || ts->opt_sig != sig || ts->words.load() > TemplateStore::kMaxWords) {
+        ts->clear();
+        ts->version = net.version;
+        ts->opt_sig = sig;
+    }
+    return ts;
+}
+
+PlanCache &plan_cache(const TemplateStore *ts) {
+    static thread_local PlanCache c;
+    if (c.store != ts || c.version != ts->version) {
+        c.store = ts;
+        c.version = ts->version;
+        c.seen = c.probe_hits = 0;
+        c.on = true;
+    }
+    return c;
+}
+
+}  // namespace
+
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
                 const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck) {
@@ -1521,6 +1624,7 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
     std::vector<std::string> terr(T);
     // dynamic distribution in blocks of 32 requests: request costs vary 100x and a worker may lose its core to
     // another rank's planner, a static split would wait for the slowest worker
+    TemplateStore *store = net.plan_cache ? template_store(net) : nullptr;
     std::atomic<int64_t> next{0};
     constexpr int64_t kBlock = 32;
     pool.run([&](int t) {
@@ -1547,9 +1651,78 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             rq.ecodes = e_codes + e_off[b];
             rq.out_off = out_off[b] - out_off[b0];
             PlanStats st;
-            std::string e = plan_request(net, rq, prog, st);
-            if (!e.empty()) { terr[t] = e; return; }
-            ck.tag_count[i] = tag_request(net, prog.data + ck.local_off[i], tags);
+            // plan templates (see above): probe at the start of every window, stay on while shapes repeat
+            PlanCache *pc = store ? &plan_cache(store) : nullptr;
+            bool use_cache = false;
+            if (pc) {
+                const uint64_t w = pc->seen++ % PlanCache::kWindow;
+                if (w == 0) { pc->probe_hits = 0; pc->on = true; }
+                if (w == PlanCache::kProbe) pc->on = pc->probe_hits * 4 >= PlanCache::kProbe;
+                use_cache = pc->on;
+            }
+            if (use_cache) {
+                std::string &key = pc->key;
+                key.assign(reinterpret_cast<const char *>(&rq.nq), sizeof(rq.nq));
+                key.append(reinterpret_cast<const char *>(rq.qvars), sizeof(int32_t) * (size_t)rq.nq);
+                key.append(reinterpret_cast<const char *>(rq.evars), sizeof(int32_t) * (size_t)rq.ne);
+                TemplateStore::Shard &sh = store->shard[std::hash<std::string>{}(key) % TemplateStore::kShards];
+                const PlanTemplate *hit = nullptr;
+                {
+                    std::lock_guard<std::mutex> lk(sh.m);
+                    auto it = sh.map.find(key);
+                    if (it != sh.map.end()) hit = it->second.get();
+                }
+                if (hit) {
+                    const PlanTemplate &tp = *hit;
+                    ++pc->probe_hits;
+                    uint32_t *w = prog.extend(tp.words.size());
+                    std::copy(tp.words.begin(), tp.words.end(), w);
+                    for (const auto &pt : tp.patches) {
+                        uint64_t off = pt.base;
+                        for (uint32_t k = pt.first; k < pt.first + pt.count; ++k) off += (uint64_t)(tp.stride[k] * rq.ecodes[tp.slot[k]]);
+                        off |= kConstFlag;
+                        w[pt.pos] = (uint32_t)(off & 0xffffffffu);
+                        w[pt.pos + 1] = (uint32_t)(off >> 32);
+                    }
+                    for (uint32_t fp : tp.finals) {
+                        w[fp] = (uint32_t)((uint64_t)rq.out_off & 0xffffffffu);
+                        w[fp + 1] = (uint32_t)((uint64_t)rq.out_off >> 32);
+                    }
+                    st = tp.st;
+                    tags.insert(tags.end(), tp.tags.begin(), tp.tags.end());
+                    ck.tag_count[i] = (uint32_t)tp.tags.size();
+                } else {
+                    pc->rec.consts.clear();
+                    pc->rec.finals.clear();
+                    std::string e = plan_request_rec(net, rq, prog, st, &pc->rec);
+                    if (!e.empty()) { terr[t] = e; return; }
+                    ck.tag_count[i] = tag_request(net, prog.data + ck.local_off[i], tags);
+                    if (store->words.load(std::memory_order_relaxed) <= TemplateStore::kMaxWords) {
+                        std::unique_ptr<PlanTemplate> up(new PlanTemplate);
+                        PlanTemplate &tp = *up;
+                        const size_t start = (size_t)ck.local_off[i];
+                        tp.words.assign(prog.data + start, prog.data + prog.size);
+                        for (const auto &cs : pc->rec.consts) {
+                            const int v = cs.second;
+                            PlanTemplate::Patch pt{(uint32_t)(cs.first - start), (uint32_t)tp.slot.size(), 0u, (uint64_t)net.pool_off[v]};
+                            for (size_t k = 0; k < net.scope[v].size(); ++k)
+                                for (int sl = 0; sl < rq.ne; ++sl)
+                                    if (rq.evars[sl] == net.scope[v][k]) { tp.slot.push_back((uint32_t)sl); tp.stride.push_back(net.cstride[v][k]); ++pt.count; }
+                            if (pt.count) tp.patches.push_back(pt);
+                        }
+                        for (uint32_t fp : pc->rec.finals) tp.finals.push_back((uint32_t)(fp - start));
+                        tp.tags.assign(tags.begin() + ck.tag_first[i], tags.end());
+                        tp.st = st;
+                        store->words.fetch_add(tp.words.size(), std::memory_order_relaxed);
+                        std::lock_guard<std::mutex> lk(sh.m);
+                        sh.map.emplace(key, std::move(up));  // (another worker may have published the shape meanwhile: kept)
+                    }
+                }
+            } else {
+                std::string e = plan_request(net, rq, prog, st);
+                if (!e.empty()) { terr[t] = e; return; }
+                ck.tag_count[i] = tag_request(net, prog.data + ck.local_off[i], tags);
+            }
             ck.cost[i] = st.alg_bytes;
             ck.arena_need[i] = st.arena_cells;
             tst[t].alg_bytes += st.alg_bytes;

@@ -13,6 +13,7 @@
 #include <array>
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -62,6 +63,9 @@ struct Network {
     int prune = 1;           // restrict a request to the ancestors of its query / evidence variables (bayes_net.py:763-765)
     int outer = 1;           // OUTER form (fp64 MFMA) for products of two big tables
     int fuse = 1;            // eliminate two consecutive variables in one FIBER step when the first result would be a big table
+    int plan_cache = 1;      // plan templates: requests that repeat a (query, evidence set) shape re-use its program (plan_batch)
+    uint64_t version = 0;    // changes with every set(): invalidates cached plan templates
+    mutable std::shared_ptr<void> templates;  // the template store of this network (planner.cpp)
     int chain = 1;           // CHAIN form: a third 4-state variable eliminated in the registers of the same pass
 
     // returns "" or an error message

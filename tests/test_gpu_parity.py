@@ -212,6 +212,26 @@ def test_wide_grids_every_request_vs_oracle(amd, shape):
     assert worst <= gu.TOL, worst
 
 
+def test_plan_templates_same_posteriors(amd):
+    """A stream that repeats 40 request shapes with changing evidence values: answered from plan templates (default)
+    and with every request planned (plan_cache=0) - the same programs, so the same posteriors bit for bit."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    rng = np.random.default_rng(3)
+    shapes = [rng.permutation(100)[:5] for _ in range(40)]
+    pick = rng.integers(0, 40, 6000)
+    q = np.array([shapes[k][0] for k in pick], np.int32)[:, None]
+    ev = np.array([shapes[k][1:] for k in pick], np.int32)
+    ec = rng.integers(0, 4, (6000, 4)).astype(np.int32)
+    templ = be.engine.query_fixed(q, ev, ec)
+    be.engine.set_option("plan_cache", 0)
+    planned = be.engine.query_fixed(q, ev, ec)
+    be.engine.set_option("plan_cache", 1)
+    assert np.array_equal(templ, planned)
+    assert np.allclose(templ.sum(1), 1.0, atol=1e-12)
+
+
 def test_single_query_api_alarm(amd):
     """README.md:225-229 (config C1): 0.715828 / 0.284172."""
     spec = next(n for n in gu.load("examples.json") if n["spec"]["name"] == "alarm")["spec"]

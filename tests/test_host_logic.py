@@ -2,6 +2,7 @@
 the CPU plan simulator, tests/simengine.py), the BayesNet API / error behaviour, and the C-ABI
 library (loads, exports every symbol of include/mibn.h, refuses to compute without a device)."""
 import copy
+import ctypes
 import os
 import pickle
 import re
@@ -325,6 +326,59 @@ def test_wide_grid_every_request_simulator_vs_oracle():
         dense = np.zeros(4)
         dense[codes[:, 0]] = vals
         assert float(np.max(np.abs(eng._one([to_var[q[i]]], to_var[ev[i]], ec[i]) - dense))) <= gu.TOL
+
+
+def _cache_check(f, reqs, small_cells=1024, tiling=(4096, 0)):
+    """reqs: list of (qvars, evars, ecodes) id/code lists -> requests answered from a plan template."""
+    L = simengine.lib()
+    L.plan_sim_cache_check.restype = ctypes.c_int64
+    L.plan_sim_set_small_cells(int(small_cells))
+    L.plan_sim_set_tiling(int(tiling[0]), int(tiling[1]))
+    q_off = np.concatenate([[0], np.cumsum([len(r[0]) for r in reqs])]).astype(np.int64)
+    e_off = np.concatenate([[0], np.cumsum([len(r[1]) for r in reqs])]).astype(np.int64)
+    qv = np.array([v for r in reqs for v in r[0]] or [0], np.int32)
+    ev = np.array([v for r in reqs for v in r[1]] or [0], np.int32)
+    ec = np.array([v for r in reqs for v in r[2]] or [0], np.int32)
+    p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    rc = L.plan_sim_cache_check(ctypes.c_int32(len(f.card)), p(f.card, ctypes.c_int32), p(f.scope_off, ctypes.c_int64),
+                                p(f.scope_vars, ctypes.c_int32), p(f.value_off, ctypes.c_int64), p(f.values, ctypes.c_double),
+                                ctypes.c_int64(len(reqs)), p(q_off, ctypes.c_int64), p(qv, ctypes.c_int32), p(e_off, ctypes.c_int64),
+                                p(ev, ctypes.c_int32), p(ec, ctypes.c_int32))
+    L.plan_sim_set_small_cells(1024)
+    L.plan_sim_set_tiling(4096, 0)
+    assert rc >= 0, L.plan_sim_error().decode()
+    return rc
+
+
+def test_plan_templates_reproduce_planned_programs():
+    """Requests that repeat a (query, evidence set) shape are instantiated from a template: the programs, items and
+    statistics must be those of planning every request (word for word) - on Asia-style streams (config 2), on the
+    10x10 grid (CHAIN / FIBER / OUTER records with evidence-sliced CPTs) and with the step forms forced onto a
+    mixed-cardinality network."""
+    rng = np.random.default_rng(0)
+
+    def stream(f, n_shapes, n, max_q=1, max_e=3):
+        nv = len(f.card)
+        shapes = []
+        for _ in range(n_shapes):
+            vs = rng.permutation(nv)
+            nq, ne = int(rng.integers(1, max_q + 1)), int(rng.integers(0, max_e + 1))
+            shapes.append((vs[:nq].tolist(), vs[nq:nq + ne].tolist()))
+        out = []
+        for _ in range(n):
+            q, e = shapes[int(rng.integers(0, n_shapes))]
+            out.append((q, e, [int(rng.integers(0, f.card[v])) for v in e]))
+        return out
+
+    asia = flatten(netspec.build(next(n for n in _nets("examples.json") if n["spec"]["name"] == "asia")["spec"], sorobn_amd.BayesNet))
+    reqs = stream(asia, 40, 1500, max_q=2)
+    assert _cache_check(asia, reqs) >= 1400
+    grid = flatten(netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet))
+    reqs = stream(grid, 12, 120, max_e=4)
+    assert _cache_check(grid, reqs) >= 100
+    dag = flatten(netspec.build(_nets("wide_cards.json")[0]["spec"], sorobn_amd.BayesNet))
+    reqs = stream(dag, 25, 400, max_q=2)
+    assert _cache_check(dag, reqs, small_cells=2, tiling=(4, 2)) >= 350
 
 
 # ------------------------------------------------------------------------------------ API behaviour
