@@ -1897,9 +1897,23 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         if (count[k + 1] > count[k]) {
             const int level = (int)(k / kNumKernels), kid = kClassOrder.kid_at[k % kNumKernels];
             if (level != cur_level) { cur_level = level; wg_level = wg; }
-            if (kid == kKidSeg)  // longest segments first: they are the tail of their level
-                std::stable_sort(out.items.begin() + count[k], out.items.begin() + count[k + 1],
-                                 [](const Item &a, const Item &b) { return a.a > b.a; });
+            if (kid == kKidSeg && count[k + 1] - count[k] > 1) {
+                // longest segments first (they are the tail of their level): stable counting sort on the step count -
+                // a comparison sort of the 100 k one-segment requests of a tiny network was the bulk of this function
+                Item *first = out.items.data() + count[k];
+                const size_t m = count[k + 1] - count[k];
+                uint32_t maxa = 0;
+                for (size_t q = 0; q < m; ++q) maxa = std::max(maxa, first[q].a & ~kItemSegment);
+                if (maxa < (1u << 16)) {
+                    std::vector<size_t> pos((size_t)maxa + 2, 0);
+                    for (size_t q = 0; q < m; ++q) ++pos[(size_t)(maxa - (first[q].a & ~kItemSegment)) + 1];
+                    for (size_t v = 0; v <= maxa; ++v) pos[v + 1] += pos[v];
+                    std::vector<Item> tmp(first, first + m);
+                    for (size_t q = 0; q < m; ++q) first[pos[(size_t)(maxa - (tmp[q].a & ~kItemSegment))]++] = tmp[q];
+                } else {
+                    std::stable_sort(first, first + m, [](const Item &a, const Item &b) { return a.a > b.a; });
+                }
+            }
             const size_t wg_first = wg;
             for (size_t q = count[k]; q < count[k + 1]; ++q) {
                 const uint32_t wgs = out.items[q].b;
