@@ -388,8 +388,7 @@ int run_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
         rq.qvars = q_vars + q_off[b];
         rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
         rq.evars = e_vars + e_off[b];
-        std::string e = validate_request(h->net, rq);
-        if (!e.empty()) { h->err = "request " + std::to_string(b) + ": " + e; return MIBN_E_ARG; }
+        if (!request_is_valid(h->net, rq)) { h->err = "request " + std::to_string(b) + ": " + validate_request(h->net, rq); return MIBN_E_ARG; }
         int64_t cells = 1;
         for (int i = 0; i < rq.nq; ++i) cells *= h->net.card[rq.qvars[i]];
         if (out_off[b + 1] - out_off[b] != cells) { h->err = "request " + std::to_string(b) + ": out_off does not match the query table size"; return MIBN_E_ARG; }

@@ -95,7 +95,22 @@ std::string Network::set(int32_t n, const int32_t *card_, const int64_t *scope_o
     return err;
 }
 
+bool request_is_valid(const Network &net, const Request &rq) {
+    if (rq.nq < 1) return false;
+    uint64_t seen[kWords];  // (only the words the network uses: a batch validates 100 k requests on one thread)
+    for (int k = 0; k < net.nw; ++k) seen[k] = 0;
+    for (int i = 0; i < rq.nq + rq.ne; ++i) {
+        const int v = i < rq.nq ? rq.qvars[i] : rq.evars[i - rq.nq];
+        if (v < 0 || v >= net.n_vars) return false;
+        const uint64_t bit = 1ull << (v & 63);
+        if (seen[v >> 6] & bit) return false;
+        seen[v >> 6] |= bit;
+    }
+    return true;
+}
+
 std::string validate_request(const Network &net, const Request &rq) {
+    if (request_is_valid(net, rq)) return "";
     if (rq.nq < 1) return "At least one query variable has to be specified";  // bayes_net.py:840-841
     Bits seen;
     for (int i = 0; i < rq.nq; ++i) {

@@ -259,6 +259,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
                     Schedule &out);
 
 // Validate a request (unknown ids, duplicates, overlap) - bayes_net.py:840-845 and the KeyError of 770.
-std::string validate_request(const Network &net, const Request &rq);
+std::string validate_request(const Network &net, const Request &rq);  // "" or the reference's error message
+bool request_is_valid(const Network &net, const Request &rq);          // the same checks without building a message
 
 }  // namespace mibn
