@@ -1,24 +1,32 @@
 #!/usr/bin/env python
 """Benchmark of the exact-inference hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched one rank per GPU by torch.distributed.run)
 
-A "step" is one pass of the hot path over one batch of synthetic requests: `--batch` exact posterior
-queries (1 query node + 4 evidence nodes, the BASELINE C3 stream from default_rng(1)) on the
-synthetic 10x10 grid BN with 4 states per node (Dirichlet(1) CPTs from default_rng(0)).  Inputs
-(the flattened network) are resident in HBM before the timed region; the timed region covers
-planning, program upload, the VE kernel, result download and - for N > 1 - the RCCL all-gather of
-the posteriors.  Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), requests
-are independent so every rank processes its own contiguous shard of the stream (weak scaling, no
-data-path collective besides the final gather).
+A "step" is one pass of the hot path over one batch of synthetic requests: `--batch` exact posterior queries per GPU
+(1 query node + 4 evidence nodes, the BASELINE C3 stream from default_rng(1)) on the synthetic 10x10 grid BN with 4
+states per node (Dirichlet(1) CPTs from default_rng(0)).  Inputs (the flattened network) are resident in HBM before
+the timed region; the timed region covers planning, program upload, the VE kernel, result download and - for N > 1 -
+the RCCL all-gather of the posteriors.  Multi-GPU: one process per GPU, requests are independent so every rank
+processes its own contiguous shard of the stream (weak scaling, no data-path collective besides the final gather).
+The whole product path is ctypes -> libmibn.so (HIP kernels + RCCL through the C-ABI): PyTorch is NOT imported unless
+the MIBN_BENCH_BACKEND=gloo|nccl test hook asks for a torch.distributed transport.
 
-Rank 0 prints ONE JSON line with the driver's contract fields plus `roofline` (dominant kernel:
-algorithmic bytes per launch / HIP-event duration, vs the 8 TB/s HBM peak) and `cpu_baseline` (the C
-oracle = port of the reference's sparse VE, timed on a bounded sample of the same stream).
+Rank 0 prints ONE JSON line with the driver's contract fields plus
+  `roofline`      dominant kernel: algorithmic bytes per launch / HIP-event duration, vs the 8 TB/s HBM peak
+  `cpu_baseline`  kind "reference": the UNMODIFIED reference (sorobn's pandas path, from oracle/_ref) timed on this box's
+                  host cores on the first requests of the same stream, no cost filter, under a wall budget: one process
+                  (cores 1 - the reference is single-threaded) and an N-process aggregate with N stated; the C port of
+                  the oracle is reported next to it as `cpu_port`
+  `configs`       the other BASELINE.json configurations measured in the same process after the C3 region: C1 (alarm,
+                  single query latency), C2 (Asia, 100 k batched queries), C5 (Gibbs, 100 k updates x chains)
+`--config c5` times the Gibbs configuration instead (a step = 100 k single-site updates x 128 chains per GPU + the
+int64 histogram reduce).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -51,13 +59,79 @@ def pmc_traffic(kernel):
     return d["traffic_bytes_per_launch"], {"file": os.path.relpath(f, ROOT), "alg_bytes_per_launch_same_run": d.get("alg_bytes_per_launch_same_run")}
 
 
-def cpu_baseline(spec, qv, ev, ec, gpu_post, budget_s, max_rows=3e7):
-    """Time the C oracle (oracle/ve_oracle.c, kind="port": sparse-table VE restating
-    bayes_net.py:739-794, eliminating in ascending-name = row-major order like the hash-ordered
-    reference) on the first requests of the stream until `budget_s` seconds are spent; also returns the
-    max-abs marginal error of the GPU posteriors on that sample.  Requests whose row-major product
-    would exceed `max_rows` rows (minutes each on the CPU; the reference needs 448 s for the worst
-    one) are skipped and counted - so the CPU figure is optimistic."""
+# ------------------------------------------------------------------------------------------------ CPU baselines
+
+def cpu_reference(budget_s, n_procs, first=200, workload="c3"):
+    """The unmodified reference on this box's host cores (oracle/ref_worker.py): one process works through requests
+    0, 1, 2, ... of the stream (the single-core figure; the reference cannot use more than one core) while `n_procs`
+    more processes work through interleaved shards of the same first `first` requests (the aggregate).  No cost
+    filter; a request still running when the budget ends is abandoned and counted as unfinished.  Returns
+    (single, aggregate, answers {request index: (index rows, values)}) or None when oracle/_ref is unavailable."""
+    from oracle import refload
+    if not refload.available():
+        return None
+    env = dict(os.environ, PYTHONHASHSEED="0", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    worker = os.path.join(ROOT, "oracle", "ref_worker.py")
+
+    def spawn(shard, nshards):
+        return subprocess.Popen([sys.executable, worker, "--workload", workload, "--first", str(first), "--shard", str(shard),
+                                 "--nshards", str(nshards), "--budget", str(budget_s)], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+
+    procs = [spawn(0, 1)] + [spawn(i, n_procs) for i in range(n_procs)]
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=budget_s + 120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            so, se = p.communicate()
+        outs.append((so, se, p.returncode))
+    answers = {}
+    summaries = []
+    for so, se, rc in outs:
+        done = None
+        times = []
+        for line in so.splitlines():
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if d.get("done"):
+                done = d
+            elif "i" in d:
+                answers[d["i"]] = (d["index"], d["values"])
+                times.append(d["s"])
+        if done is None:
+            return {"error": f"reference worker failed (rc {rc}): {se[-400:]}"}, None, {}
+        done["times"] = times
+        summaries.append(done)
+    one = summaries[0]
+    single = {"value": one["finished"] / one["elapsed"] if one["elapsed"] > 0 else 0.0, "unit": "queries/s", "cores": 1,
+              "kind": "reference",
+              "sample": f"unmodified sorobn (oracle/_ref, loaded from '{one['reference']}'; BayesNet.query, pandas 2.3.3, PYTHONHASHSEED=0, "
+                        f"hash-ordered names => row-major elimination): requests 0..{one['attempted'] - 1} of the C3 stream (rng seed 1) in "
+                        f"stream order, NO cost filter, wall budget {budget_s:.0f} s: {one['finished']} finished, "
+                        f"{one['attempted'] - one['finished']} in flight at the end (abandoned, its time counted); median "
+                        f"{(float(np.median(one['times'])) if one['times'] else float('nan')):.2f} s per finished request",
+              "finished": one["finished"], "attempted": one["attempted"], "elapsed_s": one["elapsed"]}
+    agg = summaries[1:]
+    fin = sum(d["finished"] for d in agg)
+    att = sum(d["attempted"] for d in agg)
+    el = max(d["elapsed"] for d in agg) if agg else 0.0
+    aggregate = {"value": fin / el if el > 0 else 0.0, "unit": "queries/s", "processes": len(agg), "cores": len(agg),
+                 "finished": fin, "attempted": att, "elapsed_s": el,
+                 "sample": f"{len(agg)} independent reference processes over interleaved shards (i mod {len(agg)}) of the first {first} "
+                           f"requests of the same stream, same wall budget, running beside the single-process leg"}
+    return single, aggregate, answers
+
+
+def cpu_port(spec, qv, ev, ec, gpu_post, budget_s, max_rows=3e7):
+    """The C oracle (oracle/ve_oracle.c, kind="port": sparse-table VE restating bayes_net.py:739-794, eliminating in
+    ascending-name = row-major order like the hash-ordered reference) on the first requests of the stream until
+    `budget_s` seconds are spent; also returns the max-abs marginal error of the GPU posteriors on that sample.
+    Requests whose row-major product would exceed `max_rows` rows (minutes each on the CPU) are skipped and counted -
+    so this second figure is optimistic; the unfiltered one is `cpu_baseline` (the reference itself)."""
     import netspec
     from oracle.oracle import OracleNet
 
@@ -81,10 +155,78 @@ def cpu_baseline(spec, qv, ev, ec, gpu_post, budget_s, max_rows=3e7):
         i += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt if n else 0.0, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the first {n + skipped} requests of the C3 stream (rng seed 1) in {dt:.1f} s; the other "
-                      f"{skipped} (> {max_rows:.0e} row-major product rows, minutes each on a CPU core) were not run, so "
-                      "the figure is an upper bound for the whole stream; oracle/ve_oracle.c, single thread, "
-                      "row-major (ascending name) elimination order like the hash-ordered reference"}, err
+            "sample": f"{n} of the first {n + skipped} requests of the C3 stream in {dt:.1f} s; the other {skipped} "
+                      f"(> {max_rows:.0e} row-major product rows) were NOT run, so this figure is an upper bound; "
+                      "oracle/ve_oracle.c, single thread, row-major elimination order"}, err
+
+
+# ------------------------------------------------------------------------------------------------ other configs
+
+def other_configs(device):
+    """C1 / C2 / C5 of BASELINE.json in this process (N = 1, after the C3 region)."""
+    import golden_util as gu
+    import netspec
+    import sorobn_amd
+
+    out = {}
+    nets = {n["spec"]["name"]: n["spec"] for n in gu.load("examples.json")}
+    # C1: alarm, one query() through the reference-shaped API
+    bna = netspec.build(nets["alarm"], sorobn_amd.BayesNet).use_device(device)
+    ev1 = {"Mary calls": True, "John calls": True}
+    ans = bna.query("Burglary", event=ev1)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        ans = bna.query("Burglary", event=ev1)
+    out["C1_alarm_single_query"] = {"ms_per_query": (time.perf_counter() - t0) / 200 * 1e3, "answer": ans.to_numpy().tolist(),
+                                    "reference_answer": [0.7158281646356071, 0.28417183536439294]}
+    # C2: Asia, 100 k requests of the SURVEY 8(d) stream in one batch (host-side encode of the names outside the timing)
+    bn2 = netspec.build(nets["asia"], sorobn_amd.BayesNet).use_device(device)
+    be2 = bn2.backend
+    eng2 = be2.engine
+    reqs = netspec.asia_requests(list(bn2.nodes), 100_000, seed=0)
+    q_off = np.arange(len(reqs) + 1, dtype=np.int64)
+    q_vars = np.array([be2.flat.id[q] for q, _ in reqs], np.int32)
+    e_off = np.concatenate([[0], np.cumsum([len(e) for _, e in reqs])]).astype(np.int64)
+    e_vars = np.array([be2.flat.id[k] for _, e in reqs for k in e], np.int32)
+    e_codes = np.array([be2.flat.code_of(be2.flat.id[k], v) for _, e in reqs for k, v in e.items()], np.int32)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        post, off = eng2.query_batch(q_off, q_vars, e_off, e_vars, e_codes)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    s = eng2.stats()
+    sums = np.add.reduceat(post, off[:-1])
+    nz = int((sums > 0).sum())
+    out["C2_asia_100k"] = {"queries_per_s": nz / best, "wall_ms": best * 1e3, "kernel_ms": s["kernel_ms"], "plan_ms": s["plan_ms"],
+                           "launches": s["n_launches"], "zero_probability_evidence_excluded": int(len(reqs) - nz),
+                           "note": "36 CPT numbers: not HBM-bound (roofline n/a); host- and launch-bound"}
+    # C5: 50-node K=8 grid, Gibbs, 100 k single-site updates per chain; 128 chains = one GPU's share of the 1024
+    spec5 = netspec.grid_spec(5, 10, 8, seed=0)
+    bn5 = netspec.build(spec5, sorobn_amd.BayesNet).use_device(device)
+    rng = np.random.default_rng(1)
+    ev5 = {f"{k:03d}": int(rng.integers(0, 8)) for k in (0, 9, 40, 49, 22)}
+    exact = bn5.query("025", event=ev5).to_numpy()
+    bn5.query("025", event=ev5, algorithm="gibbs", n_iterations=1000, n_chains=128)
+    for chains in (128, 1024):
+        t0 = time.perf_counter()
+        got = bn5.query("025", event=ev5, algorithm="gibbs", n_iterations=100_000, n_chains=chains).to_numpy()
+        dt = time.perf_counter() - t0
+        out[f"C5_gibbs_{chains}_chains_x_100k"] = {"wall_ms": dt * 1e3, "updates_per_s": chains * 100_000 / dt,
+                                                   "max_abs_err_vs_exact": float(np.max(np.abs(got - exact)))}
+    out["C5_note"] = "latency/LDS-bound (CPTs resident in LDS), HBM roofline n/a; 128 chains = one GPU's share of config 5"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ transports
+
+def make_comm(backend, world, rank, local_rank, engine):
+    from sorobn_amd import sharding
+    if world == 1:
+        return sharding.SoloComm()
+    if backend == "rccl":
+        return sharding.RcclComm(engine, rank, world)
+    return sharding.TorchComm()
 
 
 def main():
@@ -92,10 +234,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
     ap.add_argument("--batch", type=int, default=32768, help="requests per step per GPU")
     ap.add_argument("--n-evidence", type=int, default=4)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--balance", default="count", choices=["count", "cost"],
+                    help="split of a step's global batch over the ranks: equal counts, or equal planner cost estimates")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the reference leg of cpu_baseline")
+    ap.add_argument("--cpu-procs", type=int, default=8, help="reference processes of the aggregate figure")
+    ap.add_argument("--port-seconds", type=float, default=6.0, help="wall budget of the C-port leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true")
     ap.add_argument("--sync", action="store_true", help="one blocking mibn_query_batch per step instead of the two-deep pipeline")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (experiments), e.g. --opt chunk=32768")
     ap.add_argument("--threads", type=int, default=0, help="planner threads of this rank (0 = host threads / ranks on the node)")
@@ -110,24 +258,29 @@ def main():
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         a.gpus = world
 
-    import torch  # plumbing only: barrier / synchronize / RCCL gather
-    import torch.distributed as dist
-
+    # Transport of the final gather: "rccl" (default) = mibn_comm_* of the C-ABI, RCCL over xGMI, no PyTorch.
     # MIBN_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 path run on a box with fewer GPUs than ranks (ranks then
-    # share devices and the collectives run on host tensors); the measured configuration is always nccl (= RCCL)
-    backend = os.environ.get("MIBN_BENCH_BACKEND", "nccl")
-    device = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    coll_dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
-    torch.cuda.set_device(device)
-    if world > 1:
+    # share devices and the collectives run on host tensors through torch.distributed); "nccl" = RCCL through PyTorch.
+    backend = os.environ.get("MIBN_BENCH_BACKEND", "rccl")
+    from sorobn_amd import _capi
+    n_dev = max(1, _capi.device_count())
+    device = local_rank if backend != "gloo" else local_rank % n_dev
+    if world > 1 and backend != "rccl":
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            torch.cuda.set_device(device)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import netspec
     import sorobn_amd
+    from sorobn_amd import sharding
+
+    if a.config == "c5":
+        return run_c5(a, rank, world, local_rank, device, backend)
 
     spec = netspec.grid_spec(10, 10, 4, seed=0)
     bn = netspec.build(spec, sorobn_amd.BayesNet).use_device(device)
@@ -138,39 +291,40 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, float(v))
+    comm = make_comm(backend, world, rank, local_rank, eng)
 
     total_steps = a.warmup + a.steps
     n_req = total_steps * world * a.batch
     qv, ev, ec = netspec.c3_requests(100, 4, n_req, a.n_evidence, seed=1)
     # names "000".."099" sort like the ids, but variable ids follow bn.nodes: map stream ids -> var ids
     to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    G = world * a.batch  # a step's global batch
 
-    def shard(step):
-        lo = (step * world + rank) * a.batch
-        return to_var[qv[lo:lo + a.batch]], to_var[ev[lo:lo + a.batch]], ec[lo:lo + a.batch], lo
+    def ranges_of(step):
+        """The shard of every rank inside step `step`'s global batch (same on every rank)."""
+        if a.balance == "cost" and world > 1:
+            lo = step * G
+            cost = eng.estimate_costs(to_var[qv[lo:lo + G]][:, None], to_var[ev[lo:lo + G]])
+            return sharding.cost_balanced_ranges(cost, world)
+        return [(r * a.batch, (r + 1) * a.batch) for r in range(world)]
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    gathered = None
-    if world > 1:
-        gathered = torch.empty((world, a.batch, 4), dtype=torch.float64, device=coll_dev)
+        comm.barrier()
+        eng.synchronize()
 
     # The K timed steps are pipelined two deep (mibn_submit_batch / mibn_wait): the host plans step s+1 while the
     # GPU runs step s, as a server streaming batches would.  Every step is complete - posteriors on the host and,
     # for N > 1, gathered over RCCL - before the closing barrier.
     def submit(step):
-        q, e, c, lo = shard(step)
-        return eng.submit_fixed(q[:, None], e, c), lo
+        rg = ranges_of(step)
+        lo, hi = step * G + rg[rank][0], step * G + rg[rank][1]
+        return eng.submit_fixed(to_var[qv[lo:hi]][:, None], to_var[ev[lo:hi]], ec[lo:hi]), lo, rg
 
     def finish(pending):
-        handle, lo = pending
+        handle, lo, rg = pending
         post = eng.wait(handle)
         if world > 1:  # final gather of the posteriors over xGMI (RCCL)
-            mine = torch.from_numpy(post).to(coll_dev, non_blocking=False)
-            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
+            sharding.gather_posteriors(post, G, comm, ranges=rg)
         return post, lo
 
     def run(steps):
@@ -203,9 +357,7 @@ def main():
     kagg = {n: {f: ks1[n][f] - ks0.get(n, {}).get(f, 0.0) for f in ks1[n]} for n in ks1}
     kagg = {n: d for n, d in kagg.items() if d["launches"] > 0}
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(comm.allreduce_max([dt])[0])
 
     if rank == 0:
         n_queries = a.steps * world * a.batch
@@ -231,7 +383,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C3: 10x10 grid BN, 4 states/node, Dirichlet(1) CPTs rng(0); requests = "
                                    f"1 query + {a.n_evidence} evidence nodes, rng(1) stream",
-                       "requests_per_step_per_gpu": a.batch, "parallelism": f"dp{world} (independent shards)"},
+                       "requests_per_step_per_gpu": a.batch, "parallelism": f"dp{world} (independent shards)",
+                       "gather": "none" if world == 1 else {"rccl": "RCCL via the C-ABI (mibn_comm_allgather_f64), no PyTorch",
+                                                            "nccl": "RCCL via torch.distributed (hook)",
+                                                            "gloo": "gloo via torch.distributed (test hook)"}[backend],
+                       "shard_balance": a.balance},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": dom, "alg_bytes_per_launch": bytes_per_launch,
@@ -244,15 +400,106 @@ def main():
                         for n, d in sorted(kagg.items(), key=lambda kv: -kv[1]["ms"])},
             "breakdown_ms_per_step": {k: agg[k] / a.steps for k in ("plan_ms", "h2d_ms", "kernel_ms", "d2h_ms", "total_ms")},
         }
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(dom)
+        if world > 1:
+            lo = a.warmup * G
+            cost = eng.estimate_costs(to_var[qv[lo:lo + G]][:, None], to_var[ev[lo:lo + G]])
+            out["shard_cost_imbalance"] = {
+                "count_split": sharding.imbalance(cost, [(r * a.batch, (r + 1) * a.batch) for r in range(world)]),
+                "cost_split": sharding.imbalance(cost, sharding.cost_balanced_ranges(cost, world)),
+                "note": "max / mean shard cost (planner estimate) of one step's global batch; the C3 stream is i.i.d., "
+                        "so equal counts already balance to ~1 %"}
+        if world == 1 and not a.no_configs:
+            try:
+                out["configs"] = other_configs(device)
+            except Exception as e:  # the headline line must not die with a side measurement
+                out["configs"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu:
-            lo = first_lo
-            cb, err = cpu_baseline(spec, qv[lo:lo + a.batch], ev[lo:lo + a.batch], ec[lo:lo + a.batch],
-                                   first_post, a.cpu_seconds)
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(dom)
-            out["cpu_baseline"] = cb
-            out["max_abs_marginal_err_vs_oracle"] = err
+            # GPU posteriors of the first 200 requests of the stream (what the reference legs work on)
+            n_ref = 200
+            post200 = eng.query_fixed(to_var[qv[:n_ref]][:, None], to_var[ev[:n_ref]], ec[:n_ref])
+            ref = cpu_reference(a.cpu_seconds, a.cpu_procs, first=n_ref) if a.cpu_seconds > 0 else None
+            port, err_port = cpu_port(spec, qv[:n_ref], ev[:n_ref], ec[:n_ref], post200, a.port_seconds)
+            if ref is not None and "error" not in ref[0]:
+                single, aggregate, answers = ref
+                err_ref, n_cmp = 0.0, 0
+                for i, (index, values) in answers.items():
+                    dense = np.zeros(4)
+                    for key, v in zip(index, values):
+                        dense[int(key[0])] = v
+                    err_ref = max(err_ref, float(np.max(np.abs(dense - post200[i]))))
+                    n_cmp += 1
+                out["cpu_baseline"] = single
+                out["cpu_baseline"]["aggregate"] = aggregate
+                out["max_abs_marginal_err_vs_reference"] = {"value": err_ref, "requests_compared": n_cmp}
+                out["cpu_port"] = port
+            else:  # oracle/_ref did not travel (fresh clone without `make -C oracle _ref`): the port is all there is
+                out["cpu_baseline"] = port
+                out["cpu_baseline"]["note"] = "oracle/_ref unavailable on this box: " + (ref[0]["error"] if ref else "not built")
+            out["max_abs_marginal_err_vs_oracle"] = err_port
         print(json.dumps(out), flush=True)
+    comm.barrier()
+    comm.close()
+    if world > 1 and backend != "rccl":
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def run_c5(a, rank, world, local_rank, device, backend):
+    """BASELINE config 5: 50-node K=8 grid, algorithm='gibbs', 100 k single-site updates per chain, 128 chains per GPU
+    (1024 on 8 GPUs) of ONE chain stream, histograms summed onto rank 0 with mibn_comm_reduce_i64."""
+    import netspec
+    import sorobn_amd
+    from sorobn_amd import sharding
+
+    chains_per_gpu, iters = 128, 100_000
+    spec5 = netspec.grid_spec(5, 10, 8, seed=0)
+    bn5 = netspec.build(spec5, sorobn_amd.BayesNet).use_device(device)
+    be = bn5.backend
+    eng = be.engine
+    comm = make_comm(backend, world, rank, local_rank, eng)
+    rng = np.random.default_rng(1)
+    ev5 = {f"{k:03d}": int(rng.integers(0, 8)) for k in (0, 9, 40, 49, 22)}
+    q, evs, codes = be.encode(("025",), ev5)
+    free = [v for v in range(len(be.flat.names)) if v not in set(evs)]
+    cycle = sorted(free, key=lambda v: be.flat.names[v])
+    exact = bn5.query("025", event=ev5).to_numpy()
+    total_chains = chains_per_gpu * world
+
+    def step(s):
+        return sharding.gibbs_sharded(eng, comm, q, evs, codes, total_chains, iters, seed=1000 + s, cycle=cycle)
+
+    for s in range(a.warmup):
+        step(s)
+    comm.barrier()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    hist = None
+    for s in range(a.warmup, a.warmup + a.steps):
+        h = step(s)
+        hist = h if hist is None else hist + h
+    comm.barrier()
+    eng.synchronize()
+    dt = time.perf_counter() - t0
     if world > 1:
+        dt = float(comm.allreduce_max([dt])[0])
+    if rank == 0:
+        est = hist / float(hist.sum())
+        out = {"metric": "Gibbs single-site updates/sec on 50-node 8-state grid BN (config 5)",
+               "value": a.steps * total_chains * iters / dt, "unit": "updates/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "C5: 5x10 grid BN, 8 states/node, query node 25, 5 evidence nodes; "
+                                      f"{iters} single-site updates x {chains_per_gpu} chains per GPU",
+                          "parallelism": f"dp{world} (chain shards of one Philox stream, int64 histogram reduce)"},
+               "roofline": {"bound": "latency/LDS (CPTs resident in LDS): HBM roofline n/a", "achieved": None, "peak": None,
+                            "unit": None, "frac": None, "traffic": None},
+               "max_abs_err_vs_exact": float(np.max(np.abs(est - exact)))}
+        print(json.dumps(out), flush=True)
+    comm.barrier()
+    comm.close()
+    if world > 1 and backend != "rccl":
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -38,6 +38,7 @@ extern "C" {
 #define MIBN_E_NOMEM (-4)     /* plan needs more device memory than the arena budget */
 #define MIBN_E_STATE (-5)     /* call order (e.g. query before set_network) */
 #define MIBN_E_LIMIT (-6)     /* a compile-time limit (scope size, axes) was exceeded */
+#define MIBN_E_COMM (-7)      /* RCCL missing or a collective failed */
 
 typedef struct mibn_ctx mibn_t;
 
@@ -88,6 +89,18 @@ int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *
                      const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
                      const int64_t *out_off, double *out);
 
+/*
+ * mibn_query_batch with per-call flags (nothing engine-wide changes, so it is safe next to asynchronous calls in flight
+ * on other engines of the same network):
+ *   MIBN_Q_NOPRUNE   multiply every CPT instead of pruning to the ancestors of the query / evidence variables
+ *                    (bayes_net.py:763-765): the semantics of full_joint_dist / predict_proba (bayes_net.py:460), where
+ *                    with sparse or unnormalised CPTs a barren node does not sum to 1.
+ */
+#define MIBN_Q_NOPRUNE 1
+int mibn_query_batch_ex(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                        const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
+                        const int64_t *out_off, double *out);
+
 /* Statistics of the last mibn_query_batch call (for the roofline report). */
 typedef struct mibn_stats {
     double alg_bytes;      /* sum over steps of 8*(sum input cells + output cells) */
@@ -136,6 +149,16 @@ int mibn_plan_stats(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e,
                     const int32_t *e_vars, mibn_stats *out);
 int mibn_create_planner(mibn_t **out); /* host-only context: set_network/plan_stats work, queries fail */
 
+/* Cheap per-request cost estimate for shard balancing ("balance by the planner's bytes_query, not
+ * by count - per-request cost varies 1000x"): cost[b] = section-8(d) bytes of the cheaper of the planner's two sweep
+ * orders for request b (no program is emitted, no min-fill search; ~2 us per request and planner thread).  Works on a
+ * planner-only context too.  `sorobn_amd.sharding.cost_balanced_ranges` turns the prefix sums into contiguous shards. */
+int mibn_estimate_costs(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off,
+                        const int32_t *e_vars, double *cost);
+
+/* Wait for everything this context has submitted to its device (kernels, copies, collectives). */
+int mibn_device_synchronize(mibn_t *h);
+
 /* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "chunk" (requests per planning /
  * launch chunk), "plan_cache" (0: plan every request, no plan templates for repeated request shapes).
  * Test and profiling hooks: "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the
@@ -159,6 +182,14 @@ int mibn_set_option(mibn_t *h, const char *name, double value);
 int mibn_gibbs(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
                const int32_t *e_codes, const int32_t *cycle, int64_t n_chains, int64_t n_iterations,
                uint64_t seed, int64_t *counts);
+
+/* A shard of the chains of one mibn_gibbs call: chains [chain_first, chain_first + n_chains) of the stream `seed` (the
+ * Philox key is (seed, global chain index), so the union of disjoint shards - on any number of GPUs - gives bit for bit
+ * the histogram of the unsharded call; mibn_gibbs == chain_first 0).  Multi-GPU: every rank runs its chain range and the
+ * int64 histograms are summed with mibn_comm_reduce_i64. */
+int mibn_gibbs_shard(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                     const int32_t *e_codes, const int32_t *cycle, int64_t chain_first, int64_t n_chains,
+                     int64_t n_iterations, uint64_t seed, int64_t *counts);
 
 /*
  * Forward (ancestral) sampling and the two approximate algorithms built on it.
@@ -192,6 +223,28 @@ int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_v
 int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, int32_t row_major, const int32_t *card,
                       int32_t n_tables, const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off,
                       int64_t *counts);
+
+/*
+ * Multi-GPU: one process per GPU, requests / chains sharded with no data-path collective; the
+ * only communication is the final gather of the posteriors (exact path) or the sum of the histograms (Gibbs).  These
+ * entry points sit directly on RCCL (librccl.so is dlopen'ed by mibn_comm_init - a single-GPU process never loads it) and
+ * run on the context's own stream, over xGMI between the GPUs of a node.  No PyTorch involved.
+ *   mibn_comm_unique_id   rank 0 creates the 128-byte RCCL id; the caller hands it to the other ranks out of band
+ *                         (sorobn_amd/sharding.py: a file next to the rendezvous port, single node)
+ *   mibn_comm_init        collective: every rank calls it with the same id
+ *   mibn_comm_allgather_f64   recv[r * n .. (r+1) * n) = rank r's send[0 .. n)   (host buffers, staged through HBM)
+ *   mibn_comm_reduce_i64      sum over ranks of buf[0 .. n) -> buf on `root` (other ranks' buf unchanged)
+ *   mibn_comm_allreduce_max_f64   element-wise max over ranks, in place (the bench's max-over-ranks step time)
+ *   mibn_comm_barrier     all ranks have reached the call and their device work is complete
+ */
+#define MIBN_COMM_ID_BYTES 128
+int mibn_comm_unique_id(mibn_t *h, void *id_out /* MIBN_COMM_ID_BYTES */);
+int mibn_comm_init(mibn_t *h, int32_t rank, int32_t world, const void *id /* MIBN_COMM_ID_BYTES */);
+int mibn_comm_destroy(mibn_t *h);
+int mibn_comm_allgather_f64(mibn_t *h, const double *send, int64_t n, double *recv);
+int mibn_comm_reduce_i64(mibn_t *h, int64_t *buf, int64_t n, int32_t root);
+int mibn_comm_allreduce_max_f64(mibn_t *h, double *buf, int64_t n);
+int mibn_comm_barrier(mibn_t *h);
 
 #ifdef __cplusplus
 }

@@ -18,9 +18,14 @@ SYMBOLS = [
     "mibn_plan_stats", "mibn_create_planner", "mibn_set_option", "mibn_gibbs",
     "mibn_last_kernel_stats", "mibn_submit_batch", "mibn_wait", "mibn_drain", "mibn_total_stats",
     "mibn_total_kernel_stats", "mibn_sample", "mibn_sampling_query", "mibn_count_tables",
+    "mibn_query_batch_ex", "mibn_estimate_costs", "mibn_device_synchronize", "mibn_gibbs_shard",
+    "mibn_comm_unique_id", "mibn_comm_init", "mibn_comm_destroy", "mibn_comm_allgather_f64",
+    "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier",
 ]
 
-OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
+Q_NOPRUNE = 1
+COMM_ID_BYTES = 128
 
 
 class MibnError(RuntimeError):
@@ -68,6 +73,18 @@ def lib():
         L.mibn_set_network.argtypes = [vp, C.c_int32, i32p, i64p, i32p, i64p, f64p]
         L.mibn_set_order_hints.argtypes = [vp, C.c_int32, i32p]
         L.mibn_query_batch.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p]
+        L.mibn_query_batch_ex.argtypes = [vp, C.c_uint32, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p]
+        L.mibn_estimate_costs.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, f64p]
+        L.mibn_device_synchronize.argtypes = [vp]
+        L.mibn_gibbs_shard.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, i32p, i32p, C.c_int64, C.c_int64,
+                                       C.c_int64, C.c_uint64, i64p]
+        L.mibn_comm_unique_id.argtypes = [vp, C.c_char_p]
+        L.mibn_comm_init.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p]
+        L.mibn_comm_destroy.argtypes = [vp]
+        L.mibn_comm_allgather_f64.argtypes = [vp, f64p, C.c_int64, f64p]
+        L.mibn_comm_reduce_i64.argtypes = [vp, i64p, C.c_int64, C.c_int32]
+        L.mibn_comm_allreduce_max_f64.argtypes = [vp, f64p, C.c_int64]
+        L.mibn_comm_barrier.argtypes = [vp]
         L.mibn_submit_batch.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p, C.POINTER(C.c_int32)]
         L.mibn_wait.argtypes = [vp, C.c_int32]
         L.mibn_drain.argtypes = [vp]
@@ -152,8 +169,8 @@ class Engine:
     def set_option(self, name, value):
         self._check(self._L.mibn_set_option(self._h, name.encode(), float(value)))
 
-    def query_batch(self, q_off, q_vars, e_off, e_vars, e_codes, out_off=None):
-        """CSR request batch -> flat float64 posteriors (+ out_off)."""
+    def query_batch(self, q_off, q_vars, e_off, e_vars, e_codes, out_off=None, flags=0):
+        """CSR request batch -> flat float64 posteriors (+ out_off).  flags: Q_NOPRUNE (per call, see mibn.h)."""
         q_off, e_off = _i64(q_off), _i64(e_off)
         q_vars, e_vars, e_codes = _i32(q_vars), _i32(e_vars), _i32(e_codes)
         B = len(q_off) - 1
@@ -173,13 +190,13 @@ class Engine:
         e_codes_ = e_codes if len(e_codes) else np.zeros(1, np.int32)
         q_vars_ = q_vars if len(q_vars) else np.zeros(1, np.int32)
         out_ = out if len(out) else np.zeros(1, np.float64)
-        self._check(self._L.mibn_query_batch(
-            self._h, B, _p(q_off, C.c_int64), _p(q_vars_, C.c_int32), _p(e_off, C.c_int64),
+        self._check(self._L.mibn_query_batch_ex(
+            self._h, int(flags), B, _p(q_off, C.c_int64), _p(q_vars_, C.c_int32), _p(e_off, C.c_int64),
             _p(e_vars_, C.c_int32), _p(e_codes_, C.c_int32), _p(out_off, C.c_int64),
             _p(out_, C.c_double)))
         return out, out_off
 
-    def query_fixed(self, qvars, evars, ecodes):
+    def query_fixed(self, qvars, evars, ecodes, flags=0):
         """Fixed-shape batch: qvars[B, nq], evars[B, ne], ecodes[B, ne] -> posteriors[B, cells]
         (all requests must have the same query-table size)."""
         if len(qvars) == 0:
@@ -192,7 +209,7 @@ class Engine:
         q_off = np.arange(B + 1, dtype=np.int64) * nq
         e_off = np.arange(B + 1, dtype=np.int64) * ne
         out, out_off = self.query_batch(q_off, qvars.reshape(-1), e_off, evars.reshape(-1),
-                                        ecodes.reshape(-1))
+                                        ecodes.reshape(-1), flags=flags)
         return out.reshape(B, -1) if B else out.reshape(0, 0)
 
     def submit_fixed(self, qvars, evars, ecodes):
@@ -257,7 +274,8 @@ class Engine:
                                             _p(e_, C.c_int32), C.byref(s)))
         return s.as_dict()
 
-    def gibbs(self, qvars, evars, ecodes, n_chains, n_iterations, seed=0, cycle=None):
+    def gibbs(self, qvars, evars, ecodes, n_chains, n_iterations, seed=0, cycle=None, chain_first=0):
+        """Histogram of chains [chain_first, chain_first + n_chains) of stream `seed` (mibn_gibbs_shard)."""
         q, e, c = _i32(qvars), _i32(evars), _i32(ecodes)
         e_ = e if len(e) else np.zeros(1, np.int32)
         c_ = c if len(c) else np.zeros(1, np.int32)
@@ -267,11 +285,60 @@ class Engine:
         if cycle is not None:
             cyc_arr = _i32(cycle)
             cyc = _p(cyc_arr, C.c_int32)
-        self._check(self._L.mibn_gibbs(self._h, len(q), _p(q, C.c_int32), len(e),
-                                       _p(e_, C.c_int32), _p(c_, C.c_int32), cyc, int(n_chains),
-                                       int(n_iterations), int(seed) & (2**64 - 1),
-                                       _p(counts, C.c_int64)))
+        self._check(self._L.mibn_gibbs_shard(self._h, len(q), _p(q, C.c_int32), len(e),
+                                             _p(e_, C.c_int32), _p(c_, C.c_int32), cyc, int(chain_first), int(n_chains),
+                                             int(n_iterations), int(seed) & (2**64 - 1),
+                                             _p(counts, C.c_int64)))
         return counts
+
+    # ---- shard balancing / multi-GPU ------------------------------------------------------
+    def estimate_costs(self, qvars, evars):
+        """Planner cost estimate (section-8(d) bytes of the cheaper sweep order) per request of a fixed-shape batch."""
+        qvars = _i32(qvars).reshape(len(qvars), -1)
+        B, nq = qvars.shape
+        evars = _i32(evars).reshape(B, -1)
+        ne = evars.shape[1]
+        q_off = np.arange(B + 1, dtype=np.int64) * nq
+        e_off = np.arange(B + 1, dtype=np.int64) * ne
+        cost = np.zeros(max(1, B), np.float64)
+        ev = evars.reshape(-1) if evars.size else np.zeros(1, np.int32)
+        self._check(self._L.mibn_estimate_costs(self._h, B, _p(q_off, C.c_int64), _p(qvars.reshape(-1), C.c_int32),
+                                                _p(e_off, C.c_int64), _p(ev, C.c_int32), _p(cost, C.c_double)))
+        return cost[:B]
+
+    def synchronize(self):
+        self._check(self._L.mibn_device_synchronize(self._h))
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        self._check(self._L.mibn_comm_unique_id(self._h, buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._check(self._L.mibn_comm_init(self._h, int(rank), int(world), unique_id))
+
+    def comm_destroy(self):
+        self._check(self._L.mibn_comm_destroy(self._h))
+
+    def comm_allgather(self, send, world):
+        send = np.ascontiguousarray(send, dtype=np.float64).reshape(-1)
+        recv = np.empty(len(send) * int(world), np.float64)
+        self._check(self._L.mibn_comm_allgather_f64(self._h, _p(send, C.c_double), len(send), _p(recv, C.c_double)))
+        return recv.reshape(int(world), -1)
+
+    def comm_reduce_i64(self, buf, root=0):
+        out = np.ascontiguousarray(buf, dtype=np.int64).copy()
+        self._check(self._L.mibn_comm_reduce_i64(self._h, _p(out.reshape(-1), C.c_int64), out.size, int(root)))
+        return out
+
+    def comm_allreduce_max(self, values):
+        out = np.ascontiguousarray(values, dtype=np.float64).copy().reshape(-1)
+        self._check(self._L.mibn_comm_allreduce_max_f64(self._h, _p(out, C.c_double), len(out)))
+        return out
+
+    def comm_barrier(self):
+        self._check(self._L.mibn_comm_barrier(self._h))
 
     def sample(self, n_samples, init_vars=(), init_codes=(), seed=0):
         """Forward samples: uint8 codes [n_samples, n_vars]."""

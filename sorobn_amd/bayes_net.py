@@ -78,12 +78,8 @@ class Backend:
         q, _, _ = self.encode(names, {})
         eng = self.engine if engine is None else engine
         # every CPT takes part (bayes_net.py:460): no pruning to the ancestors - with sparse CPTs a barren node
-        # does not sum to 1
-        eng.set_option("prune", 0)
-        try:
-            return eng.query_fixed([q], np.zeros((1, 0), np.int32), np.zeros((1, 0), np.int32))[0]
-        finally:
-            eng.set_option("prune", 1)
+        # does not sum to 1.  A per-call flag: nothing engine-wide changes under asynchronous calls in flight.
+        return eng.query_fixed([q], np.zeros((1, 0), np.int32), np.zeros((1, 0), np.int32), flags=_capi.Q_NOPRUNE)[0]
 
     def joint_series(self, names, keep_zeros=False):
         """Series over the sorted `names` like `full_joint_dist` builds it (bayes_net.py:460-465): sorted levels, sorted
@@ -106,7 +102,28 @@ class Backend:
 
     @staticmethod
     def fingerprint_of(bn):
-        return tuple((id(k), id(v), len(v)) for k, v in bn.P.items())
+        """Identity AND content of the CPTs: the reference re-reads `P` on every query (bayes_net.py:770), so a value
+        edited in place (`bn.P['A'][True] = 0.9`) must reach the device tables too.  CPTs are tiny (the 10x10 grid:
+        44 KB in all), hashing their bytes costs microseconds next to a query."""
+        fp = []
+        for k, v in bn.P.items():
+            vals = getattr(v, "values", None)
+            try:
+                content = hash(np.ascontiguousarray(vals).tobytes()) if vals is not None and vals.dtype != object else None
+            except (TypeError, ValueError):
+                content = None
+            idx = getattr(v, "index", None)
+            if isinstance(idx, pd.MultiIndex):
+                ih = hash(tuple(np.ascontiguousarray(c).tobytes() for c in idx.codes)) ^ hash(tuple(len(l) for l in idx.levels))
+            elif idx is not None:
+                try:
+                    ih = hash(tuple(idx.tolist()))
+                except TypeError:
+                    ih = len(idx)
+            else:
+                ih = 0
+            fp.append((id(k), id(v), len(v), content, ih))
+        return tuple(fp)
 
     # ---- id / code conversion -------------------------------------------------------------------
     def var_id(self, name):

@@ -1,6 +1,8 @@
 // mibn engine: C-ABI (include/mibn.h) over the planner and the gfx950 kernels.
 // No CPU fallback: every query entry point needs a live HIP device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen'ed by mibn_comm_init, never linked
 
 #include <algorithm>
 #include <atomic>
@@ -69,7 +71,7 @@ struct mibn_ctx {
         size_t items_cap = 0;
         hipEvent_t uploaded = nullptr;       // the copy stream has delivered this set's programs and schedule
         std::vector<hipEvent_t> ev;          // launch boundaries of the waves in flight
-        struct Timed { int kid; size_t e0, e1; double bytes, items; };
+        struct Timed { int kid; size_t e0, e1; double bytes, items; uint64_t call; };
         std::vector<Timed> timed;
         size_t ev_used = 0;
         bool busy = false;
@@ -77,6 +79,24 @@ struct mibn_ctx {
         Schedule sched;
     } set[2];
     Staging res_stage[2];  // pinned landing buffers of asynchronous calls
+    int set_cursor = 0;    // the chunk set the next chunk plans into: alternates across calls, so that a call of one chunk
+                           // plans into the idle set while the previous call's kernels still run from the other one
+    uint64_t call_id = 0;  // kernel time retired later is booked to the call that launched it
+    // RCCL (multi-GPU gather / reduce), loaded on demand
+    struct Comm {
+        void *dl = nullptr;
+        ncclComm_t comm = nullptr;
+        int rank = 0, world = 1;
+        decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+        decltype(&ncclCommInitRank) CommInitRank = nullptr;
+        decltype(&ncclCommDestroy) CommDestroy = nullptr;
+        decltype(&ncclAllGather) AllGather = nullptr;
+        decltype(&ncclReduce) Reduce = nullptr;
+        decltype(&ncclAllReduce) AllReduce = nullptr;
+        decltype(&ncclGetErrorString) GetErrorString = nullptr;
+        void *d_send = nullptr, *d_recv = nullptr;
+        size_t send_cap = 0, recv_cap = 0;
+    } comm;
     std::string err;
     mibn_stats stats{}, total{};               // last call / since creation
     mibn_kernel_stat kstats[kNumKernels + 1];  // per class (split_kinds) + the level kernel as a whole
@@ -147,6 +167,7 @@ void mibn_destroy(mibn_t *h) {
     if (!h->planner_only) {
         (void)hipSetDevice(h->device);
         if (h->stream) (void)hipStreamSynchronize(h->stream);
+        (void)mibn_comm_destroy(h);
         (void)hipFree(h->d_pool);
         (void)hipFree(h->d_arena);
         for (int k = 0; k < 2; ++k) {
@@ -321,6 +342,16 @@ int default_threads() {
     return std::max(1, std::min(64, (int)(cpus / local_world)));
 }
 
+void ensure_pool(mibn_ctx *h) {
+    if (h->pool) return;
+    h->pool = new ThreadPool(h->threads > 0 ? h->threads : default_threads());
+    for (auto &st : h->set) {
+        st.bufs.resize(h->pool->size());
+        if (!h->planner_only)
+            for (auto &b : st.bufs) b.grow = pinned_grow;
+    }
+}
+
 // wait for a set's launches and book their HIP-event durations per kernel
 int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     if (!st.busy) return MIBN_OK;
@@ -328,11 +359,15 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     for (auto &t : st.timed) {
         float ms = 0;
         HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));
-        h->stats.kernel_ms += ms;
-        h->stats.n_launches += 1;
+        const bool mine = t.call == h->call_id;  // (launches of an earlier asynchronous call only count in the totals)
+        if (mine) {
+            h->stats.kernel_ms += ms;
+            h->stats.n_launches += 1;
+        }
         h->total.kernel_ms += ms;
         h->total.n_launches += 1;
         for (mibn_kernel_stat *ks : {&h->kstats[t.kid], &h->ktotal[t.kid]}) {
+            if (ks == &h->kstats[t.kid] && !mine) continue;
             if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", t.kid < kNumKernels ? kernel_name(t.kid) : "ve_level_kernel");
             ks->launches += 1;
             ks->ms += ms;
@@ -364,12 +399,13 @@ namespace {
 // Plan, upload and launch a batch.  Synchronous (ticket == nullptr): waits and writes `out`.  Asynchronous: the
 // results land in a pinned buffer, *ticket identifies the call for mibn_wait; up to two calls may be in flight, so
 // the host plans call s+1 while the GPU still runs call s.
-int run_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
+int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
               const int32_t *e_codes, const int64_t *out_off, double *out, int32_t *ticket) {
     if (!h || B < 0 || !q_off || !e_off || !out_off || (B && !out)) return MIBN_E_ARG;
     if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
     const double t_start = now_ms();
+    ++h->call_id;
     h->stats = mibn_stats{};
     for (int k = 0; k <= kNumKernels; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
@@ -397,13 +433,7 @@ int run_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
             if (c < 0 || c >= h->net.card[rq.evars[i]]) skip[b] = 1;  // label outside the domain -> empty posterior
         }
     }
-    if (!h->pool) {
-        h->pool = new ThreadPool(h->threads > 0 ? h->threads : default_threads());
-        for (auto &st : h->set) {
-            st.bufs.resize(h->pool->size());
-            for (auto &b : st.bufs) b.grow = pinned_grow;
-        }
-    }
+    ensure_pool(h);
     int rc;
     const size_t res_cells = (size_t)(out_off[B] - out_off[0]);
     if ((rc = ensure(h, h->d_results[slot], h->results_cap[slot], res_cells))) return rc;
@@ -417,11 +447,13 @@ int run_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
     for (int64_t b0 = 0, b1 = 0; b0 < B; b0 = b1, ++n_chunks) {
         b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
         const int64_t n = b1 - b0;
-        mibn_ctx::Set &st = h->set[n_chunks & 1];
+        mibn_ctx::Set &st = h->set[h->set_cursor];
+        h->set_cursor ^= 1;
         if ((rc = retire(h, st))) return rc;  // its buffers are about to be rewritten
         double t0 = now_ms();
         BatchPlan &ck = st.plan;
-        plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck);
+        plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck,
+                   (flags & MIBN_Q_NOPRUNE) != 0);
         if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); return MIBN_E_LIMIT; }
         for (auto &b : st.bufs)
             if (b.cap && !b.data) { h->err = "pinned host allocation failed"; return MIBN_E_HIP; }
@@ -501,7 +533,7 @@ int run_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
                 hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, h->stream, A);
                 size_t e_next = 0;
                 if ((rc = next_event(h, st, e_next))) return rc;
-                st.timed.push_back({h->split_kinds ? L.kid : kNumKernels, e_prev, e_next, bytes, (double)grid});
+                st.timed.push_back({h->split_kinds ? L.kid : kNumKernels, e_prev, e_next, bytes, (double)grid, h->call_id});
                 n_wg += (double)grid;
                 e_prev = e_next;
                 li = lj;
@@ -565,14 +597,22 @@ extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, cons
                                 const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
                                 const int64_t *out_off, double *out) {
     if (h && (h->pend[0].active || h->pend[1].active)) { h->err = "asynchronous calls in flight: collect them with mibn_wait first"; return MIBN_E_STATE; }
-    return run_batch(h, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, nullptr);
+    return run_batch(h, 0, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, nullptr);
+}
+
+extern "C" int mibn_query_batch_ex(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                                   const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
+                                   const int64_t *out_off, double *out) {
+    if (h && (h->pend[0].active || h->pend[1].active)) { h->err = "asynchronous calls in flight: collect them with mibn_wait first"; return MIBN_E_STATE; }
+    if (flags & ~(uint32_t)MIBN_Q_NOPRUNE) { if (h) h->err = "unknown query flag"; return MIBN_E_ARG; }
+    return run_batch(h, flags, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, nullptr);
 }
 
 extern "C" int mibn_submit_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
                                  const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,
                                  const int64_t *out_off, double *out, int32_t *ticket) {
     if (!ticket) return MIBN_E_ARG;
-    return run_batch(h, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, ticket);
+    return run_batch(h, 0, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, ticket);
 }
 
 extern "C" int mibn_wait(mibn_t *h, int32_t ticket) {
@@ -626,16 +666,28 @@ extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_
 extern "C" int mibn_gibbs(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
                           const int32_t *e_codes, const int32_t *cycle, int64_t n_chains, int64_t n_iterations,
                           uint64_t seed, int64_t *counts) {
-    if (!h || !q_vars || !counts || n_chains < 1 || n_iterations < 0) return MIBN_E_ARG;
+    return mibn_gibbs_shard(h, n_q, q_vars, n_e, e_vars, e_codes, cycle, 0, n_chains, n_iterations, seed, counts);
+}
+
+extern "C" int mibn_gibbs_shard(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                                const int32_t *e_codes, const int32_t *cycle, int64_t chain_first, int64_t n_chains,
+                                int64_t n_iterations, uint64_t seed, int64_t *counts) {
+    if (!h || !q_vars || !counts || n_chains < 0 || chain_first < 0 || n_iterations < 0) return MIBN_E_ARG;
     if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
     Request rq;
     rq.nq = n_q; rq.qvars = q_vars; rq.ne = n_e; rq.evars = e_vars;
     std::string e = validate_request(h->net, rq);
     if (!e.empty()) { h->err = e; return MIBN_E_ARG; }
+    if (n_chains == 0) {  // an empty shard (more ranks than chains)
+        int64_t cells = 1;
+        for (int k = 0; k < n_q; ++k) cells *= h->net.card[q_vars[k]];
+        for (int64_t c = 0; c < cells; ++c) counts[c] = 0;
+        return MIBN_OK;
+    }
     HIP_TRY(h, hipSetDevice(h->device));
-    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds != 0, n_q, q_vars, n_e, e_vars, e_codes, cycle, n_chains, n_iterations, seed,
-                     counts, h->err, h->stats.kernel_ms);
+    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds != 0, n_q, q_vars, n_e, e_vars, e_codes, cycle, chain_first, n_chains,
+                     n_iterations, seed, counts, h->err, h->stats.kernel_ms);
 }
 
 extern "C" int mibn_sample(mibn_t *h, int64_t n_samples, int32_t n_init, const int32_t *init_vars, const int32_t *init_codes,
@@ -685,4 +737,174 @@ extern "C" int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, cons
     if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
     HIP_TRY(h, hipSetDevice(h->device));
     return count_run(h->stream, n_rows, n_cols, codes, row_major != 0, card, n_tables, scope_off, scope_cols, counts_off, counts, h->err);
+}
+
+extern "C" int mibn_estimate_costs(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off,
+                                   const int32_t *e_vars, double *cost) {
+    if (!h || B < 0 || !q_off || !e_off || (B && (!q_vars || !cost))) return MIBN_E_ARG;
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    ensure_pool(h);
+    estimate_costs(h->net, *h->pool, B, q_off, q_vars, e_off, e_vars, cost);
+    return MIBN_OK;
+}
+
+extern "C" int mibn_device_synchronize(mibn_t *h) {
+    if (!h) return MIBN_E_ARG;
+    if (h->planner_only) return MIBN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    return MIBN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- RCCL
+// One process per GPU; the data path has no collective (independent request / chain shards), these are the final
+// gather / reduce over xGMI.  librccl.so (573 MB) is loaded on the first mibn_comm_* call only.
+namespace {
+
+int comm_load(mibn_ctx *h) {
+    mibn_ctx::Comm &c = h->comm;
+    if (c.dl) return MIBN_OK;
+    const char *env = std::getenv("MIBN_RCCL_LIB");
+    const char *cands[] = {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    for (const char *name : cands) {
+        if (!name || !*name) continue;
+        if ((c.dl = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    }
+    if (!c.dl) { h->err = std::string("cannot load librccl.so: ") + dlerror(); return MIBN_E_COMM; }
+#define MIBN_SYM(field, sym)                                                                  \
+    c.field = reinterpret_cast<decltype(c.field)>(dlsym(c.dl, #sym));                         \
+    if (!c.field) { h->err = "librccl.so lacks " #sym; dlclose(c.dl); c.dl = nullptr; return MIBN_E_COMM; }
+    MIBN_SYM(GetUniqueId, ncclGetUniqueId)
+    MIBN_SYM(CommInitRank, ncclCommInitRank)
+    MIBN_SYM(CommDestroy, ncclCommDestroy)
+    MIBN_SYM(AllGather, ncclAllGather)
+    MIBN_SYM(Reduce, ncclReduce)
+    MIBN_SYM(AllReduce, ncclAllReduce)
+    MIBN_SYM(GetErrorString, ncclGetErrorString)
+#undef MIBN_SYM
+    return MIBN_OK;
+}
+
+#define NCCL_TRY(h, expr)                                                                             \
+    do {                                                                                              \
+        ncclResult_t r_ = (expr);                                                                     \
+        if (r_ != ncclSuccess) {                                                                      \
+            (h)->err = std::string(#expr) + ": " + (h)->comm.GetErrorString(r_);                      \
+            return MIBN_E_COMM;                                                                       \
+        }                                                                                             \
+    } while (0)
+
+int comm_ready(mibn_ctx *h) {
+    if (!h) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound"; return MIBN_E_NODEVICE; }
+    if (!h->comm.comm) { h->err = "mibn_comm_init first"; return MIBN_E_STATE; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return MIBN_OK;
+}
+
+int comm_buf(mibn_ctx *h, void *&ptr, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return MIBN_OK;
+    if (ptr) { HIP_TRY(h, hipFree(ptr)); ptr = nullptr; cap = 0; }
+    HIP_TRY(h, hipMalloc(&ptr, bytes + bytes / 4 + 256));
+    cap = bytes + bytes / 4 + 256;
+    return MIBN_OK;
+}
+
+}  // namespace
+
+extern "C" int mibn_comm_unique_id(mibn_t *h, void *id_out) {
+    if (!h || !id_out) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound"; return MIBN_E_NODEVICE; }
+    int rc;
+    if ((rc = comm_load(h))) return rc;
+    static_assert(sizeof(ncclUniqueId) == MIBN_COMM_ID_BYTES, "RCCL unique id size");
+    ncclUniqueId id;
+    NCCL_TRY(h, h->comm.GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return MIBN_OK;
+}
+
+extern "C" int mibn_comm_init(mibn_t *h, int32_t rank, int32_t world, const void *id_in) {
+    if (!h || !id_in || world < 1 || rank < 0 || rank >= world) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound"; return MIBN_E_NODEVICE; }
+    if (h->comm.comm) { h->err = "communicator already initialised"; return MIBN_E_STATE; }
+    int rc;
+    if ((rc = comm_load(h))) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, sizeof(id));
+    NCCL_TRY(h, h->comm.CommInitRank(&h->comm.comm, world, id, rank));
+    h->comm.rank = rank;
+    h->comm.world = world;
+    return MIBN_OK;
+}
+
+extern "C" int mibn_comm_destroy(mibn_t *h) {
+    if (!h) return MIBN_E_ARG;
+    mibn_ctx::Comm &c = h->comm;
+    if (c.comm) {
+        (void)hipSetDevice(h->device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)c.CommDestroy(c.comm);
+        c.comm = nullptr;
+    }
+    if (c.d_send) { (void)hipFree(c.d_send); c.d_send = nullptr; c.send_cap = 0; }
+    if (c.d_recv) { (void)hipFree(c.d_recv); c.d_recv = nullptr; c.recv_cap = 0; }
+    return MIBN_OK;
+}
+
+extern "C" int mibn_comm_allgather_f64(mibn_t *h, const double *send, int64_t n, double *recv) {
+    int rc;
+    if ((rc = comm_ready(h))) return rc;
+    if (n < 0 || (n && (!send || !recv))) return MIBN_E_ARG;
+    if (n == 0) return MIBN_OK;
+    mibn_ctx::Comm &c = h->comm;
+    const size_t bytes = (size_t)n * 8;
+    if ((rc = comm_buf(h, c.d_send, c.send_cap, bytes))) return rc;
+    if ((rc = comm_buf(h, c.d_recv, c.recv_cap, bytes * (size_t)c.world))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(c.d_send, send, bytes, hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(h, c.AllGather(c.d_send, c.d_recv, (size_t)n, ncclDouble, c.comm, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(recv, c.d_recv, bytes * (size_t)c.world, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MIBN_OK;
+}
+
+extern "C" int mibn_comm_reduce_i64(mibn_t *h, int64_t *buf, int64_t n, int32_t root) {
+    int rc;
+    if ((rc = comm_ready(h))) return rc;
+    mibn_ctx::Comm &c = h->comm;
+    if (n < 0 || (n && !buf) || root < 0 || root >= c.world) return MIBN_E_ARG;
+    if (n == 0) return MIBN_OK;
+    const size_t bytes = (size_t)n * 8;
+    if ((rc = comm_buf(h, c.d_send, c.send_cap, bytes))) return rc;
+    if ((rc = comm_buf(h, c.d_recv, c.recv_cap, bytes))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(c.d_send, buf, bytes, hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(h, c.Reduce(c.d_send, c.d_recv, (size_t)n, ncclInt64, ncclSum, root, c.comm, h->stream));
+    if (c.rank == root) HIP_TRY(h, hipMemcpyAsync(buf, c.d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MIBN_OK;
+}
+
+extern "C" int mibn_comm_allreduce_max_f64(mibn_t *h, double *buf, int64_t n) {
+    int rc;
+    if ((rc = comm_ready(h))) return rc;
+    if (n < 0 || (n && !buf)) return MIBN_E_ARG;
+    if (n == 0) return MIBN_OK;
+    mibn_ctx::Comm &c = h->comm;
+    const size_t bytes = (size_t)n * 8;
+    if ((rc = comm_buf(h, c.d_send, c.send_cap, bytes))) return rc;
+    if ((rc = comm_buf(h, c.d_recv, c.recv_cap, bytes))) return rc;
+    HIP_TRY(h, hipMemcpyAsync(c.d_send, buf, bytes, hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(h, c.AllReduce(c.d_send, c.d_recv, (size_t)n, ncclDouble, ncclMax, c.comm, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(buf, c.d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MIBN_OK;
+}
+
+extern "C" int mibn_comm_barrier(mibn_t *h) {
+    int rc;
+    if ((rc = comm_ready(h))) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());  // this rank's own device work first
+    double one = 1.0;
+    return mibn_comm_allreduce_max_f64(h, &one, 1);
 }

@@ -62,6 +62,7 @@ struct GibbsArgs {
     int32_t n_vars, n_cycle, n_q, hist_cells;
     int32_t pool_cells;           // doubles in `pool` (the LDS-resident variant copies them all)
     int64_t n_chains, n_iterations;
+    int64_t chain_first;          // global index of this launch's first chain (shards of one stream: mibn_gibbs_shard)
     uint64_t seed;
 };
 
@@ -102,8 +103,9 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
     double *lds_pool = (double *)(smem + ((((A.n_vars * 64 + 15) & ~15) + A.hist_cells * 4 + 15) & ~15));
     if (POOL_LDS)
         for (int i = threadIdx.x; i < A.pool_cells; i += blockDim.x) lds_pool[i] = A.pool[i];
-    const int64_t chain = (int64_t)blockIdx.x * 64 + lane;
-    const bool active = chain < A.n_chains;
+    const int64_t local = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t chain = A.chain_first + local;  // the Philox key follows the global index: shards reproduce the whole
+    const bool active = local < A.n_chains;
     for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x) hist[i] = 0;
     const uint32_t k0 = (uint32_t)A.seed ^ (uint32_t)chain * 0x9E3779B1u;
     const uint32_t k1 = (uint32_t)(A.seed >> 32) ^ (uint32_t)(chain >> 32) ^ 0x85EBCA6Bu;
@@ -211,8 +213,8 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
 
 // host driver; returns MIBN_* code
 inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t stream, bool allow_lds, int32_t n_q, const int32_t *q_vars,
-                     int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle_in, int64_t n_chains,
-                     int64_t n_iterations, uint64_t seed, int64_t *counts, std::string &err, double &kernel_ms) {
+                     int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle_in, int64_t chain_first,
+                     int64_t n_chains, int64_t n_iterations, uint64_t seed, int64_t *counts, std::string &err, double &kernel_ms) {
     const int n = net.n_vars;
     std::vector<GibbsVar> vars(n);
     std::vector<int32_t> scope_var, scope_stride, children, cycle;
@@ -322,6 +324,7 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     A.n_q = n_q;
     A.hist_cells = (int32_t)cells;
     A.n_chains = n_chains;
+    A.chain_first = chain_first;
     A.n_iterations = n_iterations;
     A.seed = seed;
     hipEvent_t e0, e1;

@@ -1172,7 +1172,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     rel.nw = qb.nw = eb.nw = net.nw;
     for (int i = 0; i < rq.nq; ++i) { qb.set(rq.qvars[i]); rel.set(rq.qvars[i]); rel.or_(net.anc[rq.qvars[i]]); }
     for (int i = 0; i < rq.ne; ++i) { eb.set(rq.evars[i]); rel.set(rq.evars[i]); rel.or_(net.anc[rq.evars[i]]); }
-    if (!net.prune)  // full_joint_dist / predict_proba multiply *all* CPTs (bayes_net.py:460): with sparse or
+    if (!net.prune || rq.no_prune)  // full_joint_dist / predict_proba multiply *all* CPTs (bayes_net.py:460): with sparse or
         for (int v = 0; v < net.n_vars; ++v) rel.set(v);  // unnormalised CPTs a barren node does not sum to 1
     Bits hidden = rel;
     hidden.andnot(qb);
@@ -1404,6 +1404,71 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     return "";
 }
 
+// ------------------------------------------------------------------------------------ cost estimate
+// Byte model of the cheaper sweep order of one request (no emission, no min-fill search): what mibn_estimate_costs
+// reports for shard balancing.
+static double sweep_cost(const Network &net, const Request &rq) {
+    Scratch &S = scratch();
+    Bits rel, qb, eb;
+    rel.nw = qb.nw = eb.nw = net.nw;
+    for (int i = 0; i < rq.nq; ++i) { qb.set(rq.qvars[i]); rel.set(rq.qvars[i]); rel.or_(net.anc[rq.qvars[i]]); }
+    for (int i = 0; i < rq.ne; ++i) { eb.set(rq.evars[i]); rel.set(rq.evars[i]); rel.or_(net.anc[rq.evars[i]]); }
+    if (!net.prune || rq.no_prune)
+        for (int v = 0; v < net.n_vars; ++v) rel.set(v);
+    Bits hidden = rel;
+    hidden.andnot(qb);
+    hidden.andnot(eb);
+    std::vector<Bits> &scopes = S.scopes;
+    std::vector<double> &scells = S.scope_cells;
+    scopes.clear();
+    scells.clear();
+    rel.for_each([&](int v) {
+        Bits sc;
+        sc.nw = net.nw;
+        double cells = 1;
+        for (int u : net.scope[v])
+            if (!eb.test(u) && net.card[u] > 1) { sc.set(u); cells *= net.card[u]; }
+        scopes.push_back(sc);
+        scells.push_back(cells);
+    });
+    std::vector<int32_t> &hid = S.hid;
+    hid.clear();
+    hidden.for_each([&](int v) { if (net.card[v] > 1) hid.push_back(v); });
+    int qdepth = std::numeric_limits<int>::max();
+    for (int i = 0; i < rq.nq; ++i) qdepth = std::min(qdepth, (int)net.depth[rq.qvars[i]]);
+    std::vector<int32_t> o = hid;
+    std::stable_sort(o.begin(), o.end(), [&](int a, int b) {
+        const double ka = net.depth[a] < qdepth ? (double)net.depth[a] : 1e6 - net.depth[a];
+        const double kb = net.depth[b] < qdepth ? (double)net.depth[b] : 1e6 - net.depth[b];
+        return ka < kb;
+    });
+    double best = simulate(net, scopes, scells, o, std::numeric_limits<double>::infinity());
+    o = hid;
+    std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return net.depth[a] > net.depth[b]; });
+    best = std::min(best, simulate(net, scopes, scells, o, best));
+    return best;
+}
+
+void estimate_costs(const Network &net, ThreadPool &pool, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                    const int64_t *e_off, const int32_t *e_vars, double *cost) {
+    std::atomic<int64_t> next{0};
+    constexpr int64_t kBlock = 256;
+    pool.run([&](int) {
+        for (;;) {
+            const int64_t lo = next.fetch_add(kBlock, std::memory_order_relaxed);
+            if (lo >= B) break;
+            for (int64_t b = lo, hi = std::min(B, lo + kBlock); b < hi; ++b) {
+                Request rq;
+                rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
+                rq.qvars = q_vars + q_off[b];
+                rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
+                rq.evars = e_vars + e_off[b];
+                cost[b] = request_is_valid(net, rq) ? sweep_cost(net, rq) : 0.0;
+            }
+        }
+    });
+}
+
 // ------------------------------------------------------------------------------------ buffers / threads
 
 uint32_t *ProgBuf::extend(size_t words) {
@@ -1619,7 +1684,7 @@ PlanCache &plan_cache(const TemplateStore *ts) {
 
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
-                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck) {
+                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck, bool no_prune) {
     const int64_t n = b1 - b0;
     const int T = pool.size();
     if ((int)bufs.size() < T) bufs.resize(T);
@@ -1665,6 +1730,7 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             rq.evars = e_vars + e_off[b];
             rq.ecodes = e_codes + e_off[b];
             rq.out_off = out_off[b] - out_off[b0];
+            rq.no_prune = no_prune;
             PlanStats st;
             // plan templates (see above): probe at the start of every window, stay on while shapes repeat
             PlanCache *pc = store ? &plan_cache(store) : nullptr;
@@ -1678,6 +1744,7 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             if (use_cache) {
                 std::string &key = pc->key;
                 key.assign(reinterpret_cast<const char *>(&rq.nq), sizeof(rq.nq));
+                key.push_back(no_prune ? 'N' : 'P');
                 key.append(reinterpret_cast<const char *>(rq.qvars), sizeof(int32_t) * (size_t)rq.nq);
                 key.append(reinterpret_cast<const char *>(rq.evars), sizeof(int32_t) * (size_t)rq.ne);
                 TemplateStore::Shard &sh = store->shard[std::hash<std::string>{}(key) % TemplateStore::kShards];

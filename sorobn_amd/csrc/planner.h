@@ -79,6 +79,7 @@ struct Request {
     const int32_t *evars = nullptr;
     const int32_t *ecodes = nullptr;  // may be null for plan-only statistics
     int64_t out_off = 0;              // offset (doubles) into the batch result buffer
+    bool no_prune = false;            // MIBN_Q_NOPRUNE: every CPT takes part (full_joint_dist / predict_proba, bayes_net.py:460)
 };
 
 struct PlanStats {
@@ -206,7 +207,12 @@ struct BatchPlan {
 };
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
-                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &bp);
+                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &bp, bool no_prune = false);
+
+// Shard-balancing estimate (mibn_estimate_costs): section-8(d) bytes of the cheaper of the two sweep orders of every
+// request of a CSR batch - the byte model only, nothing is emitted.
+void estimate_costs(const Network &net, ThreadPool &pool, int64_t B, const int64_t *q_off, const int32_t *q_vars,
+                    const int64_t *e_off, const int32_t *e_vars, double *cost);
 
 // ---------------------------------------------------------------------------------------------------
 // Level-synchronous schedule.  A request's program is cut into *items*: a maximal run of small steps

@@ -84,12 +84,22 @@ class SimEngine:
         else:
             raise KeyError(name)
 
-    def query_fixed(self, qvars, evars, ecodes):
-        return np.stack([self._one(q, e, c) for q, e, c in zip(qvars, evars, ecodes)])
+    def _with_flags(self, flags, fn):
+        """MIBN_Q_NOPRUNE (per call, include/mibn.h): every CPT takes part."""
+        saved = self.prune
+        if flags & 1:
+            self.prune = 0
+        try:
+            return fn()
+        finally:
+            self.prune = saved
 
-    def query_batch(self, q_off, q_vars, e_off, e_vars, e_codes, out_off=None):
-        outs = [self._one(q_vars[a:b], e_vars[c:d], e_codes[c:d])
-                for a, b, c, d in zip(q_off[:-1], q_off[1:], e_off[:-1], e_off[1:])]
+    def query_fixed(self, qvars, evars, ecodes, flags=0):
+        return self._with_flags(flags, lambda: np.stack([self._one(q, e, c) for q, e, c in zip(qvars, evars, ecodes)]))
+
+    def query_batch(self, q_off, q_vars, e_off, e_vars, e_codes, out_off=None, flags=0):
+        outs = self._with_flags(flags, lambda: [self._one(q_vars[a:b], e_vars[c:d], e_codes[c:d])
+                                                for a, b, c, d in zip(q_off[:-1], q_off[1:], e_off[:-1], e_off[1:])])
         off = np.concatenate([[0], np.cumsum([len(o) for o in outs])]).astype(np.int64)
         return (np.concatenate(outs) if outs else np.zeros(0)), off
 

@@ -29,7 +29,7 @@ def _nets(fname):
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "mibn.h")).read()
-    declared = set(re.findall(r"\b(mibn_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mibn_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     L = _capi.lib()
     for s in declared:
