@@ -149,6 +149,12 @@ int mibn_plan_stats(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e,
                     const int32_t *e_vars, mibn_stats *out);
 int mibn_create_planner(mibn_t **out); /* host-only context: set_network/plan_stats work, queries fail */
 
+/* The elimination order the planner executes for one request: order[0 .. *n) = hidden variables, first eliminated
+ * first (`order` must hold n_vars entries).  The reference eliminates in Python-set iteration order (bayes_net.py:766,
+ * 779); tests hand this order to the CPU oracle so that it can answer the wide requests in seconds instead of minutes. */
+int mibn_plan_order(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                    int32_t *order, int32_t *n);
+
 /* Cheap per-request cost estimate for shard balancing ("balance by the planner's bytes_query, not
  * by count - per-request cost varies 1000x"): cost[b] = section-8(d) bytes of the cheaper of the planner's two sweep
  * orders for request b (no program is emitted, no min-fill search; ~2 us per request and planner thread).  Works on a
@@ -218,7 +224,8 @@ int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_v
  *                             the device)
  *   scope_off[n_tables + 1], scope_cols[]   CSR: the columns of table t
  *   counts_off[n_tables + 1], counts[]      dense C-order contingency table of every table (last column fastest);
- *                             a table may have at most 16384 cells
+ *                             tables of up to 16384 cells are counted in LDS histograms, larger ones (up to 2^28
+ *                             cells) with global atomics
  */
 int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *codes, int32_t row_major, const int32_t *card,
                       int32_t n_tables, const int64_t *scope_off, const int32_t *scope_cols, const int64_t *counts_off,

@@ -83,6 +83,8 @@ def load(which="auto"):
     if "sorobn" in sys.modules and getattr(sys.modules["sorobn"], "_mibn_refload", None):
         return sys.modules["sorobn"]
     if which == "auto":
+        which = os.environ.get("MIBN_REFLOAD", "auto")  # "build": behave like the GPU box, where only oracle/_ref exists
+    if which == "auto":
         which = "source" if source_available() else "build"
     if which == "source" and not source_available():
         raise RuntimeError("reference not mounted at /root/reference")

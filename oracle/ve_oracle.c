@@ -194,13 +194,29 @@ static int sum_out(const int32_t *card, const factor *in, int32_t x, factor *out
     if (px < 0) return VE_ERR_ARG;
     int nv = in->nv - 1;
     int pos[VE_MAX_SCOPE];
-    int64_t keyspace = 1;
+    /* group keys: mixed radix over the code range every remaining level actually takes in this table (an evidence level
+     * holds a single value, bayes_net.py:772-774, and would otherwise multiply the key space by its full cardinality).
+     * The mapping is monotone per level, so the groups still come out sorted by their level codes. */
+    int lo[VE_MAX_SCOPE], radix[VE_MAX_SCOPE];
     for (int i = 0, k = 0; i < in->nv; ++i)
-        if (i != px) {
-            pos[k++] = i;
-            keyspace *= card[in->vars[i]];
-            if (keyspace > ((int64_t)1 << 29)) return VE_ERR_KEYSPACE;
+        if (i != px) pos[k++] = i;
+    for (int k = 0; k < nv; ++k) {
+        int mn = 255, mx = 0;
+        for (int64_t i = 0; i < in->n; ++i) {
+            const int c = in->codes[i * in->nv + pos[k]];
+            if (c < mn) mn = c;
+            if (c > mx) mx = c;
         }
+        if (in->n == 0) mn = mx = 0;
+        lo[k] = mn;
+        radix[k] = mx - mn + 1;
+    }
+    int64_t keyspace = 1;
+    for (int k = 0; k < nv; ++k) {
+        keyspace *= radix[k];
+        if (keyspace > ((int64_t)1 << 29)) return VE_ERR_KEYSPACE;
+    }
+    (void)card;
     double *sum = (double *)calloc((size_t)keyspace, sizeof(double));
     double *comp = (double *)calloc((size_t)keyspace, sizeof(double));
     uint8_t *seen = (uint8_t *)calloc((size_t)keyspace, 1);
@@ -209,7 +225,7 @@ static int sum_out(const int32_t *card, const factor *in, int32_t x, factor *out
     for (int64_t i = 0; i < in->n; ++i) {
         int64_t key = 0;
         for (int k = 0; k < nv; ++k)
-            key = key * card[in->vars[pos[k]]] + in->codes[i * in->nv + pos[k]];
+            key = key * radix[k] + (in->codes[i * in->nv + pos[k]] - lo[k]);
         if (!seen[key]) {
             seen[key] = 1;
             ++groups;
@@ -226,9 +242,8 @@ static int sum_out(const int32_t *card, const factor *in, int32_t x, factor *out
         if (seen[key]) {
             int64_t r = key;
             for (int k = nv - 1; k >= 0; --k) {
-                int c = card[out->vars[k]];
-                out->codes[o * nv + k] = (uint8_t)(r % c);
-                r /= c;
+                out->codes[o * nv + k] = (uint8_t)(lo[k] + r % radix[k]);
+                r /= radix[k];
             }
             out->vals[o++] = sum[key];
         }

@@ -18,7 +18,7 @@ SYMBOLS = [
     "mibn_plan_stats", "mibn_create_planner", "mibn_set_option", "mibn_gibbs",
     "mibn_last_kernel_stats", "mibn_submit_batch", "mibn_wait", "mibn_drain", "mibn_total_stats",
     "mibn_total_kernel_stats", "mibn_sample", "mibn_sampling_query", "mibn_count_tables",
-    "mibn_query_batch_ex", "mibn_estimate_costs", "mibn_device_synchronize", "mibn_gibbs_shard",
+    "mibn_query_batch_ex", "mibn_plan_order", "mibn_estimate_costs", "mibn_device_synchronize", "mibn_gibbs_shard",
     "mibn_comm_unique_id", "mibn_comm_init", "mibn_comm_destroy", "mibn_comm_allgather_f64",
     "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier",
 ]
@@ -74,6 +74,7 @@ def lib():
         L.mibn_set_order_hints.argtypes = [vp, C.c_int32, i32p]
         L.mibn_query_batch.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p]
         L.mibn_query_batch_ex.argtypes = [vp, C.c_uint32, C.c_int64, i64p, i32p, i64p, i32p, i32p, i64p, f64p]
+        L.mibn_plan_order.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, i32p, i32p]
         L.mibn_estimate_costs.argtypes = [vp, C.c_int64, i64p, i32p, i64p, i32p, f64p]
         L.mibn_device_synchronize.argtypes = [vp]
         L.mibn_gibbs_shard.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, i32p, i32p, C.c_int64, C.c_int64,
@@ -273,6 +274,16 @@ class Engine:
         self._check(self._L.mibn_plan_stats(self._h, len(q), _p(q, C.c_int32), len(e),
                                             _p(e_, C.c_int32), C.byref(s)))
         return s.as_dict()
+
+    def plan_order(self, qvars, evars):
+        """The elimination order the planner executes for this request (hidden variables, first eliminated first)."""
+        q, e = _i32(qvars), _i32(evars)
+        e_ = e if len(e) else np.zeros(1, np.int32)
+        order = np.zeros(len(self.card), np.int32)
+        n = C.c_int32(0)
+        self._check(self._L.mibn_plan_order(self._h, len(q), _p(q, C.c_int32), len(e), _p(e_, C.c_int32),
+                                            _p(order, C.c_int32), C.byref(n)))
+        return order[:n.value].copy()
 
     def gibbs(self, qvars, evars, ecodes, n_chains, n_iterations, seed=0, cycle=None, chain_first=0):
         """Histogram of chains [chain_first, chain_first + n_chains) of stream `seed` (mibn_gibbs_shard)."""

@@ -503,20 +503,24 @@ class BayesNet:
         return learning.fit(self, X)
 
 
-def accelerate(bn, device=None):
+def accelerate(bn, device=None, backend_factory=None):
     """Attach the MI355X backend to an existing *reference* `sorobn.BayesNet` instance.
 
     Replaces the two bound methods `BayesNet.query` dispatches to - `_variable_elimination`
     (bayes_net.py:848) and `_gibbs_sampling` (851-853) - and leaves `query`'s own post-processing
     (869-875) and `impute` (877-908) untouched, so naming / sorting stay byte-identical; also replaces
     `full_joint_dist` (398-465), on which the reference's `predict_proba` / `predict_log_proba` build.
+
+    `backend_factory(bn) -> Backend` is a test seam (the GPU-less build container injects the CPU plan simulator of
+    tests/simengine.py); the default builds the HIP backend and raises without a gfx950 device.
     """
     state = {"backend": None}
+    make = backend_factory or (lambda b: Backend(b, device=device))
 
     def backend():
         b = state["backend"]
         if b is None or b.fingerprint != Backend.fingerprint_of(bn):
-            b = state["backend"] = Backend(bn, device=device)
+            b = state["backend"] = make(bn)
         return b
 
     def _variable_elimination(self, *query, event):

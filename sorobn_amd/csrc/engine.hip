@@ -739,6 +739,25 @@ extern "C" int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, cons
     return count_run(h->stream, n_rows, n_cols, codes, row_major != 0, card, n_tables, scope_off, scope_cols, counts_off, counts, h->err);
 }
 
+extern "C" int mibn_plan_order(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
+                               int32_t *order, int32_t *n) {
+    if (!h || !order || !n) return MIBN_E_ARG;
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    Request rq;
+    rq.nq = n_q; rq.qvars = q_vars; rq.ne = n_e; rq.evars = e_vars;
+    std::string e = validate_request(h->net, rq);
+    if (!e.empty()) { h->err = e; return MIBN_E_ARG; }
+    std::vector<uint32_t> prog;
+    std::vector<int32_t> ord;
+    PlanStats st;
+    st.order = &ord;
+    e = plan_request(h->net, rq, prog, st);
+    if (!e.empty()) { h->err = e; return MIBN_E_LIMIT; }
+    *n = (int32_t)ord.size();
+    std::copy(ord.begin(), ord.end(), order);
+    return MIBN_OK;
+}
+
 extern "C" int mibn_estimate_costs(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off,
                                    const int32_t *e_vars, double *cost) {
     if (!h || B < 0 || !q_off || !e_off || (B && (!q_vars || !cost))) return MIBN_E_ARG;

@@ -1259,6 +1259,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     }
 
     PROF(4);
+    if (st.order) *st.order = best;
     S.key.assign(net.n_vars, 0.0);
     S.pos.assign(net.n_vars, -1);
     Emitter em{net, prog, st, Arena{}, S.key, S.pos, "", rec};

@@ -86,6 +86,7 @@ struct PlanStats {
     double alg_bytes = 0, alg_flops = 0, n_steps = 0, max_step_cells = 0;
     int64_t arena_cells = 0;  // scratch cells this request needs in its arena slot
     int64_t out_cells = 0;
+    std::vector<int32_t> *order = nullptr;  // optional: receives the elimination order the plan executes (mibn_plan_order)
 };
 
 // Step program encoding (uint32 words), consumed by ve_kernel.hip.h and oracle/plan_sim.cpp:

@@ -506,10 +506,20 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
                 const int ha = uni(sh_hoff[2][hh]), hb = uni(sh_hoff[3][hh]);
                 if (hh == 0 || ha != prev_a) { fetch(0, ha, (uint32_t)lane_off[2], av); prev_a = ha; }
                 if (hh == 0 || hb != prev_b) { fetch(NBIG - 1, hb, (uint32_t)lane_off[3], bv); prev_b = hb; }
-                double f[1][CX ? CX : 1];
+                if constexpr (NCT == 1) {
+                    // one output per cell: reduce the product of the two tables directly (a third 16-double array
+                    // next to av / bv made the allocator spill)
+                    const double *__restrict__ Tp = shT + (uni(sh_hoff[1][hh]) + lo_t);
+                    double s = 0.0;
 #pragma unroll
-                for (int x = 0; x < 16; ++x) f[0][x % (CX ? CX : 1)] = av[x] * bv[x];
-                finish(hh, f);
+                    for (int x = 0; x < 16; ++x) s += (av[x] * bv[x]) * Tp[x];
+                    if (active) outp[uni(sh_hoff[0][hh]) + lo_o] = s;
+                } else {
+                    double f[1][CX ? CX : 1];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) f[0][x % (CX ? CX : 1)] = av[x] * bv[x];
+                    finish(hh, f);
+                }
             }
         } else {
             double fa[U][CX ? CX : 1];
@@ -768,20 +778,21 @@ __device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__re
     const int lrow = lane & 15, lk = lane >> 4;
     const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);
     uint32_t la[4];
-    int tb[4], t3b[4], oc[4][4];
+    int tb[4], t3b[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);
         la[rb] = (uint32_t)(sh_cell[c] + lk * bxs1);
         tb[rb] = sh_cell[2 * kWG + wave * 64 + rs * rb] + lrow + 16 * lk;
         t3b[rb] = T12 + sh_cell[kWG + wave * 64 + rs * rb] + (n12dep ? 16 * lrow : 0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int i = lk + 4 * v;
-            const int cell = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
-            oc[rb][v] = cell < d.lo_cells ? sh_cell[3 * kWG + cell] + lrow : -1;
-        }
     }
+    // output offset of accumulator element v of row block rb: the lane block of a CHAIN step is contiguous in the output
+    // (cell l at 64 * l, emit_chain_as), so the 16 offsets are arithmetic in (rb, v) and need no registers
+    const int lo_cells = d.lo_cells;
+    auto out_cell = [&](const int rb, const int v) {
+        const int i = lk + 4 * v;
+        return wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
+    };
     // two load buffers: the 16 loads of the next row block are issued before the MFMAs of the current one
     double fa[4][4], fb[4][4];  // [x3][ks]
     auto issue = [&](const int hh, const int rb, double (&dst)[4][4]) {
@@ -817,8 +828,10 @@ __device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__re
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (oc[rb][v] >= 0) outp[ho + oc[rb][v] + 16 * (2 * half + e)] = o[e][v];  // 16 lanes = one full 128-byte line
+                for (int v = 0; v < 4; ++v) {
+                    const int cell = out_cell(rb, v);
+                    if (cell < lo_cells) outp[ho + 64 * cell + lrow + 16 * (2 * half + e)] = o[e][v];  // 16 lanes = one full 128-byte line
+                }
         }
     };
     issue(0, 0, fa);
@@ -848,6 +861,9 @@ __device__ __forceinline__ void normalise(double *__restrict__ p, int n, double 
     __syncthreads();
 }
 
+#ifndef MIBN_PATHS
+#define MIBN_PATHS 0xff  // build-time experiment hook: which families of tile code are compiled in (register / spill reports per family)
+#endif
 #define MIBN_FIBER_CASES(NB, C)                                                                        \
     case (NB - 1) * 18 + C * 6 + 0: fiber_call<NB, C, 0>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
     case (NB - 1) * 18 + C * 6 + 1: fiber_call<NB, C, 1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break; \
@@ -877,7 +893,7 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
             __syncthreads();  // previous step's stores are done and visible to the workgroup; sh_step reusable
             for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
             __syncthreads();
-            generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, 0, (int)sh_step[3]);
+            if constexpr (MIBN_PATHS & 64) generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, 0, (int)sh_step[3]);
             if ((sh_step[1] >> 16) & kFlagFinal) {
                 const uint64_t out_off = (uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32);
                 normalise(A.results + out_off, (int)(sh_step[2] * sh_step[3]), sh_red, tid);
@@ -893,7 +909,7 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
     const int h0 = (int)((wg - it.b) * it.a);
     const int h1 = min((int)sh_step[3], h0 + (int)it.a);
     if ((sh_step[0] & 0xff) == kKindFiber && ((sh_step[1] >> 16) & kFlagChain)) {
-        chain_mfma_call(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1);
+        if constexpr (MIBN_PATHS & 1) chain_mfma_call(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1);
     } else if ((sh_step[0] & 0xff) == kKindFiber) {
         const int cx = (int)(sh_step[1] & 0xffff), c1 = (int)(sh_step[8] >> 16), NC = (int)(sh_step[7] >> 16);
         const bool contig = ((sh_step[1] >> 16) & kFlagContig) != 0;
@@ -902,19 +918,29 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
         const bool outer = ((sh_step[1] >> 16) & kFlagOuter) != 0;
         const int ncc = outer ? 5 : (NC == 1 ? 0 : ((NC == 4 && contig) ? 1 : ((NC == 16 && mfma) ? 4 : ((NC == 16 && contig) ? 2 : 3))));
         switch (((int)(sh_step[7] & 0xf) - 1) * 18 + cxc * 6 + ncc) {
+#if MIBN_PATHS & 2
             MIBN_FIBER_CASES(1, 0)
             MIBN_FIBER_CASES(1, 1)
             MIBN_FIBER_CASES(1, 2)
+#endif
+#if MIBN_PATHS & 4
             MIBN_FIBER_CASES(2, 0)
             MIBN_FIBER_CASES(2, 1)
             MIBN_FIBER_CASES(2, 2)
+#endif
+#if MIBN_PATHS & 8
             MIBN_MFMA_CASES(1)
+#endif
+#if MIBN_PATHS & 16
             MIBN_MFMA_CASES(2)
+#endif
+#if MIBN_PATHS & 32
             case 18 + 0 * 6 + 5: outer_mfma_call<1>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
             case 18 + 1 * 6 + 5: outer_mfma_call<4>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1); break;
+#endif
         }
     } else {
-        generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);
+        if constexpr (MIBN_PATHS & 64) generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);
     }
 }
 #undef MIBN_FIBER_CASES

@@ -26,30 +26,48 @@ def counting_engine(device=None):
 
 
 def encode_columns(X, columns):
-    """Label columns -> (uint8 codes [n_rows, n_cols], sorted label domains).  More than 256 labels per column is
-    outside what the count kernel (and any CPT one would learn) handles."""
+    """Label columns -> (uint8 codes [n_rows, n_cols], sorted label domains, cards).  Missing values (NaN / None / NaT)
+    are NOT labels: pandas' `groupby(...).size()` and `value_counts()` drop them (dropna=True), so they get the extra
+    code len(domain) - `cards[j]` is then len(domain) + 1 - and `count_tables_dropna` cuts that slice off every table.
+    More than 256 codes per column is outside what the count kernel (and any CPT one would learn) handles."""
     codes = np.empty((len(columns), len(X)), np.uint8)  # filled column by column: column-major, as the count kernel reads it
-    domains = []
+    domains, cards = [], []
     for j, c in enumerate(columns):
         v = X[c].to_numpy()
         col = dom = None
-        if v.dtype.kind in "iub" and len(v):  # small integer range: a lookup table instead of hashing
+        has_na = False
+        if v.dtype.kind in "iub" and len(v):  # small integer range: a lookup table instead of hashing (no NA possible)
             iv = v.view(np.uint8) if v.dtype.kind == "b" else v
             lo, hi = int(iv.min()), int(iv.max())
             if hi - lo < (1 << 16):
-                shifted = iv - iv.dtype.type(lo) if lo else iv
+                shifted = iv.astype(np.int64) - lo  # (in int64: narrow signed dtypes would wrap, e.g. int8 100 - (-100))
                 present = np.zeros(hi - lo + 1, bool)
                 present[shifted] = True
                 dom = (np.flatnonzero(present) + lo).astype(v.dtype)
                 if len(dom) <= 256:
                     col = (np.cumsum(present) - 1).astype(np.uint8)[shifted]
         if col is None:
-            col, dom = pd.factorize(v, sort=True, use_na_sentinel=False)  # one hash pass per column
-        if len(dom) > 256:
+            col, dom = pd.factorize(v, sort=True, use_na_sentinel=True)  # one hash pass per column; NA -> -1
+            has_na = bool((col < 0).any())
+            if has_na:
+                col = np.where(col < 0, len(dom), col)
+        if len(dom) + int(has_na) > 256:
             raise ValueError(f"column {c!r} has {len(dom)} distinct labels (max 256)")
         codes[j] = col
         domains.append(pd.Index(dom, name=c))
-    return codes.T, domains
+        cards.append(len(dom) + int(has_na))
+    return codes.T, domains, cards
+
+
+def count_tables_dropna(engine, codes, domains, cards, tables):
+    """Dense contingency tables over the *labels*: rows with a missing value in any of a table's columns are dropped
+    (the NA slice, where a column has one, is cut off) - pandas' dropna=True."""
+    dense = engine.count_tables(codes, cards, tables)
+    out = []
+    for d, t in zip(dense, tables):
+        cut = tuple(slice(0, len(domains[c])) for c in t)
+        out.append(np.ascontiguousarray(d[cut]) if any(cards[c] != len(domains[c]) for c in t) else d)
+    return out
 
 
 def count_series(counts, domains, names):
@@ -67,10 +85,9 @@ def count_series(counts, domains, names):
 def grouped_counts(X, tables, device=None):
     """`tables`: list of column-name tuples -> list of `X.groupby(list(t)).size()`-like Series, one GPU launch."""
     columns = sorted({c for t in tables for c in t}, key=list(X.columns).index)
-    codes, domains = encode_columns(X, columns)
+    codes, domains, cards = encode_columns(X, columns)
     pos = {c: j for j, c in enumerate(columns)}
-    card = [len(d) for d in domains]
-    dense = counting_engine(device).count_tables(codes, card, [tuple(pos[c] for c in t) for t in tables])
+    dense = count_tables_dropna(counting_engine(device), codes, domains, cards, [tuple(pos[c] for c in t) for t in tables])
     return [count_series(d, [domains[pos[c]] for c in t], list(t)) for d, t in zip(dense, tables)]
 
 
@@ -114,12 +131,13 @@ def fit(bn, X):
 def mutual_information(X, device=None):
     """All pairwise mutual informations (structure.py:33-45, 55-63) from one counting launch: {(u, v): mi} for u < v."""
     cols = sorted(X.columns)
-    codes, domains = encode_columns(X, cols)
-    card = [len(d) for d in domains]
+    codes, domains, cards = encode_columns(X, cols)
     pairs = list(itertools.combinations(range(len(cols)), 2))
-    dense = counting_engine(device).count_tables(codes, card, [(j,) for j in range(len(cols))] + pairs)
+    dense = count_tables_dropna(counting_engine(device), codes, domains, cards, [(j,) for j in range(len(cols))] + pairs)
     n = float(len(X))
-    marg = [d / n for d in dense[:len(cols)]]
+    # value_counts(normalize=True) divides by the non-missing rows of the column, groupby().size() / len(X) by all rows
+    # (structure.py:33-41)
+    marg = [d / float(d.sum()) if d.sum() else d.astype(np.float64) for d in dense[:len(cols)]]
     out = {}
 
     def one(i, j, c):
@@ -154,7 +172,9 @@ def mutual_information(X, device=None):
 def chow_liu(X, root=None, device=None):
     """structure.chow_liu (structure.py:9-52): maximum spanning tree of the mutual-information graph (Kruskal with a
     union-find over the edges in descending MI order, ties in sorted-pair order like the reference's stable sort),
-    oriented away from `root` (default: the first column).  Returns (parent, child) tuples."""
+    oriented away from `root` (default: the first column).  Returns (parent, child) tuples.  Like the reference's
+    `kruskal` (structure.py:108-117) the scan stops as soon as every vertex has a neighbour - which can be before the
+    components are joined: the result is then the part of that forest reachable from `root`."""
     mi = mutual_information(X, device=device)
     ranked = sorted(mi, key=lambda e: mi[e], reverse=True)  # stable: equal MI keeps combinations() order
     leader = {v: v for v in X.columns}
@@ -167,15 +187,19 @@ def chow_liu(X, root=None, device=None):
 
     size = {v: 1 for v in X.columns}
     adj = {v: [] for v in X.columns}
+    touched = 0  # vertices with at least one neighbour
     for u, v in ranked:
         a, b = find(u), find(v)
         if a != b:
+            touched += (not adj[u]) + (not adj[v])
             adj[u].append(v)
             adj[v].append(u)
             if size[a] < size[b]:
                 a, b = b, a
             leader[b] = a
             size[a] += size[b]
+        if touched == len(X.columns):  # structure.py:116-117
+            break
     root = X.columns[0] if root is None else root
     edges, stack, seen = [], [root], {root}
     while stack:

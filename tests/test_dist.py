@@ -4,7 +4,9 @@ import os
 import subprocess
 import sys
 
-from sorobn_amd.sharding import shard_range
+import numpy as np
+
+from sorobn_amd.sharding import cost_balanced_ranges, exchange_id, imbalance, shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -17,6 +19,43 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
             sizes = [hi - lo for lo, hi in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_cost_balanced_ranges():
+    rng = np.random.default_rng(0)
+    for n, world in ((0, 4), (1, 4), (3, 8), (1000, 2), (1000, 8), (32768, 8)):
+        cost = rng.lognormal(0.0, 2.0, n)  # request costs vary ~1000x
+        rg = cost_balanced_ranges(cost, world)
+        assert len(rg) == world and rg[0][0] == 0 and rg[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(rg, rg[1:])) and all(lo <= hi for lo, hi in rg)
+        if n >= 1000:
+            count = [shard_range(n, world, r) for r in range(world)]
+            assert imbalance(cost, rg) <= imbalance(cost, count) + 1e-12
+            assert imbalance(cost, rg) < 1.0 + 4 * cost.max() / (cost.sum() / world)
+    # one dominant request: it gets a shard of its own
+    cost = np.ones(100)
+    cost[40] = 1000.0
+    rg = cost_balanced_ranges(cost, 4)
+    assert any(lo <= 40 < hi and hi - lo <= 2 for lo, hi in rg), rg
+    assert cost_balanced_ranges(np.zeros(10), 2) == [shard_range(10, 2, r) for r in range(2)]
+
+
+def test_rccl_id_exchange_through_a_file(tmp_path):
+    """The out-of-band leg of mibn_comm_init: rank 0 publishes the 128-byte id atomically, the other ranks of the node
+    wait for it (here: a second process that starts waiting before the file exists)."""
+    path = str(tmp_path / "id")
+    waiter = subprocess.Popen([sys.executable, "-c", (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from sorobn_amd.sharding import exchange_id\n"
+        "uid, _ = exchange_id(1, 2, None, path=%r, timeout_s=60)\n"
+        "sys.stdout.write(uid.hex())") % (ROOT, path)], stdout=subprocess.PIPE, text=True)
+    import time
+    time.sleep(0.5)
+    uid = bytes(range(128))
+    got, _ = exchange_id(0, 2, lambda: uid, path=path)
+    assert got == uid
+    out, _ = waiter.communicate(timeout=60)
+    assert waiter.returncode == 0 and bytes.fromhex(out) == uid
 
 
 def test_two_rank_gloo_gather(tmp_path):

@@ -559,27 +559,137 @@ def test_backend_rebuilds_when_cpts_change(asia):
     assert asia.query("Lung cancer", event={"Smoker": True}).to_numpy() == pytest.approx([0.8, 0.2])
 
 
-@pytest.mark.skipif(not os.path.isdir("/root/reference/sorobn"), reason="reference only exists in the build container")
-def test_strict_series_equality_against_the_live_reference():
-    """In the build container the unmodified reference is importable: compare whole Series objects
-    (values, dtype, index type/dtype/names, name) with pandas' strict checker."""
+def _random_requests(ref, name, n, seed=3):
+    nodes = list(ref.nodes)
+    dom = netspec.domains(netspec.dump(ref, name))
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        perm = rng.permutation(len(nodes))
+        nq = int(rng.integers(1, 3))
+        ne = int(rng.integers(0, 3))
+        q = [nodes[i] for i in perm[:nq]]
+        ev = {nodes[i]: dom[nodes[i]][int(rng.integers(0, len(dom[nodes[i]])))] for i in perm[nq:nq + ne]}
+        yield q, ev
+
+
+def _reference_or_skip():
     from oracle import refload
-    ref_mod = refload.load()
+    if not refload.available():
+        pytest.skip("neither /root/reference nor oracle/_ref (make -C oracle _ref) is present")
+    return refload.load()
+
+
+def test_strict_series_equality_against_the_live_reference():
+    """The unmodified reference is importable (sources in the build container, oracle/_ref elsewhere): compare whole
+    Series objects (values, dtype, index type/dtype/names, name) with pandas' strict checker - `sorobn_amd.BayesNet`
+    built from the same CPTs, answering through the CPU plan simulator."""
+    ref_mod = _reference_or_skip()
     for mk in ("alarm", "asia", "sprinkler", "grades"):
         ref = getattr(ref_mod.examples, mk)()
         mine = simengine.attach(netspec.build(netspec.dump(ref, mk), sorobn_amd.BayesNet))
-        acc = sorobn_amd.accelerate(getattr(ref_mod.examples, mk)())  # reference object + our backend
-        acc._mibn_backend = None
-        nodes = list(ref.nodes)
-        dom = netspec.domains(netspec.dump(ref, mk))
-        rng = np.random.default_rng(3)
-        for _ in range(40):
-            perm = rng.permutation(len(nodes))
-            nq = int(rng.integers(1, 3))
-            ne = int(rng.integers(0, 3))
-            q = [nodes[i] for i in perm[:nq]]
-            ev = {nodes[i]: dom[nodes[i]][int(rng.integers(0, len(dom[nodes[i]])))] for i in perm[nq:nq + ne]}
+        for q, ev in _random_requests(ref, mk, 40):
             want = ref.query(*q, event=ev)
             got = mine.query(*q, event=ev)
             pd.testing.assert_series_equal(got, want, rtol=0, atol=1e-12, check_exact=False)
             assert type(got.index) is type(want.index) and got.index.dtype == want.index.dtype
+
+
+def check_accelerated_reference_object(ref_mod, backend_factory):
+    """The drop-in proper: `accelerate(ref_bn)` rebinds `_variable_elimination` / `_gibbs_sampling` / `full_joint_dist`
+    of a LIVE reference object (bayes_net.py:848, 851-853, 398); its own `query` (796-875), `impute` (877-908) and
+    `predict_proba` (934-962) then run unmodified on top of our backend and must return what the untouched reference
+    returns.  Shared by the CPU test below (plan simulator) and the `-m gpu` test (HIP backend, reference from
+    oracle/_ref)."""
+    calls = {"n": 0}
+    for mk in ("alarm", "asia", "sprinkler", "grades"):
+        ref = getattr(ref_mod.examples, mk)()
+        acc = sorobn_amd.accelerate(getattr(ref_mod.examples, mk)(), backend_factory=backend_factory)
+        assert type(acc) is ref_mod.BayesNet
+        inner = acc._variable_elimination
+
+        def counted(*q, event, _inner=inner):
+            calls["n"] += 1
+            return _inner(*q, event=event)
+
+        acc._variable_elimination = counted
+        for q, ev in _random_requests(ref, mk, 40, seed=11):
+            want = ref.query(*q, event=ev)
+            before = calls["n"]
+            got = acc.query(*q, event=ev)          # the reference's own query() on top of our backend
+            assert calls["n"] == before + 1
+            pd.testing.assert_series_equal(got, want, rtol=0, atol=1e-12, check_exact=False)
+            assert type(got.index) is type(want.index) and got.index.dtype == want.index.dtype
+        # impute (README.md:278-293 and friends): >= 2 missing variables - with one the reference itself fails (SURVEY 3.2)
+        nodes = list(ref.nodes)
+        rng = np.random.default_rng(5)
+        for _ in range(10):
+            perm = rng.permutation(len(nodes))
+            sample = ref.sample()
+            sample = {k: (None if k in {nodes[i] for i in perm[:2]} else sample[k]) for k in nodes}
+            want = ref.impute(dict(sample))
+            post = ref.query(*[k for k, v in sample.items() if v is None], event={k: v for k, v in sample.items() if v is not None})
+            top = np.sort(post.to_numpy())[::-1]
+            if len(top) > 1 and top[0] - top[1] < 1e-9:
+                continue  # an exact tie of the arg-max is resolved by last-bit rounding in the reference itself
+            got = acc.impute(dict(sample))
+            pd.testing.assert_series_equal(got, want)
+        # full_joint_dist / predict_proba of the reference object ride on the replaced full_joint_dist
+        pd.testing.assert_series_equal(acc.full_joint_dist(), ref.full_joint_dist(), rtol=0, atol=1e-12, check_exact=False)
+        X = ref.sample(6)
+        pd.testing.assert_series_equal(acc.predict_proba(X), ref.predict_proba(X), rtol=0, atol=1e-12, check_exact=False)
+    assert calls["n"] >= 160
+
+
+def test_accelerate_live_reference_object_query_and_impute():
+    ref_mod = _reference_or_skip()
+    check_accelerated_reference_object(ref_mod, simengine.sim_backend)
+
+
+def test_in_place_cpt_edit_reaches_the_backend():
+    """the reference re-reads `P` on every query (bayes_net.py:770); an in-place edit of a CPT value must
+    not be answered from stale device tables - the backend fingerprint covers the CPT *contents*."""
+    spec = next(n for n in _nets("examples.json") if n["spec"]["name"] == "asia")["spec"]
+    bn = netspec.build(spec, sorobn_amd.BayesNet)
+    acc = sorobn_amd.accelerate(bn, backend_factory=simengine.sim_backend)
+    ev = {"Smoker": True}
+    before = acc._variable_elimination("Lung cancer", event=ev).to_numpy().copy()
+    fp = sorobn_amd.Backend.fingerprint_of(bn)
+    bn.P["Smoker"].iloc[0] += 0.0
+    assert sorobn_amd.Backend.fingerprint_of(bn) == fp          # unchanged content: no rebuild
+    bn.P["Lung cancer"].iloc[:] = bn.P["Lung cancer"].to_numpy()[::-1].copy()  # in place: same Series object, same index
+    assert sorobn_amd.Backend.fingerprint_of(bn) != fp
+    after = acc._variable_elimination("Lung cancer", event=ev).to_numpy()
+    assert not np.allclose(before, after)
+    fresh = simengine.sim_backend(bn).variable_elimination("Lung cancer", event=ev).to_numpy()
+    assert np.array_equal(after, fresh)
+
+
+def test_heavy_c3_requests_simulator_vs_oracle():
+    """CPU twin of tests/test_gpu_parity.py::test_c3_heavy_requests_vs_oracle (two requests): 60-120 MB plans of the C3
+    stream - CHAIN / pair / OUTER steps over 4^10-cell frontiers - executed by the plan simulator against the C oracle,
+    which eliminates in the planner's own order (mibn_plan_order) to finish in seconds."""
+    from oracle.oracle import OracleNet
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, sorobn_amd.BayesNet)
+    f = flatten(bn)
+    eng = _capi.Engine(planner_only=True)
+    eng.set_network(f.card, f.scope_off, f.scope_vars, f.value_off, f.values)
+    if f.hints:
+        eng.set_order_hints(np.stack(f.hints))
+    q, ev, ec = netspec.c3_requests(100, 4, 1024, 4, seed=1)
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
+    cost = eng.estimate_costs(to_var[q][:, None], to_var[ev])
+    heavy = [int(i) for i in np.argsort(-cost) if 5e7 < eng.plan_stats([to_var[q[i]]], to_var[ev[i]])["alg_bytes"] < 1.2e8][:2]
+    assert len(heavy) == 2
+    on = OracleNet(spec)
+    oid = np.array([on.id[f"{i:03d}"] for i in range(100)], np.int32)
+    var_to_stream = np.argsort(to_var)
+    sim = simengine.SimEngine(f)
+    for i in heavy:
+        order = eng.plan_order([to_var[q[i]]], to_var[ev[i]])
+        assert len(set(order.tolist())) == len(order) and to_var[q[i]] not in order
+        prio = np.full(100, 1 << 20, np.int32)
+        prio[oid[var_to_stream[order]]] = np.arange(len(order), dtype=np.int32)
+        codes, vals = on.query_codes([int(oid[q[i]])], oid[ev[i]].tolist(), ec[i].tolist(), order=prio)
+        got = sim._one([to_var[q[i]]], to_var[ev[i]], ec[i])
+        assert float(np.max(np.abs(got[codes[:, 0]] - vals))) <= gu.TOL
