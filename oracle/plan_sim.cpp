@@ -308,8 +308,7 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     net.fuse = g_fuse;
     net.chain = g_chain;
     net.prune = g_prune;
-    for (int i = 0; i < n_hints; ++i)
-        net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
+    net.set_hints(n_hints, hints);
     // one-request batch through the product's batch planner and level-synchronous scheduler
     int64_t q_off[2] = {0, nq}, e_off[2] = {0, ne}, out_off[2] = {0, 1};
     for (int i = 0; i < nq; ++i) out_off[1] *= card[qvars[i]];
@@ -457,8 +456,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     net.fuse = g_fuse;
     net.chain = g_chain;
     net.prune = g_prune;
-    for (int i = 0; i < n_hints; ++i)
-        net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
+    net.set_hints(n_hints, hints);
     Request rq;
     rq.nq = nq; rq.qvars = qvars; rq.ne = ne; rq.evars = evars; rq.ecodes = ecodes; rq.out_off = 0;
     std::vector<uint32_t> prog;
@@ -479,8 +477,7 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
     net.chain = g_chain;
-    for (int i = 0; i < n_hints; ++i)
-        net.hints.emplace_back(hints + (size_t)i * n_vars, hints + (size_t)(i + 1) * n_vars);
+    net.set_hints(n_hints, hints);
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
     for (int64_t b = 0; b <= B; ++b) { q_off[b] = b * nq; e_off[b] = b * ne; out_off[b] = b * 4; }
     BatchPlan bp;

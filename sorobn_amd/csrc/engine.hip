@@ -237,9 +237,7 @@ int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64
 int mibn_set_order_hints(mibn_t *h, int32_t n_hints, const int32_t *priorities) {
     if (!h || n_hints < 0 || (n_hints && !priorities)) return MIBN_E_ARG;
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
-    h->net.hints.clear();
-    for (int i = 0; i < n_hints; ++i)
-        h->net.hints.emplace_back(priorities + (size_t)i * h->net.n_vars, priorities + (size_t)(i + 1) * h->net.n_vars);
+    h->net.set_hints(n_hints, priorities);
     return MIBN_OK;
 }
 

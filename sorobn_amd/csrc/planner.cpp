@@ -92,7 +92,29 @@ std::string Network::set(int32_t n, const int32_t *card_, const int64_t *scope_o
     };
     for (int v = 0; v < n; ++v) visit(v);
     hints.clear();
+    hint_sorted.clear();
+    // the sweep orders of the planner are filtered from these lists (no per-request sorting)
+    topo_asc.resize(n);
+    std::iota(topo_asc.begin(), topo_asc.end(), 0);
+    topo_desc = topo_asc;
+    if (err.empty()) {
+        std::stable_sort(topo_asc.begin(), topo_asc.end(), [&](int a, int b) { return depth[a] < depth[b]; });
+        std::stable_sort(topo_desc.begin(), topo_desc.end(), [&](int a, int b) { return depth[a] > depth[b]; });
+    }
     return err;
+}
+
+void Network::set_hints(int32_t n_hints, const int32_t *priorities) {
+    hints.clear();
+    hint_sorted.clear();
+    for (int i = 0; i < n_hints; ++i) {
+        hints.emplace_back(priorities + (size_t)i * n_vars, priorities + (size_t)(i + 1) * n_vars);
+        std::vector<int32_t> o(n_vars);
+        std::iota(o.begin(), o.end(), 0);
+        const std::vector<int32_t> &h = hints.back();
+        std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return h[a] < h[b]; });
+        hint_sorted.push_back(std::move(o));
+    }
 }
 
 bool request_is_valid(const Network &net, const Request &rq) {
@@ -192,14 +214,28 @@ template <class F> inline void b2_each(const B2 &s, F f) {
     for (uint64_t m = s.a; m; m &= m - 1) f(__builtin_ctzll(m));
     for (uint64_t m = s.b; m; m &= m - 1) f(64 + __builtin_ctzll(m));
 }
-// simulate() for networks of up to 128 variables
+// simulate() for networks of up to 128 variables and up to 320 factor slots: every variable keeps the set of factor
+// slots whose scope contains it, so an elimination touches only the factors it consumes (the flat scan over all live
+// factors per eliminated variable was most of the order search).
 double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
                     double abort_above) {
-    constexpr int kCap = 512;
+    constexpr int kSlotWords = 5, kCap = 64 * kSlotWords;
+    struct Slots { uint64_t w[kSlotWords]; };
     B2 f[kCap];
     double fc[kCap];
+    Slots mem[128];
+    const int nv = net.n_vars;
+    for (int v = 0; v < nv; ++v)
+        for (int k = 0; k < kSlotWords; ++k) mem[v].w[k] = 0;
+    Slots alive;
+    for (int k = 0; k < kSlotWords; ++k) alive.w[k] = 0;
     int nf = (int)f0.size();
-    for (int i = 0; i < nf; ++i) { f[i] = B2{f0[i].w[0], f0[i].w[1]}; fc[i] = f0c[i]; }
+    for (int i = 0; i < nf; ++i) {
+        f[i] = B2{f0[i].w[0], f0[i].w[1]};
+        fc[i] = f0c[i];
+        alive.w[i >> 6] |= 1ull << (i & 63);
+        b2_each(f[i], [&](int v) { mem[v].w[i >> 6] |= 1ull << (i & 63); });
+    }
     auto cells = [&](const B2 &u) {
         double c = 1;
         b2_each(u, [&](int v) { c *= net.card[v]; });
@@ -209,16 +245,14 @@ double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::
     for (int32_t x : order) {
         B2 u;
         double in = 0;
-        for (int i = 0; i < nf;) {
-            if (f[i].test(x)) {
+        for (int k = 0; k < kSlotWords; ++k) {
+            uint64_t m = mem[x].w[k] & alive.w[k];
+            alive.w[k] &= ~m;
+            for (; m; m &= m - 1) {
+                const int i = k * 64 + __builtin_ctzll(m);
                 u.a |= f[i].a;
                 u.b |= f[i].b;
                 in += fc[i];
-                --nf;
-                f[i] = f[nf];
-                fc[i] = fc[nf];
-            } else {
-                ++i;
             }
         }
         u.clr(x);
@@ -227,18 +261,26 @@ double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::
         if (bytes > abort_above) return bytes;
         f[nf] = u;
         fc[nf] = uc;
+        alive.w[nf >> 6] |= 1ull << (nf & 63);
+        b2_each(u, [&](int v) { mem[v].w[nf >> 6] |= 1ull << (nf & 63); });
         ++nf;
     }
     B2 u;
     double in = 0;
-    for (int i = 0; i < nf; ++i) { u.a |= f[i].a; u.b |= f[i].b; in += fc[i]; }
+    for (int k = 0; k < kSlotWords; ++k)
+        for (uint64_t m = alive.w[k]; m; m &= m - 1) {
+            const int i = k * 64 + __builtin_ctzll(m);
+            u.a |= f[i].a;
+            u.b |= f[i].b;
+            in += fc[i];
+        }
     return bytes + 8.0 * (in + cells(u));
 }
 
 // SURVEY section 8(d) byte model of an elimination order over factor scopes (f0c = cells of every scope).
 double simulate(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
                 double abort_above) {
-    if (net.n_vars <= 128 && f0.size() + order.size() + 1 <= 512) return simulate_128(net, f0, f0c, order, abort_above);
+    if (net.n_vars <= 128 && f0.size() + order.size() + 1 <= 320) return simulate_128(net, f0, f0c, order, abort_above);
     Scratch &S = scratch();
     std::vector<Bits> &f = S.sim;
     std::vector<double> &fc = S.simc;
@@ -1240,18 +1282,32 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     if (!hid.empty()) {
         int qdepth = std::numeric_limits<int>::max();
         for (int i = 0; i < rq.nq; ++i) qdepth = std::min(qdepth, (int)net.depth[rq.qvars[i]]);
-        auto sorted_by = [&](auto keyfn) {
-            std::vector<int32_t> o = hid;
-            std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return keyfn(a) < keyfn(b); });
-            return o;
+        // the candidate sweeps are the hidden variables in the order of a per-network sorted list (Network::set /
+        // set_hints): filtered, not sorted, per request
+        auto filtered = [&](const std::vector<int32_t> &sorted_all, int lo_depth, int hi_depth, std::vector<int32_t> &o) {
+            for (int32_t v : sorted_all)
+                if (hidden.test(v) && net.depth[v] >= lo_depth && net.depth[v] < hi_depth) o.push_back(v);
         };
+        constexpr int kNoDepth = std::numeric_limits<int>::max();
         {
             PROF(1);
             // "meet": sweep down from the roots to the query's depth, then up from the leaves
-            consider(sorted_by([&](int v) { return net.depth[v] < qdepth ? (double)net.depth[v] : 1e6 - net.depth[v]; }));
+            std::vector<int32_t> o;
+            o.reserve(hid.size());
+            filtered(net.topo_asc, 0, qdepth, o);
+            filtered(net.topo_desc, qdepth, kNoDepth, o);
+            consider(std::move(o));
             // (a plain topological sweep wins on < 1 % of the C3 requests: not worth its simulation)
-            consider(sorted_by([&](int v) { return -(double)net.depth[v]; }));  // reverse sweep
-            for (auto &h : net.hints) consider(sorted_by([&](int v) { return (double)h[v]; }));
+            std::vector<int32_t> r;
+            r.reserve(hid.size());
+            filtered(net.topo_desc, 0, kNoDepth, r);  // reverse sweep
+            consider(std::move(r));
+            for (auto &h : net.hint_sorted) {
+                std::vector<int32_t> ho;
+                ho.reserve(hid.size());
+                filtered(h, 0, kNoDepth, ho);
+                consider(std::move(ho));
+            }
         }
         // greedy min-fill: the best order on 60 % of the C3 requests (52.7 MB mean against 67.6 MB for the sweeps alone),
         // skipped where the sweeps already found a plan too cheap to be worth the host time
@@ -1432,20 +1488,20 @@ static double sweep_cost(const Network &net, const Request &rq) {
         scopes.push_back(sc);
         scells.push_back(cells);
     });
-    std::vector<int32_t> &hid = S.hid;
-    hid.clear();
-    hidden.for_each([&](int v) { if (net.card[v] > 1) hid.push_back(v); });
+    Bits live = hidden;
+    hidden.for_each([&](int v) { if (net.card[v] <= 1) live.clr(v); });
     int qdepth = std::numeric_limits<int>::max();
     for (int i = 0; i < rq.nq; ++i) qdepth = std::min(qdepth, (int)net.depth[rq.qvars[i]]);
-    std::vector<int32_t> o = hid;
-    std::stable_sort(o.begin(), o.end(), [&](int a, int b) {
-        const double ka = net.depth[a] < qdepth ? (double)net.depth[a] : 1e6 - net.depth[a];
-        const double kb = net.depth[b] < qdepth ? (double)net.depth[b] : 1e6 - net.depth[b];
-        return ka < kb;
-    });
+    std::vector<int32_t> &o = S.hid;
+    o.clear();
+    for (int32_t v : net.topo_asc)
+        if (live.test(v) && net.depth[v] < qdepth) o.push_back(v);
+    for (int32_t v : net.topo_desc)
+        if (live.test(v) && net.depth[v] >= qdepth) o.push_back(v);
     double best = simulate(net, scopes, scells, o, std::numeric_limits<double>::infinity());
-    o = hid;
-    std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return net.depth[a] > net.depth[b]; });
+    o.clear();
+    for (int32_t v : net.topo_desc)
+        if (live.test(v)) o.push_back(v);
     best = std::min(best, simulate(net, scopes, scells, o, best));
     return best;
 }

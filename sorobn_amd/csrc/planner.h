@@ -54,7 +54,9 @@ struct Network {
     std::vector<double> pool;
     std::vector<Bits> anc;                       // ancestors (bayes_net.py:373-378), memoised
     std::vector<int32_t> depth;                  // longest path from a root
-    std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier)
+    std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier); install with set_hints()
+    std::vector<std::vector<int32_t>> hint_sorted;  // every hint as a variable list in ascending (priority, id) order
+    std::vector<int32_t> topo_asc, topo_desc;    // all variables by (depth ascending, id) / (depth descending, id)
     int nw = 1;
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
@@ -71,6 +73,7 @@ struct Network {
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
                     const int64_t *value_off, const double *values);
+    void set_hints(int32_t n_hints, const int32_t *priorities);  // n_hints arrays of n_vars priorities
 };
 
 struct Request {

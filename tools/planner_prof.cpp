@@ -1,0 +1,71 @@
+// Host-planner profiling harness (CPU only): plans a random 1-query + 4-evidence stream on an R x C grid network with K
+// states and reports us per request.  Build with -pg for gprof:
+//   g++ -O2 -g -pg -mpopcnt -std=c++17 tools/planner_prof.cpp sorobn_amd/csrc/planner.cpp -lpthread -o /tmp/planner_prof
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../sorobn_amd/csrc/planner.h"
+using namespace mibn;
+
+int main(int argc, char **argv) {
+    const int R = 10, C = 10, K = 4;
+    const int64_t B = argc > 1 ? atoll(argv[1]) : 8192;
+    const int threads = argc > 2 ? atoi(argv[2]) : 1;
+    const int reps = argc > 3 ? atoi(argv[3]) : 3;
+    const int n = R * C;
+    // variable ids in anti-diagonal topological order like BayesNet.nodes (any topological order would do here)
+    std::vector<int32_t> card(n, K), scope_vars;
+    std::vector<int64_t> scope_off{0}, value_off{0};
+    std::vector<double> values;
+    std::mt19937_64 rng(1);
+    std::uniform_real_distribution<double> U(0.1, 1.0);
+    for (int v = 0; v < n; ++v) {
+        const int r = v / C, c = v % C;
+        if (r) scope_vars.push_back(v - C);
+        if (c) scope_vars.push_back(v - 1);
+        scope_vars.push_back(v);
+        scope_off.push_back((int64_t)scope_vars.size());
+        int64_t cells = K;
+        if (r) cells *= K;
+        if (c) cells *= K;
+        for (int64_t i = 0; i < cells; ++i) values.push_back(U(rng));
+        value_off.push_back((int64_t)values.size());
+    }
+    Network net;
+    std::string e = net.set(n, card.data(), scope_off.data(), scope_vars.data(), value_off.data(), values.data());
+    if (!e.empty()) { std::fprintf(stderr, "%s\n", e.c_str()); return 1; }
+    std::vector<int32_t> hint(n);
+    for (int v = 0; v < n; ++v) hint[v] = v;
+    net.set_hints(1, hint.data());
+    std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
+    std::vector<int32_t> qv(B), ev(4 * B), ec(4 * B);
+    for (int64_t b = 0; b < B; ++b) {
+        int pick[5];
+        for (int k = 0; k < 5;) {
+            const int v = (int)(rng() % n);
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup = dup || pick[j] == v;
+            if (!dup) pick[k++] = v;
+        }
+        qv[b] = pick[0];
+        for (int k = 0; k < 4; ++k) { ev[4 * b + k] = pick[1 + k]; ec[4 * b + k] = (int)(rng() % K); }
+    }
+    for (int64_t b = 0; b <= B; ++b) { q_off[b] = b; e_off[b] = 4 * b; out_off[b] = 4 * b; }
+    ThreadPool pool(threads);
+    std::vector<ProgBuf> bufs;
+    BatchPlan bp;
+    double best = 1e30;
+    for (int r = 0; r < reps; ++r) {
+        auto t0 = std::chrono::steady_clock::now();
+        plan_batch(net, pool, bufs, 0, B, q_off.data(), qv.data(), e_off.data(), ev.data(), ec.data(), out_off.data(), nullptr, bp);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms < best) best = ms;
+    }
+    if (!bp.err.empty()) { std::fprintf(stderr, "%s\n", bp.err.c_str()); return 1; }
+    std::printf("threads %d: %.1f ms for %lld requests = %.2f us/request/thread (x%d threads), %.0f req/s; %.1f steps, %.0f words, %.2f MB per request\n",
+                threads, best, (long long)B, best * 1e3 / B * threads, threads, B / best * 1e3, bp.st.n_steps / B, (double)bp.total_words / B, bp.st.alg_bytes / B / 1e6);
+    return 0;
+}
