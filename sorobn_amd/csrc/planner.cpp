@@ -167,6 +167,7 @@ struct PF {  // planning-time factor (plain data: no heap allocation on the plan
     int64_t cells = 0;           // product of the free cardinalities
     int64_t alloc = 0;           // arena cells owned (0 for constants)
     int32_t src = -1;            // initial factor: the variable whose CPT it slices (its offset depends on the evidence codes)
+    PF() {}                      // (user-provided: emplace_back() does not zero the 480 bytes of vars / strides)
 };
 
 inline double scope_log2(const Network &net, const Bits &b) {
@@ -190,6 +191,9 @@ struct Scratch {
     std::vector<int> live;
     std::vector<int32_t> pos;  // variable -> axis position in the current output (or -1)
     std::vector<double> key;
+    std::vector<uint64_t> mem;    // per variable: the factor slots (pool indices) whose scope contains it
+    std::vector<uint64_t> slot_alive;  // factor slots not yet consumed
+    std::vector<int32_t> cand, best;   // candidate elimination orders (no per-request heap traffic)
 };
 Scratch &scratch() {
     static thread_local Scratch s;
@@ -322,7 +326,11 @@ double simulate(const Network &net, const std::vector<Bits> &f0, const std::vect
     return bytes;
 }
 
-void greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits &hidden, std::vector<int32_t> &order) {
+// `abort_above`: every factor an elimination creates is written once and read once later, so 16 bytes x the cells
+// created so far is a lower bound of the order's section-8(d) cost - once it passes the best sweep the search stops
+// (returns false: the order cannot win).
+bool greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits &hidden, std::vector<int32_t> &order,
+                      double abort_above) {
     const int n = net.n_vars;
     B2 adj[128];
     for (int v = 0; v < n; ++v) adj[v] = B2{};
@@ -352,6 +360,7 @@ void greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits
     for (int i = 0; i < n_alive; ++i) { full(hid[i]); alive[hid[i]] = true; }
     order.clear();
     const int total = n_alive;
+    double created = 0;
     for (int it = 0; it < total; ++it) {
         int best = -1;
         double wbest = 0;
@@ -371,6 +380,8 @@ void greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits
         n_alive = k;
         order.push_back(best);
         alive[best] = false;
+        created += std::exp2(ws[best]);  // cells of the factor this elimination creates (its scope = the neighbours)
+        if (16.0 * created > abort_above) return false;
         const B2 nb = adj[best];
         b2_each(nb, [&](int y) {
             B2 fresh{nb.a & ~adj[y].a, nb.b & ~adj[y].b};  // members of nb not yet adjacent to y
@@ -390,20 +401,16 @@ void greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits
         });
         b2_each(nb, [&](int y) { if (alive[y]) full(y); });
     }
+    return true;
 }
 
 // Greedy min-fill elimination order on the interaction graph: eliminate the vertex whose elimination adds the
 // fewest edges, ties by the size of the factor it creates, then by depth and id.  The fill counts are maintained
 // incrementally: eliminating a vertex changes the neighbourhood of its neighbours (recomputed) and connects pairs
 // of them - every common neighbour of a newly connected pair loses that pair from its fill count.
-std::vector<int32_t> greedy_order(const Network &net, const std::vector<Bits> &f, const Bits &hidden) {
+bool greedy_order(const Network &net, const std::vector<Bits> &f, const Bits &hidden, std::vector<int32_t> &order, double abort_above) {
     const int n = net.n_vars, nw = net.nw;
-    if (n <= 128) {
-        std::vector<int32_t> order;
-        order.reserve(128);
-        greedy_order_128(net, f, hidden, order);
-        return order;
-    }
+    if (n <= 128) return greedy_order_128(net, f, hidden, order, abort_above);
     Scratch &S = scratch();
     S.adj.assign(n, Bits{});
     for (auto &a : S.adj) a.nw = nw;
@@ -428,8 +435,7 @@ std::vector<int32_t> greedy_order(const Network &net, const std::vector<Bits> &f
         S.miss[x] = missing;
     };
     for (int x : hid) { full(x); S.alive[x] = 1; }
-    std::vector<int32_t> order;
-    order.reserve(hid.size());
+    order.clear();
     size_t n_alive = hid.size();
     for (size_t it = 0, total = hid.size(); it < total; ++it) {
         int best = -1;
@@ -472,7 +478,7 @@ std::vector<int32_t> greedy_order(const Network &net, const std::vector<Bits> &f
         });
         nb.for_each([&](int y) { if (S.alive[y]) full(y); });
     }
-    return order;
+    return true;
 }
 
 struct Arena {
@@ -1131,7 +1137,6 @@ struct Emitter {
         out.scope = Bits{};
         out.scope.nw = net.nw;
         for (int j = 0; j < n_in; ++j) out.scope.or_(ins[j]->scope);
-        const double prod_log2 = scope_log2(net, out.scope);
         for (int k = 0; k < nx; ++k) out.scope.clr(X[k]);
         int na = 0;
         bool overflow = false;
@@ -1194,7 +1199,8 @@ struct Emitter {
         if (!err.empty()) return false;
         prog.data[step_base + 9] = (uint32_t)(((int64_t)in_cells + cells + 2) >> 2);  // section-8(d) cells of this step, units of 4
         st.alg_bytes += 8.0 * (in_cells + (double)cells);
-        const double pc = std::exp2(prod_log2);
+        double pc = (double)cells;  // cells of the product scope = the output's cells x the eliminated cardinalities
+        for (int k = 0; k < nx; ++k) pc *= net.card[X[k]];
         st.alg_flops += n_in * pc;
         st.max_step_cells = std::max(st.max_step_cells, pc);
         st.n_steps += 1;
@@ -1271,47 +1277,47 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     hidden.andnot(trivial);
 
     // candidate elimination orders, cheapest by the byte model wins
-    std::vector<int32_t> hid;
-    hidden.for_each([&](int v) { hid.push_back(v); });
-    std::vector<int32_t> best;
+    std::vector<int32_t> &best = S.best, &cand = S.cand;
+    best.clear();
     double best_cost = std::numeric_limits<double>::infinity();
-    auto consider = [&](std::vector<int32_t> &&o) {
-        double c = simulate(net, scopes, scells, o, best_cost);
-        if (c < best_cost) { best_cost = c; best = std::move(o); }
+    auto consider = [&]() {  // evaluates `cand`
+        const double c = simulate(net, scopes, scells, cand, best_cost);
+        if (c < best_cost) { best_cost = c; best.swap(cand); }
     };
-    if (!hid.empty()) {
+    if (hidden.any()) {
         int qdepth = std::numeric_limits<int>::max();
         for (int i = 0; i < rq.nq; ++i) qdepth = std::min(qdepth, (int)net.depth[rq.qvars[i]]);
         // the candidate sweeps are the hidden variables in the order of a per-network sorted list (Network::set /
         // set_hints): filtered, not sorted, per request
-        auto filtered = [&](const std::vector<int32_t> &sorted_all, int lo_depth, int hi_depth, std::vector<int32_t> &o) {
+        auto filtered = [&](const std::vector<int32_t> &sorted_all, int lo_depth, int hi_depth) {
             for (int32_t v : sorted_all)
-                if (hidden.test(v) && net.depth[v] >= lo_depth && net.depth[v] < hi_depth) o.push_back(v);
+                if (hidden.test(v) && net.depth[v] >= lo_depth && net.depth[v] < hi_depth) cand.push_back(v);
         };
         constexpr int kNoDepth = std::numeric_limits<int>::max();
         {
             PROF(1);
             // "meet": sweep down from the roots to the query's depth, then up from the leaves
-            std::vector<int32_t> o;
-            o.reserve(hid.size());
-            filtered(net.topo_asc, 0, qdepth, o);
-            filtered(net.topo_desc, qdepth, kNoDepth, o);
-            consider(std::move(o));
+            cand.clear();
+            filtered(net.topo_asc, 0, qdepth);
+            filtered(net.topo_desc, qdepth, kNoDepth);
+            consider();
             // (a plain topological sweep wins on < 1 % of the C3 requests: not worth its simulation)
-            std::vector<int32_t> r;
-            r.reserve(hid.size());
-            filtered(net.topo_desc, 0, kNoDepth, r);  // reverse sweep
-            consider(std::move(r));
+            cand.clear();
+            filtered(net.topo_desc, 0, kNoDepth);  // reverse sweep
+            consider();
             for (auto &h : net.hint_sorted) {
-                std::vector<int32_t> ho;
-                ho.reserve(hid.size());
-                filtered(h, 0, kNoDepth, ho);
-                consider(std::move(ho));
+                cand.clear();
+                filtered(h, 0, kNoDepth);
+                consider();
             }
         }
         // greedy min-fill: the best order on 60 % of the C3 requests (52.7 MB mean against 67.6 MB for the sweeps alone),
         // skipped where the sweeps already found a plan too cheap to be worth the host time
-        if (best_cost > net.minfill_above) { PROF(3); consider(greedy_order(net, scopes, hidden)); }
+        if (best_cost > net.minfill_above) {
+            PROF(3);
+            cand.clear();
+            if (greedy_order(net, scopes, hidden, cand, best_cost)) consider();
+        }
     }
 
     PROF(4);
@@ -1343,16 +1349,37 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
         em.emit(ins, n_in, &x, x >= 0 ? 1 : 0, final_, final_off, pool.back(), false);
         return (int)pool.size() - 1;
     };
+    // Which factors mention a variable: every variable keeps the set of factor slots (pool indices) whose scope contains
+    // it, `alive` the slots not yet consumed.  Slots are handed out in creation order, so walking a set in ascending order
+    // visits the factors in the order of the reference's factor list (bayes_net.py:780-784 pops from it, 786 appends).
+    const int sw = (int)((pool.capacity() + 63) / 64);
+    std::vector<uint64_t> &mem = S.mem, &alive = S.slot_alive;
+    if (mem.size() < (size_t)net.n_vars * sw) mem.resize((size_t)net.n_vars * sw);
+    alive.assign(sw, 0);
+    rel.for_each([&](int v) { std::fill(mem.begin() + (size_t)v * sw, mem.begin() + (size_t)(v + 1) * sw, 0ull); });
+    auto add_factor = [&](int idx) {
+        alive[idx >> 6] |= 1ull << (idx & 63);
+        pool[idx].scope.for_each([&](int v) { mem[(size_t)v * sw + (idx >> 6)] |= 1ull << (idx & 63); });
+    };
+    for (int idx : live) add_factor(idx);
+    // factors alive whose scope contains a (or b, if b >= 0), in slot order; f(idx) returns false to stop early
+    auto each_with = [&](int a, int b, auto f) {
+        for (int k = 0; k < sw; ++k) {
+            uint64_t m = (mem[(size_t)a * sw + k] | (b >= 0 ? mem[(size_t)b * sw + k] : 0ull)) & alive[k];
+            for (; m; m &= m - 1)
+                if (!f(k * 64 + __builtin_ctzll(m))) return;
+        }
+    };
+    auto consume = [&](const PF *f) {
+        const int idx = (int)(f - pool.data());
+        alive[idx >> 6] &= ~(1ull << (idx & 63));
+    };
     for (size_t i = 0; i < best.size(); ++i) {
         const int32_t x = best[i];
         // pop every factor mentioning x (bayes_net.py:780-784)
         int n_in = 0;
-        size_t k = 0;
-        for (size_t l = 0; l < live.size(); ++l) {
-            if (pool[live[l]].scope.test(x)) ins[n_in++] = &pool[live[l]];
-            else live[k++] = live[l];
-        }
-        live.resize(k);
+        each_with(x, -1, [&](int idx) { ins[n_in++] = &pool[idx]; return true; });
+        for (int j = 0; j < n_in; ++j) consume(ins[j]);
         // Joint elimination: if the factor this step creates is a big table that the very next step consumes, both
         // variables are summed out in one pass over the inputs and the intermediate never touches HBM.
         // CHAIN: three consecutive 4-state variables of one big table in a single pass (planner.h)
@@ -1366,13 +1393,12 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
             if (nbig == 1 && bigf->scope.test(x2) && bigf->scope.test(x3) && bigf->cells >= 16 * (int64_t)net.big_iters) {
                 int n3 = n_in;
                 bool fits = true;
-                for (size_t l = 0; l < live.size() && fits; ++l) {
-                    const PF &f = pool[live[l]];
-                    if (f.scope.test(x2) || f.scope.test(x3)) {
-                        if (n3 >= kMaxIn || f.cells > net.small_cells) fits = false;
-                        else ins[n3++] = &f;
-                    }
-                }
+                each_with(x2, x3, [&](int idx) {
+                    const PF &f = pool[idx];
+                    if (n3 >= kMaxIn || f.cells > net.small_cells) { fits = false; return false; }
+                    ins[n3++] = &f;
+                    return true;
+                });
                 if (fits) {  // exactly three new variables (the frontier keeps its width), cheap to check before any layout work
                     Bits u;
                     u.nw = net.nw;
@@ -1383,11 +1409,8 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
                     const int X[3] = {x, x2, x3};
                     pool.emplace_back();
                     if (em.emit(ins, n3, X, 3, false, 0, pool.back(), true)) {
-                        k = 0;
-                        for (size_t l = 0; l < live.size(); ++l)
-                            if (!pool[live[l]].scope.test(x2) && !pool[live[l]].scope.test(x3)) live[k++] = live[l];
-                        live.resize(k);
-                        live.push_back((int)pool.size() - 1);
+                        for (int j = n_in; j < n3; ++j) consume(ins[j]);
+                        add_factor((int)pool.size() - 1);
                         i += 2;
                         continue;
                     }
@@ -1406,12 +1429,12 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
                 scope_log2(net, u) - net.log2card[x] > std::log2((double)net.small_cells)) {
                 int n2 = n_in;
                 bool fits = true;
-                for (size_t l = 0; l < live.size(); ++l)
-                    if (pool[live[l]].scope.test(x2)) {
-                        if (n2 >= kMaxIn) { fits = false; break; }
-                        ins[n2++] = &pool[live[l]];
-                        u.or_(pool[live[l]].scope);
-                    }
+                each_with(x2, -1, [&](int idx) {
+                    if (n2 >= kMaxIn) { fits = false; return false; }
+                    ins[n2++] = &pool[idx];
+                    u.or_(pool[idx].scope);
+                    return true;
+                });
                 // cheap necessary conditions of the FIBER form, before any emission work (most candidates fail here):
                 // one or two big inputs, and enough R cells (output cells / predicted NC) for a tiled step
                 if (fits) {
@@ -1431,11 +1454,8 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
                     const int X[2] = {x, x2};
                     pool.emplace_back();
                     if (em.emit(ins, n2, X, 2, false, 0, pool.back(), true)) {
-                        k = 0;
-                        for (size_t l = 0; l < live.size(); ++l)
-                            if (!pool[live[l]].scope.test(x2)) live[k++] = live[l];
-                        live.resize(k);
-                        live.push_back((int)pool.size() - 1);
+                        for (int j = n_in; j < n2; ++j) consume(ins[j]);
+                        add_factor((int)pool.size() - 1);
                         ++i;
                         continue;
                     }
@@ -1446,14 +1466,15 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
         }
         const int out = emit_limited(n_in, x, false, 0);  // pointwise_mul + sum_out (785)
         if (!em.err.empty()) return em.err;
-        live.push_back(out);
+        add_factor(out);
     }
     // posterior = pointwise_mul(factors) / sum (bayes_net.py:789-790), written in the caller's
     // query order (C-order, last query variable fastest)
     st.out_cells = 1;
     for (int i = 0; i < rq.nq; ++i) st.out_cells *= net.card[rq.qvars[i]];
     int n_in = 0;
-    for (int i : live) ins[n_in++] = &pool[i];
+    for (int k = 0; k < sw; ++k)
+        for (uint64_t m = alive[k]; m; m &= m - 1) ins[n_in++] = &pool[k * 64 + __builtin_ctzll(m)];
     emit_limited(n_in, -1, true, rq.out_off);
     if (!em.err.empty()) return em.err;
     prog.data[count_pos] = (uint32_t)(st.n_steps - steps0);

@@ -65,6 +65,16 @@ int main(int argc, char **argv) {
         if (ms < best) best = ms;
     }
     if (!bp.err.empty()) { std::fprintf(stderr, "%s\n", bp.err.c_str()); return 1; }
+    // fingerprint of the emitted programs in request order (independent of which worker planned a request): planner
+    // optimisations must not change a single word
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t b = 0; b < B; ++b) {
+        const uint32_t *w = bufs[bp.thread_of[b]].data + bp.local_off[b];
+        const uint32_t *end = w + 1;
+        for (uint32_t s = 0, off = 1; s < w[0]; ++s) { off += w[off + 6]; end = w + off; }
+        for (const uint32_t *p = w; p < end; ++p) h = (h ^ *p) * 1099511628211ull;
+    }
+    std::printf("program fingerprint %016llx\n", (unsigned long long)h);
     std::printf("threads %d: %.1f ms for %lld requests = %.2f us/request/thread (x%d threads), %.0f req/s; %.1f steps, %.0f words, %.2f MB per request\n",
                 threads, best, (long long)B, best * 1e3 / B * threads, threads, B / best * 1e3, bp.st.n_steps / B, (double)bp.total_words / B, bp.st.alg_bytes / B / 1e6);
     return 0;
