@@ -244,6 +244,7 @@ def main():
     ap.add_argument("--port-seconds", type=float, default=6.0, help="wall budget of the C-port leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true")
+    ap.add_argument("--only-configs", action="store_true", help="measure C1 / C2 / C5 only and print them (quick check)")
     ap.add_argument("--sync", action="store_true", help="one blocking mibn_query_batch per step instead of the two-deep pipeline")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (experiments), e.g. --opt chunk=32768")
     ap.add_argument("--threads", type=int, default=0, help="planner threads of this rank (0 = host threads / ranks on the node)")
@@ -279,6 +280,9 @@ def main():
     import sorobn_amd
     from sorobn_amd import sharding
 
+    if a.only_configs:
+        print(json.dumps(other_configs(device)), flush=True)
+        return
     if a.config == "c5":
         return run_c5(a, rank, world, local_rank, device, backend)
 

@@ -166,7 +166,9 @@ int mibn_estimate_costs(mibn_t *h, int64_t B, const int64_t *q_off, const int32_
 int mibn_device_synchronize(mibn_t *h);
 
 /* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "chunk" (requests per planning /
- * launch chunk), "plan_cache" (0: plan every request, no plan templates for repeated request shapes).
+ * launch chunk), "plan_cache" (0: plan every request, no plan templates for repeated request shapes), "tiny" (0: never use the
+ * small-network kernel - one lane per request, CPTs in LDS, no planning - that answers blocking calls on networks of at
+ * most 32 variables / 4096 CPT cells / 65536 joint states).
  * Test and profiling hooks: "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the
  * kernels' step forms onto small networks), "split_kinds" (one launch per class of work and level, so that
  * mibn_last_kernel_stats reports per-class rates), "trace" (one stderr line per launch), "gibbs_lds" (0: the Gibbs

@@ -20,6 +20,7 @@
 #include "sample_kernel.hip.h"
 #include "count_kernel.hip.h"
 #include "planner.h"
+#include "tiny_kernel.hip.h"
 #include "ve_kernel.hip.h"
 
 using namespace mibn;
@@ -79,6 +80,15 @@ struct mibn_ctx {
         Schedule sched;
     } set[2];
     Staging res_stage[2];  // pinned landing buffers of asynchronous calls
+    // small-network specialisation (tiny_kernel.hip.h): one lane per request, no planning
+    bool tiny_ok = false;
+    int tiny = 1;              // option: 1 = use it where the network is eligible, 0 = always plan step programs
+    int32_t *d_tiny_meta = nullptr;
+    int32_t tiny_meta_words = 0;
+    char *d_tiny_req = nullptr;  // request arrays of the call in flight
+    size_t tiny_req_cap = 0;
+    Staging tiny_stage;
+    int32_t *d_tiny_bad = nullptr;
     int set_cursor = 0;    // the chunk set the next chunk plans into: alternates across calls, so that a call of one chunk
                            // plans into the idle set while the previous call's kernels still run from the other one
     uint64_t call_id = 0;  // kernel time retired later is booked to the call that launched it
@@ -99,8 +109,8 @@ struct mibn_ctx {
     } comm;
     std::string err;
     mibn_stats stats{}, total{};               // last call / since creation
-    mibn_kernel_stat kstats[kNumKernels + 1];  // per class (split_kinds) + the level kernel as a whole
-    mibn_kernel_stat ktotal[kNumKernels + 1];
+    mibn_kernel_stat kstats[kNumKernels + 2];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel
+    mibn_kernel_stat ktotal[kNumKernels + 2];
     // options
     double arena_gb = 96.0;
     int threads = 0;
@@ -170,6 +180,10 @@ void mibn_destroy(mibn_t *h) {
         (void)mibn_comm_destroy(h);
         (void)hipFree(h->d_pool);
         (void)hipFree(h->d_arena);
+        (void)hipFree(h->d_tiny_meta);
+        (void)hipFree(h->d_tiny_req);
+        (void)hipFree(h->d_tiny_bad);
+        if (h->tiny_stage.p) (void)hipHostFree(h->tiny_stage.p);
         for (int k = 0; k < 2; ++k) {
             (void)hipFree(h->d_results[k]);
             if (h->pend[k].done) (void)hipEventDestroy(h->pend[k].done);
@@ -208,6 +222,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "trace") h->trace = (int)value;
     else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
+    else if (n == "tiny") h->tiny = value != 0;  // small-network kernel (one lane per request, no planning) where eligible
     else if (n == "fuse") h->net.fuse = value != 0;
     else if (n == "plan_cache") h->net.plan_cache = value != 0;  // plan templates for repeated request shapes
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
@@ -230,6 +245,16 @@ int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64
         size_t bytes = std::max<size_t>(8, h->net.pool.size() * sizeof(double));
         HIP_TRY(h, hipMalloc(&h->d_pool, bytes));
         HIP_TRY(h, hipMemcpy(h->d_pool, h->net.pool.data(), h->net.pool.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->tiny_ok = tiny_eligible(h->net);
+        if (h->d_tiny_meta) { HIP_TRY(h, hipFree(h->d_tiny_meta)); h->d_tiny_meta = nullptr; }
+        if (h->tiny_ok) {
+            const std::vector<int32_t> meta = tiny_meta(h->net);
+            h->tiny_meta_words = (int32_t)meta.size();
+            HIP_TRY(h, hipMalloc(&h->d_tiny_meta, meta.size() * 4));
+            HIP_TRY(h, hipMemcpy(h->d_tiny_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
+            if (!h->d_tiny_bad) HIP_TRY(h, hipMalloc(&h->d_tiny_bad, 8));
+            h->tiny_ok = tiny_lds_bytes((int)h->net.pool.size(), h->tiny_meta_words) <= 64 * 1024;
+        }
     }
     return MIBN_OK;
 }
@@ -394,6 +419,104 @@ int next_event(mibn_ctx *h, mibn_ctx::Set &st, size_t &idx) {
 }  // namespace
 
 namespace {
+// Small-network path (tiny_kernel.hip.h): the request arrays go to the device as they are, one lane answers one request,
+// malformed requests are detected by the kernel (the host then re-validates to build the reference's message).
+// Returns MIBN_OK / an error, or 1 when the batch does not fit the kernel and has to be planned.
+int run_tiny(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off,
+             const int32_t *e_vars, const int32_t *e_codes, const int64_t *out_off, double *out, double t_start) {
+    const size_t nq = (size_t)(q_off[B] - q_off[0]), ne = (size_t)(e_off[B] - e_off[0]);
+    const size_t res_cells = (size_t)(out_off[B] - out_off[0]);
+    if (q_off[0] != 0 || e_off[0] != 0) return 1;                    // (offsets relative to a larger array: plan)
+    if (res_cells > (size_t)B * kTinyMaxQCells) return 1;
+    int rc;
+    // one pinned staging buffer, one DMA: [q_off | e_off | out_off | q_vars | e_vars | e_codes]
+    const size_t off_bytes = (size_t)(B + 1) * 8;
+    const size_t bytes = 3 * off_bytes + (nq + 2 * ne) * 4 + 64;
+    mibn_ctx::Staging &sg = h->tiny_stage;
+    if (bytes > sg.cap) {
+        if (sg.p) { HIP_TRY(h, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
+        HIP_TRY(h, hipHostMalloc((void **)&sg.p, bytes + bytes / 4, hipHostMallocDefault));
+        sg.cap = bytes + bytes / 4;
+    }
+    if ((rc = ensure(h, h->d_tiny_req, h->tiny_req_cap, bytes))) return rc;
+    if ((rc = ensure(h, h->d_results[0], h->results_cap[0], res_cells))) return rc;
+    char *p = sg.p;
+    std::memcpy(p, q_off, off_bytes);
+    std::memcpy(p + off_bytes, e_off, off_bytes);
+    std::memcpy(p + 2 * off_bytes, out_off, off_bytes);
+    char *pv = p + 3 * off_bytes;
+    std::memcpy(pv, q_vars, nq * 4);
+    if (ne) { std::memcpy(pv + nq * 4, e_vars, ne * 4); std::memcpy(pv + (nq + ne) * 4, e_codes, ne * 4); }
+    const int32_t none = 0x7fffffff;
+    HIP_TRY(h, hipMemcpyAsync(h->d_tiny_bad, &none, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tiny_req, p, bytes, hipMemcpyHostToDevice, h->stream));
+    TinyArgs A;
+    A.pool = h->d_pool;
+    A.meta = h->d_tiny_meta;
+    A.q_off = reinterpret_cast<const int64_t *>(h->d_tiny_req);
+    A.e_off = reinterpret_cast<const int64_t *>(h->d_tiny_req + off_bytes);
+    A.out_off = reinterpret_cast<const int64_t *>(h->d_tiny_req + 2 * off_bytes);
+    A.q_vars = reinterpret_cast<const int32_t *>(h->d_tiny_req + 3 * off_bytes);
+    A.e_vars = A.q_vars + nq;
+    A.e_codes = A.e_vars + ne;
+    A.out = h->d_results[0];
+    A.bad = h->d_tiny_bad;
+    A.B = B;
+    A.n_vars = h->net.n_vars;
+    A.pool_cells = (int32_t)h->net.pool.size();
+    A.meta_words = h->tiny_meta_words;
+    A.flags = flags;
+    const size_t lds = tiny_lds_bytes(A.pool_cells, A.meta_words);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((B + 63) / 64, (int64_t)h->n_cu * 16));
+    mibn_ctx::Set &st = h->set[0];
+    if ((rc = retire(h, st))) return rc;
+    size_t e0 = 0, e1 = 0;
+    if ((rc = next_event(h, st, e0))) return rc;
+    hipLaunchKernelGGL(tiny_kernel, dim3(grid), dim3(64), lds, h->stream, A);
+    HIP_TRY(h, hipGetLastError());
+    if ((rc = next_event(h, st, e1))) return rc;
+    int32_t bad = none;
+    const double t_d2h = now_ms();
+    HIP_TRY(h, hipMemcpyAsync(&bad, h->d_tiny_bad, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out + out_off[0], h->d_results[0], res_cells * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stats.d2h_ms += now_ms() - t_d2h;
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[e0], st.ev[e1]));
+    st.ev_used = 0;
+    if (bad != none) {  // the kernel skipped a malformed request: the message comes from the host-side checks
+        Request rq;
+        const int64_t b = bad;
+        rq.nq = (int32_t)(q_off[b + 1] - q_off[b]);
+        rq.qvars = q_vars + q_off[b];
+        rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
+        rq.evars = e_vars + e_off[b];
+        std::string why = validate_request(h->net, rq);
+        if (why.empty()) why = "out_off does not match the query table size";
+        h->err = "request " + std::to_string(b) + ": " + why;
+        return MIBN_E_ARG;
+    }
+    const double io_bytes = (double)bytes + 8.0 * (double)res_cells;
+    h->stats.kernel_ms = ms;
+    h->stats.n_launches = 1;
+    h->stats.n_workgroups = grid;
+    h->stats.alg_bytes = io_bytes;  // (request arrays in + posteriors out: nothing else touches HBM)
+    h->stats.total_ms = now_ms() - t_start;
+    h->total.kernel_ms += ms;
+    h->total.n_launches += 1;
+    h->total.alg_bytes += io_bytes;
+    h->total.total_ms += h->stats.total_ms;
+    h->total.d2h_ms += h->stats.d2h_ms;
+    for (mibn_kernel_stat *ks : {&h->kstats[kNumKernels + 1], &h->ktotal[kNumKernels + 1]}) {
+        std::snprintf(ks->name, sizeof(ks->name), "%s", "tiny_kernel");
+        ks->launches += 1;
+        ks->ms += ms;
+        ks->alg_bytes += io_bytes;
+        ks->items += grid;
+    }
+    return MIBN_OK;
+}
+
 // Plan, upload and launch a batch.  Synchronous (ticket == nullptr): waits and writes `out`.  Asynchronous: the
 // results land in a pinned buffer, *ticket identifies the call for mibn_wait; up to two calls may be in flight, so
 // the host plans call s+1 while the GPU still runs call s.
@@ -405,15 +528,19 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     const double t_start = now_ms();
     ++h->call_id;
     h->stats = mibn_stats{};
-    for (int k = 0; k <= kNumKernels; ++k) {
+    for (int k = 0; k <= kNumKernels + 1; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
-        std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", k < kNumKernels ? kernel_name(k) : "ve_level_kernel");
+        std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : "tiny_kernel"));
     }
     const int slot = h->next_slot;
     if (h->pend[slot].active) { h->err = "two asynchronous calls are already in flight: mibn_wait the older one first"; return MIBN_E_STATE; }
     if (ticket) *ticket = slot;
     if (B == 0) return MIBN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->tiny && h->tiny_ok && !ticket && B < 0x7ffffff0 && out_off[B] - out_off[0] >= B) {
+        const int rc_tiny = run_tiny(h, flags, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, t_start);
+        if (rc_tiny != 1) return rc_tiny;  // 1: a request does not fit the kernel (query table too large) - plan it
+    }
     // validation (bayes_net.py:840-845) and the out-of-domain-evidence short cut
     std::vector<char> skip((size_t)B, 0);
     for (int64_t b = 0; b < B; ++b) {
@@ -646,7 +773,7 @@ extern "C" int mibn_total_stats(const mibn_t *h, mibn_stats *out) {
 extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 1 && k < cap; ++i)
         if (h->ktotal[i].launches > 0) out[k++] = h->ktotal[i];
     *n = k;
     return MIBN_OK;
@@ -655,7 +782,7 @@ extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel
 extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 1 && k < cap; ++i)
         if (h->kstats[i].launches > 0) out[k++] = h->kstats[i];
     *n = k;
     return MIBN_OK;

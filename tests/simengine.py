@@ -81,6 +81,8 @@ class SimEngine:
             self.prune = int(value)
         elif name == "chain":
             self.chain = int(value)
+        elif name == "tiny":
+            pass  # (the small-network kernel exists on the device only)
         else:
             raise KeyError(name)
 

@@ -47,6 +47,7 @@ def _check_requests(bn, requests, ctx):
 def test_golden_networks(amd, fname, small_cells, tiling, fuse):
     for net in gu.load(fname):
         bn = netspec.build(net["spec"], amd.BayesNet)
+        bn.backend.engine.set_option("tiny", 0)  # (the small-network kernel has its own test below)
         bn.backend.engine.set_option("small_cells", small_cells)
         bn.backend.engine.set_option("big_iters", tiling[0])
         bn.backend.engine.set_option("tile_h", tiling[1])
@@ -59,11 +60,46 @@ def test_golden_small_grids(amd, small_cells, tiling, fuse):
     for entry in gu.load("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
         bn = netspec.build(spec, amd.BayesNet)
+        bn.backend.engine.set_option("tiny", 0)  # (the small-network kernel has its own test below)
         bn.backend.engine.set_option("small_cells", small_cells)
         bn.backend.engine.set_option("big_iters", tiling[0])
         bn.backend.engine.set_option("tile_h", tiling[1])
         bn.backend.engine.set_option("fuse", fuse)
         _check_requests(bn, entry["requests"], spec["name"])
+
+
+def test_tiny_kernel_goldens(amd):
+    """The small-network specialisation (csrc/tiny_kernel.hip.h: one lane per request, CPTs in LDS, no planning) on
+    every golden network it is eligible for - the four example networks, the small random DAGs (mixed cardinalities,
+    zeros, missing rows) and the small grids - against the reference's answers, and against the step-program path."""
+    used = 0
+    for fname in ("examples.json", "random_dags.json", "wide_cards.json"):
+        for net in gu.load(fname):
+            bn = netspec.build(net["spec"], amd.BayesNet)
+            eng = bn.backend.engine
+            _check_requests(bn, net["requests"], net["spec"]["name"] + " tiny")
+            if any(k["name"] == "tiny_kernel" for k in eng.kernel_stats()):
+                used += 1
+                assert eng.stats()["plan_ms"] == 0.0 and eng.stats()["n_launches"] == 1
+                reqs = [(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in net["requests"]]
+                tiny = bn.query_many(reqs)
+                eng.set_option("tiny", 0)
+                planned = bn.query_many(reqs)
+                assert not any(k["name"] == "tiny_kernel" for k in eng.kernel_stats())
+                for a, b in zip(tiny, planned):
+                    assert a.index.equals(b.index)
+                    if len(a):
+                        assert float(np.max(np.abs(a.to_numpy() - b.to_numpy()))) <= 1e-12
+    assert used >= 8, used
+    for entry in gu.load("grids_small.json"):
+        spec = gu.grid_spec_from_recipe(entry)
+        bn = netspec.build(spec, amd.BayesNet)
+        _check_requests(bn, entry["requests"], spec["name"] + " tiny")
+    # the four example networks must all take the kernel
+    for net in gu.load("examples.json"):
+        bn = netspec.build(net["spec"], amd.BayesNet)
+        bn.query_many([(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in net["requests"][:4]])
+        assert [k["name"] for k in bn.backend.engine.kernel_stats()] == ["tiny_kernel"], net["spec"]["name"]
 
 
 def test_golden_grid10x10(amd):
@@ -132,6 +168,7 @@ def test_c3_chain_form_vs_pair_form(amd):
         for small_cells, tiling in [(3, (4, 1)), (20, (64, 2))]:
             b = netspec.build(sp, amd.BayesNet)
             b.backend.engine.set_option("chain", 1)
+            b.backend.engine.set_option("tiny", 0)
             b.backend.engine.set_option("small_cells", small_cells)
             b.backend.engine.set_option("big_iters", tiling[0])
             b.backend.engine.set_option("tile_h", tiling[1])
@@ -173,6 +210,7 @@ def test_fresh_random_dags_vs_oracle(amd, seed):
     on = OracleNet(spec)
     for small_cells, tiling in [(1024, (4096, 0)), (2, (4, 2))]:
         bn = netspec.build(spec, amd.BayesNet)
+        bn.backend.engine.set_option("tiny", 0)  # (the small-network kernel has its own test below)
         bn.backend.engine.set_option("small_cells", small_cells)
         bn.backend.engine.set_option("big_iters", tiling[0])
         bn.backend.engine.set_option("tile_h", tiling[1])
