@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true")
     ap.add_argument("--only-configs", action="store_true", help="measure C1 / C2 / C5 only and print them (quick check)")
+    ap.add_argument("--no-adaptive", action="store_true", help="keep the planner's full order search even when the host is the bottleneck")
     ap.add_argument("--sync", action="store_true", help="one blocking mibn_query_batch per step instead of the two-deep pipeline")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (experiments), e.g. --opt chunk=32768")
     ap.add_argument("--threads", type=int, default=0, help="planner threads of this rank (0 = host threads / ranks on the node)")
@@ -292,6 +293,10 @@ def main():
     eng = be.engine
     if a.threads:
         eng.set_option("threads", a.threads)
+    if not a.no_adaptive:
+        # planning effort follows the host: with few cores per GPU (8 ranks on a small CPU quota) the min-fill search
+        # is reserved for the expensive requests; never triggers while planning hides under the kernels (N = 1 here)
+        eng.set_option("adaptive", 1)
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, float(v))
@@ -391,7 +396,8 @@ def main():
                        "gather": "none" if world == 1 else {"rccl": "RCCL via the C-ABI (mibn_comm_allgather_f64), no PyTorch",
                                                             "nccl": "RCCL via torch.distributed (hook)",
                                                             "gloo": "gloo via torch.distributed (test hook)"}[backend],
-                       "shard_balance": a.balance},
+                       "shard_balance": a.balance, "planner_threads": a.threads or "auto (cgroup quota / ranks)",
+                       "adaptive_planning": not a.no_adaptive},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": dom, "alg_bytes_per_launch": bytes_per_launch,

@@ -166,7 +166,11 @@ int mibn_estimate_costs(mibn_t *h, int64_t B, const int64_t *q_off, const int32_
 int mibn_device_synchronize(mibn_t *h);
 
 /* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "chunk" (requests per planning /
- * launch chunk), "plan_cache" (0: plan every request, no plan templates for repeated request shapes), "tiny" (0: never use the
+ * launch chunk), "plan_cache" (0: plan every request, no plan templates for repeated request shapes), "adaptive" (1: when host planning rather than the GPU bounds a stream
+ * of calls, reserve the min-fill order search for ever more expensive requests - fewer host microseconds, more bytes per
+ * query - and give it back when the host has slack; off by default: answers then never depend on timing, not even in
+ * the last bit), "minfill_above" (bytes of the best sweep order above which the min-fill search runs), "stagger" (groups
+ * of requests whose levels are staggered inside a chunk), "tiny" (0: never use the
  * small-network kernel - one lane per request, CPTs in LDS, no planning - that answers blocking calls on networks of at
  * most 32 variables / 4096 CPT cells / 65536 joint states).
  * Test and profiling hooks: "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the

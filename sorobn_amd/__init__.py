@@ -6,8 +6,8 @@ weighting, fit / partial_fit, structure.chow_liu), with the reference's API and 
 hand-written gfx950 HIP kernels behind the C-ABI in include/mibn.h (libmibn.so, loaded through ctypes - no PyTorch on
 the product path).
 """
-from . import structure
+from . import examples, structure
 from .bayes_net import Backend, BayesNet, accelerate
 
-__all__ = ["BayesNet", "Backend", "accelerate", "structure"]
+__all__ = ["BayesNet", "Backend", "accelerate", "examples", "structure"]
 __version__ = "0.1.0"

@@ -18,7 +18,8 @@ sampling kernel (one sample per lane); like Gibbs their parity is statistical (t
 `fit` / `partial_fit` (467-516; rank 3) and `sorobn_amd.structure.chow_liu` (structure.py:9-52; rank 4) count their
 contingency tables with one launch of the count kernel (learning.py).
 
-Out of scope: graph drawing, GUI, CLI.
+`sorobn_amd.examples` offers the reference's four example networks; `is_tree`, `markov_boundary`, `iter_dfs` mirror the
+small graph helpers.  Out of scope: graph drawing (`graphviz`), GUI, CLI.
 
 `accelerate(bn)` attaches the same backend to an *existing reference object* by replacing the two
 methods `query` dispatches to (bayes_net.py:848, 851-853); see INTEGRATION.md.
@@ -351,6 +352,33 @@ class BayesNet:
     @property
     def leaves(self):
         return [n for n in self.nodes if n not in self.children]
+
+    @property
+    def is_tree(self):
+        """No node has more than one parent (bayes_net.py:975-1000)."""
+        return all(len(ps) <= 1 for ps in self.parents.values())
+
+    def markov_boundary(self, node):
+        """Parents, children and the children's other parents, sorted (bayes_net.py:1002-1039) - the variables the
+        Gibbs kernel reads when it resamples `node`."""
+        boundary = set(self.parents.get(node, []))
+        for child in self.children.get(node, []):
+            boundary.add(child)
+            boundary.update(self.parents[child])
+        boundary.discard(node)
+        return sorted(boundary)
+
+    def iter_dfs(self):
+        """Depth-first pre-order from every root in `roots` order, children in sorted order (bayes_net.py:1041-1075)."""
+        seen = set()
+        stack = list(reversed(self.roots))
+        while stack:
+            node = stack.pop()
+            if node in seen:
+                continue
+            seen.add(node)
+            yield node
+            stack.extend(c for c in reversed(self.children.get(node, [])) if c not in seen)
 
     # ---- backend --------------------------------------------------------------------------------
     def use_device(self, device: int):

@@ -89,6 +89,11 @@ struct mibn_ctx {
     size_t tiny_req_cap = 0;
     Staging tiny_stage;
     int32_t *d_tiny_bad = nullptr;
+    // adaptive planning effort (option "adaptive"): when planning, not the GPU, bounds a stream of calls (few host cores
+    // per GPU), the greedy min-fill search - a third of the planning time for ~20 % fewer bytes - is reserved for ever
+    // more expensive requests, and given back when the host has slack again
+    int adaptive = 0;
+    double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
     int set_cursor = 0;    // the chunk set the next chunk plans into: alternates across calls, so that a call of one chunk
                            // plans into the idle set while the previous call's kernels still run from the other one
     uint64_t call_id = 0;  // kernel time retired later is booked to the call that launched it
@@ -222,11 +227,14 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "trace") h->trace = (int)value;
     else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
-    else if (n == "tiny") h->tiny = value != 0;  // small-network kernel (one lane per request, no planning) where eligible
+    else if (n == "tiny") h->tiny = value != 0;
+    else if (n == "adaptive") { h->adaptive = value != 0; if (!h->adaptive) h->net.minfill_above = h->base_minfill; }
+    else if (n == "minfill_above") { h->base_minfill = value; h->net.minfill_above = value; }  // bytes of the best sweep above which min-fill runs  // small-network kernel (one lane per request, no planning) where eligible
     else if (n == "fuse") h->net.fuse = value != 0;
     else if (n == "plan_cache") h->net.plan_cache = value != 0;  // plan templates for repeated request shapes
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
     else if (n == "outer") h->net.outer = value != 0;
+    else if (n == "stagger") h->net.stagger = std::max(1, std::min(8, (int)value));  // groups of requests with staggered levels per chunk
     else if (n == "prune") h->net.prune = value != 0;  // 0: multiply every CPT (full_joint_dist / predict_proba semantics)  // OUTER (MFMA) form for products of two big tables  // joint elimination of two variables per pass
     else if (n == "small_cells") h->net.small_cells = std::max(1, std::min(kMaxT, (int)value));  // test hook: forces FIBER steps on small networks
     else { h->err = "unknown option " + n; return MIBN_E_ARG; }
@@ -559,6 +567,16 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         }
     }
     ensure_pool(h);
+    if (h->adaptive) {
+        // over the calls since the last adjustment: host planning wall time against GPU kernel time (retired launches)
+        const double dp = h->total.plan_ms - h->seen_plan_ms, dk = h->total.kernel_ms - h->seen_kernel_ms;
+        if (dp > 20.0 && dk > 20.0) {
+            if (dp > 1.15 * dk) h->net.minfill_above = std::min(h->net.minfill_above * 8.0, 1e18);
+            else if (dp < 0.5 * dk) h->net.minfill_above = std::max(h->net.minfill_above / 8.0, h->base_minfill);
+            h->seen_plan_ms = h->total.plan_ms;
+            h->seen_kernel_ms = h->total.kernel_ms;
+        }
+    }
     int rc;
     const size_t res_cells = (size_t)(out_off[B] - out_off[0]);
     if ((rc = ensure(h, h->d_results[slot], h->results_cap[slot], res_cells))) return rc;

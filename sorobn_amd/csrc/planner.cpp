@@ -2002,7 +2002,6 @@ static const ClassOrder kClassOrder;
 
 void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<ProgBuf> &bufs, int64_t r0, int64_t r1,
                     Schedule &out) {
-    (void)net;
     (void)bufs;
     const int64_t n = r1 - r0;
     out.items.clear();
@@ -2025,6 +2024,15 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         if (cnt) n_levels = std::max(n_levels, (int)tg[cnt - 1].level + 1);
         n_tags += cnt;
     }
+    // Staggered levels (Network::stagger = G > 1): the requests of a chunk are dealt into G groups and group g starts
+    // g * (levels / G) launches late, so that every launch mixes the phases of a request's program - the latency-bound
+    // chains of tiny steps at its start, the frontier sweeps that stream at the HBM rate in the middle, the write-
+    // dominated joins where two sweeps meet - instead of running each phase for all requests at once.  Dependencies are
+    // per request (item k of a request still runs one launch after item k - 1), arenas are private: nothing else changes.
+    const int G = std::max(1, std::min(net.stagger, 8));
+    const int delta = G > 1 ? (n_levels + G - 1) / G : 0;
+    auto shift = [&](int64_t i) { return (int)(i % G) * delta; };
+    n_levels += (G - 1) * delta;
     out.n_levels = n_levels;
     const size_t nb = (size_t)n_levels * kNumKernels;
     std::vector<size_t> count(nb + 1, 0);
@@ -2032,8 +2040,9 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
     for (int64_t i = 0; i < n; ++i) {
         const int64_t r = r0 + i;
         const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
+        const int sh = shift(i);
         for (uint32_t k = 0; k < bp.tag_count[r]; ++k) {
-            const size_t bkt = (size_t)tg[k].level * kNumKernels + kClassOrder.rank_of[tg[k].kid];
+            const size_t bkt = (size_t)(tg[k].level + sh) * kNumKernels + kClassOrder.rank_of[tg[k].kid];
             ++count[bkt + 1];
             bytes[bkt] += tg[k].bytes;
             n_wg += tg[k].wgs;
@@ -2046,8 +2055,9 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
     for (int64_t i = 0; i < n; ++i) {
         const int64_t r = r0 + i;
         const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
+        const int sh = shift(i);
         for (uint32_t k = 0; k < bp.tag_count[r]; ++k)
-            out.items[cur[(size_t)tg[k].level * kNumKernels + kClassOrder.rank_of[tg[k].kid]]++] = Item{(uint32_t)i, tg[k].rel_off, tg[k].a, tg[k].wgs};
+            out.items[cur[(size_t)(tg[k].level + sh) * kNumKernels + kClassOrder.rank_of[tg[k].kid]]++] = Item{(uint32_t)i, tg[k].rel_off, tg[k].a, tg[k].wgs};
     }
     // pass 3: workgroup -> item table, level by level
     out.wg_item.resize(n_wg);

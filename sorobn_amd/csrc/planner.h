@@ -69,6 +69,7 @@ struct Network {
     uint64_t version = 0;    // changes with every set(): invalidates cached plan templates
     mutable std::shared_ptr<void> templates;  // the template store of this network (planner.cpp)
     int chain = 1;           // CHAIN form: a third 4-state variable eliminated in the registers of the same pass
+    int stagger = 1;         // build_schedule: groups of requests whose levels are staggered inside a chunk (1 = all in phase)
 
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,

@@ -9,8 +9,8 @@ from row order.
 Output layout (the `mibn_set_network` contract, include/mibn.h): variable ids follow `bn.nodes`
 (topological order), each variable's label domain is the sorted union of the labels it takes in
 any CPT, and factor v is a dense C-order table over its scope with 0.0 for absent rows.  This is
-pure integer index math and must be bit-exact; tests/test_flatten.py checks it against the sparse
-rows.
+pure integer index math and must be bit-exact; tests/test_host_logic.py::test_flatten_is_bit_exact checks it
+against the sparse rows.
 """
 import numpy as np
 import pandas as pd

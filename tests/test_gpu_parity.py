@@ -250,6 +250,27 @@ def test_wide_grids_every_request_vs_oracle(amd, shape):
     assert worst <= gu.TOL, worst
 
 
+def test_schedule_and_effort_options_do_not_change_answers(amd):
+    """`stagger` (groups of requests whose levels are staggered inside a chunk: the same programs in another launch
+    order) must reproduce the posteriors bit for bit; `minfill_above` (the knob the adaptive planning effort turns:
+    which requests get the min-fill order search) changes elimination orders, i.e. rounding only."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 6000, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    base = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    base_bytes = be.engine.stats()["alg_bytes"]
+    for g in (2, 3, 5):
+        be.engine.set_option("stagger", g)
+        assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base), g
+    be.engine.set_option("stagger", 1)
+    be.engine.set_option("minfill_above", 1e18)  # sweeps only
+    sweeps = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert be.engine.stats()["alg_bytes"] > 1.1 * base_bytes
+    assert float(np.max(np.abs(sweeps - base))) <= 1e-12
+
+
 def test_plan_templates_same_posteriors(amd):
     """A stream that repeats 40 request shapes with changing evidence values: answered from plan templates (default)
     and with every request planned (plan_cache=0) - the same programs, so the same posteriors bit for bit."""

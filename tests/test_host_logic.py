@@ -693,3 +693,23 @@ def test_heavy_c3_requests_simulator_vs_oracle():
         codes, vals = on.query_codes([int(oid[q[i]])], oid[ev[i]].tolist(), ec[i].tolist(), order=prio)
         got = sim._one([to_var[q[i]]], to_var[ev[i]], ec[i])
         assert float(np.max(np.abs(got[codes[:, 0]] - vals))) <= gu.TOL
+
+
+def test_examples_module_and_graph_helpers_match_the_reference():
+    """`sorobn_amd.examples.*` and the small graph helpers (`is_tree`, `markov_boundary`, `iter_dfs`,
+    bayes_net.py:975-1075) so that code written against `sorobn.examples.asia()` ports by changing the import."""
+    ref_mod = _reference_or_skip()
+    for name in ("alarm", "asia", "grades", "sprinkler"):
+        ref = getattr(ref_mod.examples, name)()
+        mine = getattr(sorobn_amd.examples, name)()
+        assert mine.nodes == ref.nodes and mine.parents == ref.parents and mine.children == ref.children
+        assert mine.is_tree == ref.is_tree
+        assert list(mine.iter_dfs()) == list(ref.iter_dfs())
+        for node in ref.nodes:
+            assert mine.markov_boundary(node) == ref.markov_boundary(node)
+            a, b = mine.P[node].sort_index(), ref.P[node].sort_index()
+            assert a.index.tolist() == b.index.tolist() and list(a.index.names) == list(b.index.names)
+            assert np.array_equal(a.to_numpy(dtype=float), b.to_numpy(dtype=float))
+    wiki = [(0, 3), (1, 4), (2, 5), (3, 6), (4, 6), (5, 8), (6, 8), (6, 9), (7, 9), (7, 10), (8, 11), (8, 12)]
+    assert sorobn_amd.BayesNet(*wiki).markov_boundary(6) == [3, 4, 5, 7, 8, 9]  # bayes_net.py:1015-1031
+    assert sorobn_amd.BayesNet(("a", "b"), ("a", "c")).is_tree and not sorobn_amd.BayesNet(("a", "c"), ("b", "c")).is_tree
