@@ -111,6 +111,8 @@ struct mibn_ctx {
         decltype(&ncclGetErrorString) GetErrorString = nullptr;
         void *d_send = nullptr, *d_recv = nullptr;
         size_t send_cap = 0, recv_cap = 0;
+        hipStream_t stream = nullptr;  // collectives run on their own stream: the gather of batch s must not queue behind the
+                                       // kernels of batch s + 1, which the two-deep pipeline has already submitted
     } comm;
     std::string err;
     mibn_stats stats{}, total{};               // last call / since creation
@@ -995,6 +997,7 @@ extern "C" int mibn_comm_init(mibn_t *h, int32_t rank, int32_t world, const void
     HIP_TRY(h, hipSetDevice(h->device));
     ncclUniqueId id;
     std::memcpy(&id, id_in, sizeof(id));
+    if (!h->comm.stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->comm.stream, hipStreamNonBlocking));
     NCCL_TRY(h, h->comm.CommInitRank(&h->comm.comm, world, id, rank));
     h->comm.rank = rank;
     h->comm.world = world;
@@ -1006,10 +1009,11 @@ extern "C" int mibn_comm_destroy(mibn_t *h) {
     mibn_ctx::Comm &c = h->comm;
     if (c.comm) {
         (void)hipSetDevice(h->device);
-        (void)hipStreamSynchronize(h->stream);
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
         (void)c.CommDestroy(c.comm);
         c.comm = nullptr;
     }
+    if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     if (c.d_send) { (void)hipFree(c.d_send); c.d_send = nullptr; c.send_cap = 0; }
     if (c.d_recv) { (void)hipFree(c.d_recv); c.d_recv = nullptr; c.recv_cap = 0; }
     return MIBN_OK;
@@ -1024,10 +1028,10 @@ extern "C" int mibn_comm_allgather_f64(mibn_t *h, const double *send, int64_t n,
     const size_t bytes = (size_t)n * 8;
     if ((rc = comm_buf(h, c.d_send, c.send_cap, bytes))) return rc;
     if ((rc = comm_buf(h, c.d_recv, c.recv_cap, bytes * (size_t)c.world))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(c.d_send, send, bytes, hipMemcpyHostToDevice, h->stream));
-    NCCL_TRY(h, c.AllGather(c.d_send, c.d_recv, (size_t)n, ncclDouble, c.comm, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(recv, c.d_recv, bytes * (size_t)c.world, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(c.d_send, send, bytes, hipMemcpyHostToDevice, c.stream));
+    NCCL_TRY(h, c.AllGather(c.d_send, c.d_recv, (size_t)n, ncclDouble, c.comm, c.stream));
+    HIP_TRY(h, hipMemcpyAsync(recv, c.d_recv, bytes * (size_t)c.world, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(h, hipStreamSynchronize(c.stream));
     return MIBN_OK;
 }
 
@@ -1040,10 +1044,10 @@ extern "C" int mibn_comm_reduce_i64(mibn_t *h, int64_t *buf, int64_t n, int32_t 
     const size_t bytes = (size_t)n * 8;
     if ((rc = comm_buf(h, c.d_send, c.send_cap, bytes))) return rc;
     if ((rc = comm_buf(h, c.d_recv, c.recv_cap, bytes))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(c.d_send, buf, bytes, hipMemcpyHostToDevice, h->stream));
-    NCCL_TRY(h, c.Reduce(c.d_send, c.d_recv, (size_t)n, ncclInt64, ncclSum, root, c.comm, h->stream));
-    if (c.rank == root) HIP_TRY(h, hipMemcpyAsync(buf, c.d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(c.d_send, buf, bytes, hipMemcpyHostToDevice, c.stream));
+    NCCL_TRY(h, c.Reduce(c.d_send, c.d_recv, (size_t)n, ncclInt64, ncclSum, root, c.comm, c.stream));
+    if (c.rank == root) HIP_TRY(h, hipMemcpyAsync(buf, c.d_recv, bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(h, hipStreamSynchronize(c.stream));
     return MIBN_OK;
 }
 
@@ -1056,10 +1060,10 @@ extern "C" int mibn_comm_allreduce_max_f64(mibn_t *h, double *buf, int64_t n) {
     const size_t bytes = (size_t)n * 8;
     if ((rc = comm_buf(h, c.d_send, c.send_cap, bytes))) return rc;
     if ((rc = comm_buf(h, c.d_recv, c.recv_cap, bytes))) return rc;
-    HIP_TRY(h, hipMemcpyAsync(c.d_send, buf, bytes, hipMemcpyHostToDevice, h->stream));
-    NCCL_TRY(h, c.AllReduce(c.d_send, c.d_recv, (size_t)n, ncclDouble, ncclMax, c.comm, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(buf, c.d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpyAsync(c.d_send, buf, bytes, hipMemcpyHostToDevice, c.stream));
+    NCCL_TRY(h, c.AllReduce(c.d_send, c.d_recv, (size_t)n, ncclDouble, ncclMax, c.comm, c.stream));
+    HIP_TRY(h, hipMemcpyAsync(buf, c.d_recv, bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(h, hipStreamSynchronize(c.stream));
     return MIBN_OK;
 }
 

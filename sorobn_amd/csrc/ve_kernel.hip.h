@@ -479,47 +479,49 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
             // two tables: a table whose wave-uniform offset did not change since the previous iteration (the planner makes
             // the axes only the other table depends on run fastest) stays in registers - these steps are bound by L1 load
             // issue, a reused table saves 4-16 of their 8-32 loads per output cell
-            double av[16], bv[16];
-            int prev_a = 0, prev_b = 0;
-            auto fetch = [&](const int b, const int hb, const uint32_t loff, double (&dst)[16]) {
-                const int s1 = bxs1[b], s2 = bxs2[b];
+            // (one of the two stays - `keep` - the other is loaded into the product buffer every iteration: a third
+            // 16-double array, both tables cached, made the register allocator spill)
+            double keep[16];
+            // the slow table: the one whose wave-uniform offset does not move between the first two iterations
+            const bool slow_b = nh > 1 && uni(sh_hoff[2][0]) != uni(sh_hoff[2][1]) && uni(sh_hoff[3][0]) == uni(sh_hoff[3][1]);
+            const int sb = slow_b ? NBIG - 1 : 0, fb = slow_b ? 0 : NBIG - 1;           // slow / fast table
+            const int srow = slow_b ? 3 : 2, frow = slow_b ? 2 : 3;                       // their rows of sh_hoff
+            const uint32_t sloff = (uint32_t)(slow_b ? lane_off[3] : lane_off[2]), floff = (uint32_t)(slow_b ? lane_off[2] : lane_off[3]);
+            const double *__restrict__ sbig = big[sb], *__restrict__ fbig = big[fb];
+            const int ss1 = bxs1[sb], ss2 = bxs2[sb], fs1 = bxs1[fb], fs2 = bxs2[fb];
+            // a table of a two-table step often lacks one of the two eliminated variables (a sweep meeting another one):
+            // 4 distinct values then, not 16
+            auto fetch = [&](const double *__restrict__ tab, const int s1, const int s2, const int hb, const uint32_t loff, double (&dst)[16],
+                             const bool multiply) {
                 if (s1 == 0) {
 #pragma unroll
                     for (int x2 = 0; x2 < 4; ++x2) {
-                        const double v = (big[b] + (hb + x2 * s2))[loff];
+                        const double v = (tab + (hb + x2 * s2))[loff];
 #pragma unroll
-                        for (int x1 = 0; x1 < 4; ++x1) dst[x1 + 4 * x2] = v;
+                        for (int x1 = 0; x1 < 4; ++x1) dst[x1 + 4 * x2] = multiply ? v * keep[x1 + 4 * x2] : v;
                     }
                 } else if (s2 == 0) {
 #pragma unroll
                     for (int x1 = 0; x1 < 4; ++x1) {
-                        const double v = (big[b] + (hb + x1 * s1))[loff];
+                        const double v = (tab + (hb + x1 * s1))[loff];
 #pragma unroll
-                        for (int x2 = 0; x2 < 4; ++x2) dst[x1 + 4 * x2] = v;
+                        for (int x2 = 0; x2 < 4; ++x2) dst[x1 + 4 * x2] = multiply ? v * keep[x1 + 4 * x2] : v;
                     }
                 } else {
 #pragma unroll
-                    for (int x = 0; x < 16; ++x) dst[x] = (big[b] + (hb + (x & 3) * s1 + (x >> 2) * s2))[loff];
+                    for (int x = 0; x < 16; ++x) {
+                        const double v = (tab + (hb + (x & 3) * s1 + (x >> 2) * s2))[loff];
+                        dst[x] = multiply ? v * keep[x] : v;
+                    }
                 }
             };
+            int prev_s = 0;
             for (int hh = 0; hh < nh; ++hh) {
-                const int ha = uni(sh_hoff[2][hh]), hb = uni(sh_hoff[3][hh]);
-                if (hh == 0 || ha != prev_a) { fetch(0, ha, (uint32_t)lane_off[2], av); prev_a = ha; }
-                if (hh == 0 || hb != prev_b) { fetch(NBIG - 1, hb, (uint32_t)lane_off[3], bv); prev_b = hb; }
-                if constexpr (NCT == 1) {
-                    // one output per cell: reduce the product of the two tables directly (a third 16-double array
-                    // next to av / bv made the allocator spill)
-                    const double *__restrict__ Tp = shT + (uni(sh_hoff[1][hh]) + lo_t);
-                    double s = 0.0;
-#pragma unroll
-                    for (int x = 0; x < 16; ++x) s += (av[x] * bv[x]) * Tp[x];
-                    if (active) outp[uni(sh_hoff[0][hh]) + lo_o] = s;
-                } else {
-                    double f[1][CX ? CX : 1];
-#pragma unroll
-                    for (int x = 0; x < 16; ++x) f[0][x % (CX ? CX : 1)] = av[x] * bv[x];
-                    finish(hh, f);
-                }
+                const int hs = uni(sh_hoff[srow][hh]), hf = uni(sh_hoff[frow][hh]);
+                if (hh == 0 || hs != prev_s) { fetch(sbig, ss1, ss2, hs, sloff, keep, false); prev_s = hs; }
+                double f[1][CX ? CX : 1];
+                fetch(fbig, fs1, fs2, hf, floff, f[0], true);
+                finish(hh, f);
             }
         } else {
             double fa[U][CX ? CX : 1];
