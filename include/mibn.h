@@ -167,9 +167,10 @@ int mibn_device_synchronize(mibn_t *h);
 
 /* Tunables: "arena_gb" (scratch budget), "threads" (planner threads), "chunk" (requests per planning /
  * launch chunk), "plan_cache" (0: plan every request, no plan templates for repeated request shapes), "adaptive" (1: when host planning rather than the GPU bounds a stream
- * of calls, reserve the min-fill order search for ever more expensive requests - fewer host microseconds, more bytes per
- * query - and give it back when the host has slack; off by default: answers then never depend on timing, not even in
- * the last bit), "minfill_above" (bytes of the best sweep order above which the min-fill search runs), "stagger" (groups
+ * of calls, move the elimination-order search to the device - "gpu_search" - or, for networks of more than 128 variables,
+ * reserve the min-fill search for ever more expensive requests; given back when the host has slack), "gpu_search" (1: the
+ * order search of every chunk but the first of a call runs as a kernel, one request per lane, the same code as on the
+ * host: identical orders and programs; 2: every chunk, synchronously - tests), "minfill_above" (bytes of the best sweep order above which the min-fill search runs), "stagger" (groups
  * of requests whose levels are staggered inside a chunk), "tiny" (0: never use the
  * small-network kernel - one lane per request, CPTs in LDS, no planning - that answers blocking calls on networks of at
  * most 32 variables / 4096 CPT cells / 65536 joint states).

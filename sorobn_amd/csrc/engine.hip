@@ -31,6 +31,34 @@ double now_ms() {
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- device order search
+// The elimination-order search of the planner (order_search.h - the same code the host runs) as a kernel: one request
+// per lane, the search state in a global buffer.  Pure bit-set / integer work, independent per request and latency-bound:
+// it occupies a few hundred wave slots for a few milliseconds beside the level kernels and takes ~40 % of the planning
+// time off the host cores (option "gpu_search").
+struct OrderArgs {
+    OrderNet net;
+    const int64_t *q_off, *e_off;
+    const int32_t *q_vars, *e_vars;
+    int64_t B;
+    uint32_t flags;
+    uint8_t *orders;       // [B][128]
+    int32_t *order_len;    // [B]
+    OrderScratch *scratch; // [B]
+};
+
+__global__ __launch_bounds__(64) void order_kernel(const OrderArgs A) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    OrderScratch &S = A.scratch[b];
+    const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
+    order_search(A.net, S, (int)(A.q_off[b + 1] - q0), A.q_vars + q0, (int)(A.e_off[b + 1] - e0), A.e_vars + e0,
+                 (A.flags & MIBN_Q_NOPRUNE) != 0);
+    uint8_t *out = A.orders + b * 128;
+    for (int i = 0; i < S.n_best; ++i) out[i] = S.best[i];
+    A.order_len[b] = S.n_best;
+}
+
 struct mibn_ctx {
     Network net;
     bool has_net = false;
@@ -89,11 +117,29 @@ struct mibn_ctx {
     size_t tiny_req_cap = 0;
     Staging tiny_stage;
     int32_t *d_tiny_bad = nullptr;
-    // adaptive planning effort (option "adaptive"): when planning, not the GPU, bounds a stream of calls (few host cores
-    // per GPU), the greedy min-fill search - a third of the planning time for ~20 % fewer bytes - is reserved for ever
-    // more expensive requests, and given back when the host has slack again
+    // adaptive planning (option "adaptive"): when planning, not the GPU, bounds a stream of calls (few host cores per
+    // GPU), the elimination-order search - 40 % of the planning time - moves to the device (order_kernel); for networks the
+    // device search does not cover (> 128 variables) the greedy min-fill search is reserved for ever more expensive
+    // requests instead; both are given back when the host has slack again
     int adaptive = 0;
+    bool auto_search = false;  // gpu_search was switched on by the adaptive policy
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
+    // device order search (order_kernel)
+    int gpu_search = 0;              // option: 1 = search elimination orders on the device (networks of <= 128 variables)
+    hipStream_t search_stream = nullptr;
+    char *d_order_net = nullptr;     // the OrderNet arrays
+    OrderNet order_net_dev;          // pointers into d_order_net
+    bool order_net_ok = false;
+    char *d_search_req = nullptr;    // request arrays of the chunk
+    size_t search_req_cap = 0;
+    uint8_t *d_orders = nullptr;
+    size_t orders_cap = 0;
+    int32_t *d_order_len = nullptr;
+    size_t order_len_cap = 0;
+    OrderScratch *d_order_scratch = nullptr;
+    size_t order_scratch_cap = 0;
+    Staging search_in, search_out;   // pinned: request arrays in, orders + lengths out
+    double search_ms = 0;            // host wall time spent waiting for the device search (last call)
     int set_cursor = 0;    // the chunk set the next chunk plans into: alternates across calls, so that a call of one chunk
                            // plans into the idle set while the previous call's kernels still run from the other one
     uint64_t call_id = 0;  // kernel time retired later is booked to the call that launched it
@@ -135,6 +181,41 @@ struct mibn_ctx {
             return MIBN_E_HIP;                                                                        \
         }                                                                                             \
     } while (0)
+
+// The arrays order_search.h reads, in one device buffer (rebuilt by set_network / set_order_hints).
+static int upload_order_net(mibn_ctx *h) {
+    h->order_net_ok = false;
+    if (h->planner_only || h->net.n_vars > 128 || h->net.n_vars < 1) return MIBN_OK;
+    const Network &net = h->net;
+    const size_t n = (size_t)net.n_vars, nh = net.hint_sorted.size();
+    std::vector<char> buf;
+    auto put = [&](const void *p, size_t bytes) {
+        const size_t off = (buf.size() + 15) & ~size_t(15);
+        buf.resize(off + bytes);
+        if (bytes) std::memcpy(buf.data() + off, p, bytes);
+        return off;
+    };
+    const size_t o_card = put(net.card.data(), n * 4), o_depth = put(net.depth.data(), n * 4);
+    const size_t o_asc = put(net.topo_asc.data(), n * 4), o_desc = put(net.topo_desc.data(), n * 4);
+    const size_t o_hint = put(net.hint_flat.data(), nh * n * 4), o_log = put(net.log2card.data(), n * 8);
+    const size_t o_anc = put(net.anc2.data(), n * sizeof(B2)), o_sc = put(net.scope2.data(), n * sizeof(B2));
+    if (h->d_order_net) { HIP_TRY(h, hipFree(h->d_order_net)); h->d_order_net = nullptr; }
+    HIP_TRY(h, hipMalloc(&h->d_order_net, buf.size()));
+    HIP_TRY(h, hipMemcpy(h->d_order_net, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    OrderNet &o = h->order_net_dev;
+    o = net.order_view();
+    char *d = h->d_order_net;
+    o.card = reinterpret_cast<const int32_t *>(d + o_card);
+    o.depth = reinterpret_cast<const int32_t *>(d + o_depth);
+    o.topo_asc = reinterpret_cast<const int32_t *>(d + o_asc);
+    o.topo_desc = reinterpret_cast<const int32_t *>(d + o_desc);
+    o.hint_sorted = reinterpret_cast<const int32_t *>(d + o_hint);
+    o.log2card = reinterpret_cast<const double *>(d + o_log);
+    o.anc = reinterpret_cast<const B2 *>(d + o_anc);
+    o.cpt_scope = reinterpret_cast<const B2 *>(d + o_sc);
+    h->order_net_ok = true;
+    return MIBN_OK;
+}
 
 extern "C" {
 
@@ -190,6 +271,14 @@ void mibn_destroy(mibn_t *h) {
         (void)hipFree(h->d_tiny_meta);
         (void)hipFree(h->d_tiny_req);
         (void)hipFree(h->d_tiny_bad);
+        (void)hipFree(h->d_order_net);
+        (void)hipFree(h->d_search_req);
+        (void)hipFree(h->d_orders);
+        (void)hipFree(h->d_order_len);
+        (void)hipFree(h->d_order_scratch);
+        if (h->search_in.p) (void)hipHostFree(h->search_in.p);
+        if (h->search_out.p) (void)hipHostFree(h->search_out.p);
+        if (h->search_stream) (void)hipStreamDestroy(h->search_stream);
         if (h->tiny_stage.p) (void)hipHostFree(h->tiny_stage.p);
         for (int k = 0; k < 2; ++k) {
             (void)hipFree(h->d_results[k]);
@@ -230,6 +319,8 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
     else if (n == "tiny") h->tiny = value != 0;
+    else if (n == "gpu_search") h->gpu_search = std::max(0, std::min(2, (int)value));  // elimination-order search on the device
+        // (order_kernel): 1 = the first chunk of a call on the host, the rest of the call by one launch; 2 = every chunk, synchronously (tests)
     else if (n == "adaptive") { h->adaptive = value != 0; if (!h->adaptive) h->net.minfill_above = h->base_minfill; }
     else if (n == "minfill_above") { h->base_minfill = value; h->net.minfill_above = value; }  // bytes of the best sweep above which min-fill runs  // small-network kernel (one lane per request, no planning) where eligible
     else if (n == "fuse") h->net.fuse = value != 0;
@@ -265,6 +356,7 @@ int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64
             if (!h->d_tiny_bad) HIP_TRY(h, hipMalloc(&h->d_tiny_bad, 8));
             h->tiny_ok = tiny_lds_bytes((int)h->net.pool.size(), h->tiny_meta_words) <= 64 * 1024;
         }
+        return upload_order_net(h);
     }
     return MIBN_OK;
 }
@@ -273,6 +365,7 @@ int mibn_set_order_hints(mibn_t *h, int32_t n_hints, const int32_t *priorities) 
     if (!h || n_hints < 0 || (n_hints && !priorities)) return MIBN_E_ARG;
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
     h->net.set_hints(n_hints, priorities);
+    if (!h->planner_only) return upload_order_net(h);
     return MIBN_OK;
 }
 
@@ -429,6 +522,72 @@ int next_event(mibn_ctx *h, mibn_ctx::Set &st, size_t &idx) {
 }  // namespace
 
 namespace {
+int pinned(mibn_ctx *h, mibn_ctx::Staging &sg, size_t bytes) {
+    if (bytes <= sg.cap) return MIBN_OK;
+    if (sg.p) { HIP_TRY(h, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
+    HIP_TRY(h, hipHostMalloc((void **)&sg.p, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+    sg.cap = bytes + bytes / 4 + 4096;
+    return MIBN_OK;
+}
+
+// Device order search for requests [b0, b1): uploads their query / evidence variables and launches order_kernel on a
+// high-priority stream of its own (it must not queue behind the level kernels of the previous chunk); the orders (128
+// bytes per request) and their lengths land in h->search_out.  Asynchronous: search_wait() before they are read.  The
+// kernel is latency-bound with one request per lane - its duration hardly depends on the number of requests - so the
+// whole remainder of a call is searched by one launch (slices of kSearchSlice requests share the scratch buffer).
+constexpr int64_t kSearchSlice = 65536;  // 1.3 GB of search state
+int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, const int64_t *q_off, const int32_t *q_vars,
+                        const int64_t *e_off, const int32_t *e_vars) {
+    const int64_t n = b1 - b0;
+    int rc;
+    if (!h->search_stream) {
+        int lo = 0, hi = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->search_stream, hipStreamNonBlocking, hi));
+    }
+    const size_t nq = (size_t)(q_off[b1] - q_off[b0]), ne = (size_t)(e_off[b1] - e_off[b0]);
+    const size_t off_bytes = (size_t)(n + 1) * 8;
+    const size_t in_bytes = 2 * off_bytes + (nq + ne) * 4 + 64;
+    if ((rc = pinned(h, h->search_in, in_bytes))) return rc;
+    if ((rc = pinned(h, h->search_out, (size_t)n * 132))) return rc;
+    if ((rc = ensure(h, h->d_search_req, h->search_req_cap, in_bytes))) return rc;
+    if ((rc = ensure(h, h->d_orders, h->orders_cap, (size_t)n * 128))) return rc;
+    if ((rc = ensure(h, h->d_order_len, h->order_len_cap, (size_t)n))) return rc;
+    if ((rc = ensure(h, h->d_order_scratch, h->order_scratch_cap, (size_t)std::min(n, kSearchSlice)))) return rc;
+    int64_t *qo = reinterpret_cast<int64_t *>(h->search_in.p), *eo = qo + (n + 1);
+    for (int64_t i = 0; i <= n; ++i) { qo[i] = q_off[b0 + i] - q_off[b0]; eo[i] = e_off[b0 + i] - e_off[b0]; }
+    char *pv = h->search_in.p + 2 * off_bytes;
+    std::memcpy(pv, q_vars + q_off[b0], nq * 4);
+    if (ne) std::memcpy(pv + nq * 4, e_vars + e_off[b0], ne * 4);
+    HIP_TRY(h, hipMemcpyAsync(h->d_search_req, h->search_in.p, in_bytes, hipMemcpyHostToDevice, h->search_stream));
+    for (int64_t s0 = 0; s0 < n; s0 += kSearchSlice) {
+        const int64_t m = std::min(kSearchSlice, n - s0);
+        OrderArgs A;
+        A.net = h->order_net_dev;
+        A.net.prune = h->net.prune;
+        A.net.minfill_above = h->net.minfill_above;
+        A.q_off = reinterpret_cast<const int64_t *>(h->d_search_req) + s0;
+        A.e_off = reinterpret_cast<const int64_t *>(h->d_search_req + off_bytes) + s0;
+        A.q_vars = reinterpret_cast<const int32_t *>(h->d_search_req + 2 * off_bytes);
+        A.e_vars = A.q_vars + nq;
+        A.B = m;
+        A.flags = flags;
+        A.orders = h->d_orders + s0 * 128;
+        A.order_len = h->d_order_len + s0;
+        A.scratch = h->d_order_scratch;
+        hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, h->search_stream, A);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->search_out.p, h->d_orders, (size_t)n * 128, hipMemcpyDeviceToHost, h->search_stream));
+    HIP_TRY(h, hipMemcpyAsync(h->search_out.p + (size_t)n * 128, h->d_order_len, (size_t)n * 4, hipMemcpyDeviceToHost, h->search_stream));
+    return MIBN_OK;
+}
+
+int search_wait(mibn_ctx *h) {
+    HIP_TRY(h, hipStreamSynchronize(h->search_stream));
+    return MIBN_OK;
+}
+
 // Small-network path (tiny_kernel.hip.h): the request arrays go to the device as they are, one lane answers one request,
 // malformed requests are detected by the kernel (the host then re-validates to build the reference's message).
 // Returns MIBN_OK / an error, or 1 when the batch does not fit the kernel and has to be planned.
@@ -537,6 +696,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
     const double t_start = now_ms();
     ++h->call_id;
+    h->search_ms = 0;
     h->stats = mibn_stats{};
     for (int k = 0; k <= kNumKernels + 1; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
@@ -573,8 +733,15 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         // over the calls since the last adjustment: host planning wall time against GPU kernel time (retired launches)
         const double dp = h->total.plan_ms - h->seen_plan_ms, dk = h->total.kernel_ms - h->seen_kernel_ms;
         if (dp > 20.0 && dk > 20.0) {
-            if (dp > 1.15 * dk) h->net.minfill_above = std::min(h->net.minfill_above * 8.0, 1e18);
-            else if (dp < 0.5 * dk) h->net.minfill_above = std::max(h->net.minfill_above / 8.0, h->base_minfill);
+            if (dp > 1.15 * dk) {
+                // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
+                // not cover give up the min-fill search for ever more expensive requests instead
+                if (h->order_net_ok && !h->gpu_search) { h->gpu_search = 1; h->auto_search = true; }
+                else if (!h->order_net_ok) h->net.minfill_above = std::min(h->net.minfill_above * 8.0, 1e18);
+            } else if (dp < 0.3 * dk) {
+                if (h->net.minfill_above > h->base_minfill) h->net.minfill_above = std::max(h->net.minfill_above / 8.0, h->base_minfill);
+                else if (h->auto_search) { h->gpu_search = 0; h->auto_search = false; }
+            }
             h->seen_plan_ms = h->total.plan_ms;
             h->seen_kernel_ms = h->total.kernel_ms;
         }
@@ -588,6 +755,9 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
     const int64_t budget_cells = (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes)) / 8.0);
     int64_t n_chunks = 0;
+    const bool search_on = h->gpu_search && h->order_net_ok;
+    int64_t search_b0 = -1;
+    bool search_done = false;
     // a short first chunk gets the GPU going while the host plans the first full-size one
     for (int64_t b0 = 0, b1 = 0; b0 < B; b0 = b1, ++n_chunks) {
         b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
@@ -596,9 +766,28 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         h->set_cursor ^= 1;
         if ((rc = retire(h, st))) return rc;  // its buffers are about to be rewritten
         double t0 = now_ms();
+        // device order search: the first (short) chunk of a call is searched on the host while one launch searches the
+        // rest of the call on the device; the later chunks only emit
+        const uint8_t *orders = nullptr;
+        const int32_t *order_len = nullptr;
+        if (search_on && h->gpu_search == 2) {  // test mode: every chunk searched on the device, synchronously
+            if ((rc = search_orders_async(h, flags, b0, b1, q_off, q_vars, e_off, e_vars))) return rc;
+            if ((rc = search_wait(h))) return rc;
+            orders = reinterpret_cast<const uint8_t *>(h->search_out.p);
+            order_len = reinterpret_cast<const int32_t *>(h->search_out.p + (size_t)n * 128);
+        } else if (search_on) {
+            if (n_chunks == 0 && b1 < B) {
+                if ((rc = search_orders_async(h, flags, b1, B, q_off, q_vars, e_off, e_vars))) return rc;
+                search_b0 = b1;
+            } else if (search_b0 >= 0) {
+                if (!search_done) { if ((rc = search_wait(h))) return rc; search_done = true; h->search_ms += now_ms() - t0; }
+                orders = reinterpret_cast<const uint8_t *>(h->search_out.p) + (size_t)(b0 - search_b0) * 128;
+                order_len = reinterpret_cast<const int32_t *>(h->search_out.p + (size_t)(B - search_b0) * 128) + (b0 - search_b0);
+            }
+        }
         BatchPlan &ck = st.plan;
         plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck,
-                   (flags & MIBN_Q_NOPRUNE) != 0);
+                   (flags & MIBN_Q_NOPRUNE) != 0, orders, order_len);
         if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); return MIBN_E_LIMIT; }
         for (auto &b : st.bufs)
             if (b.cap && !b.data) { h->err = "pinned host allocation failed"; return MIBN_E_HIP; }

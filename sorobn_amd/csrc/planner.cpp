@@ -101,18 +101,49 @@ std::string Network::set(int32_t n, const int32_t *card_, const int64_t *scope_o
         std::stable_sort(topo_asc.begin(), topo_asc.end(), [&](int a, int b) { return depth[a] < depth[b]; });
         std::stable_sort(topo_desc.begin(), topo_desc.end(), [&](int a, int b) { return depth[a] > depth[b]; });
     }
+    anc2.clear();
+    scope2.clear();
+    hint_flat.clear();
+    if (n <= 128 && err.empty()) {
+        anc2.resize(n);
+        scope2.resize(n);
+        for (int v = 0; v < n; ++v) {
+            anc2[v].a = anc[v].w[0];
+            anc2[v].b = anc[v].w[1];
+            for (int32_t u : scope[v]) scope2[v].set(u);
+        }
+    }
     return err;
+}
+
+OrderNet Network::order_view() const {
+    OrderNet o;
+    o.n_vars = n_vars;
+    o.n_hints = (int32_t)hint_sorted.size();
+    o.card = card.data();
+    o.log2card = log2card.data();
+    o.depth = depth.data();
+    o.anc = anc2.data();
+    o.cpt_scope = scope2.data();
+    o.topo_asc = topo_asc.data();
+    o.topo_desc = topo_desc.data();
+    o.hint_sorted = hint_flat.data();
+    o.prune = prune;
+    o.minfill_above = minfill_above;
+    return o;
 }
 
 void Network::set_hints(int32_t n_hints, const int32_t *priorities) {
     hints.clear();
     hint_sorted.clear();
+    hint_flat.clear();
     for (int i = 0; i < n_hints; ++i) {
         hints.emplace_back(priorities + (size_t)i * n_vars, priorities + (size_t)(i + 1) * n_vars);
         std::vector<int32_t> o(n_vars);
         std::iota(o.begin(), o.end(), 0);
         const std::vector<int32_t> &h = hints.back();
         std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return h[a] < h[b]; });
+        hint_flat.insert(hint_flat.end(), o.begin(), o.end());
         hint_sorted.push_back(std::move(o));
     }
 }
@@ -199,6 +230,10 @@ Scratch &scratch() {
     static thread_local Scratch s;
     return s;
 }
+OrderScratch &order_scratch() {  // state of the shared host / device order search (order_search.h), ~35 KB per planning thread
+    static thread_local OrderScratch s;
+    return s;
+}
 
 inline double scope_cells(const Network &net, const Bits &b) {
     double c = 1;
@@ -206,85 +241,9 @@ inline double scope_cells(const Network &net, const Bits &b) {
     return c;
 }
 
-// Two-word bitsets for networks of up to 128 variables (the common case): the byte model and the min-fill search
-// below run ~3x faster on them than on the generic kMaxVars-wide Bits.
-struct B2 {
-    uint64_t a = 0, b = 0;
-    bool test(int i) const { return ((i < 64 ? a : b) >> (i & 63)) & 1; }
-    void set(int i) { (i < 64 ? a : b) |= 1ull << (i & 63); }
-    void clr(int i) { (i < 64 ? a : b) &= ~(1ull << (i & 63)); }
-};
-template <class F> inline void b2_each(const B2 &s, F f) {
-    for (uint64_t m = s.a; m; m &= m - 1) f(__builtin_ctzll(m));
-    for (uint64_t m = s.b; m; m &= m - 1) f(64 + __builtin_ctzll(m));
-}
-// simulate() for networks of up to 128 variables and up to 320 factor slots: every variable keeps the set of factor
-// slots whose scope contains it, so an elimination touches only the factors it consumes (the flat scan over all live
-// factors per eliminated variable was most of the order search).
-double simulate_128(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
-                    double abort_above) {
-    constexpr int kSlotWords = 5, kCap = 64 * kSlotWords;
-    struct Slots { uint64_t w[kSlotWords]; };
-    B2 f[kCap];
-    double fc[kCap];
-    Slots mem[128];
-    const int nv = net.n_vars;
-    for (int v = 0; v < nv; ++v)
-        for (int k = 0; k < kSlotWords; ++k) mem[v].w[k] = 0;
-    Slots alive;
-    for (int k = 0; k < kSlotWords; ++k) alive.w[k] = 0;
-    int nf = (int)f0.size();
-    for (int i = 0; i < nf; ++i) {
-        f[i] = B2{f0[i].w[0], f0[i].w[1]};
-        fc[i] = f0c[i];
-        alive.w[i >> 6] |= 1ull << (i & 63);
-        b2_each(f[i], [&](int v) { mem[v].w[i >> 6] |= 1ull << (i & 63); });
-    }
-    auto cells = [&](const B2 &u) {
-        double c = 1;
-        b2_each(u, [&](int v) { c *= net.card[v]; });
-        return c;
-    };
-    double bytes = 0;
-    for (int32_t x : order) {
-        B2 u;
-        double in = 0;
-        for (int k = 0; k < kSlotWords; ++k) {
-            uint64_t m = mem[x].w[k] & alive.w[k];
-            alive.w[k] &= ~m;
-            for (; m; m &= m - 1) {
-                const int i = k * 64 + __builtin_ctzll(m);
-                u.a |= f[i].a;
-                u.b |= f[i].b;
-                in += fc[i];
-            }
-        }
-        u.clr(x);
-        const double uc = cells(u);
-        bytes += 8.0 * (in + uc);
-        if (bytes > abort_above) return bytes;
-        f[nf] = u;
-        fc[nf] = uc;
-        alive.w[nf >> 6] |= 1ull << (nf & 63);
-        b2_each(u, [&](int v) { mem[v].w[nf >> 6] |= 1ull << (nf & 63); });
-        ++nf;
-    }
-    B2 u;
-    double in = 0;
-    for (int k = 0; k < kSlotWords; ++k)
-        for (uint64_t m = alive.w[k]; m; m &= m - 1) {
-            const int i = k * 64 + __builtin_ctzll(m);
-            u.a |= f[i].a;
-            u.b |= f[i].b;
-            in += fc[i];
-        }
-    return bytes + 8.0 * (in + cells(u));
-}
-
 // SURVEY section 8(d) byte model of an elimination order over factor scopes (f0c = cells of every scope).
 double simulate(const Network &net, const std::vector<Bits> &f0, const std::vector<double> &f0c, const std::vector<int32_t> &order,
                 double abort_above) {
-    if (net.n_vars <= 128 && f0.size() + order.size() + 1 <= 320) return simulate_128(net, f0, f0c, order, abort_above);
     Scratch &S = scratch();
     std::vector<Bits> &f = S.sim;
     std::vector<double> &fc = S.simc;
@@ -326,91 +285,14 @@ double simulate(const Network &net, const std::vector<Bits> &f0, const std::vect
     return bytes;
 }
 
-// `abort_above`: every factor an elimination creates is written once and read once later, so 16 bytes x the cells
-// created so far is a lower bound of the order's section-8(d) cost - once it passes the best sweep the search stops
-// (returns false: the order cannot win).
-bool greedy_order_128(const Network &net, const std::vector<Bits> &f, const Bits &hidden, std::vector<int32_t> &order,
-                      double abort_above) {
-    const int n = net.n_vars;
-    B2 adj[128];
-    for (int v = 0; v < n; ++v) adj[v] = B2{};
-    for (auto &s : f) {
-        const B2 sc{s.w[0], s.w[1]};
-        b2_each(sc, [&](int v) { adj[v].a |= sc.a; adj[v].b |= sc.b; });
-    }
-    for (int v = 0; v < n; ++v) adj[v].clr(v);
-    int32_t hid[128];
-    int n_alive = 0;
-    b2_each(B2{hidden.w[0], hidden.w[1]}, [&](int v) { hid[n_alive++] = v; });
-    double ws[128];
-    int miss[128];
-    bool alive[128];
-    for (int v = 0; v < n; ++v) alive[v] = false;
-    auto full = [&](int x) {
-        const B2 ax = adj[x];
-        double w = 0;
-        int missing = 0;
-        b2_each(ax, [&](int y) {
-            w += net.log2card[y];
-            missing += __builtin_popcountll(ax.a & ~adj[y].a) + __builtin_popcountll(ax.b & ~adj[y].b) - 1;
-        });
-        ws[x] = w;
-        miss[x] = missing;
-    };
-    for (int i = 0; i < n_alive; ++i) { full(hid[i]); alive[hid[i]] = true; }
-    order.clear();
-    const int total = n_alive;
-    double created = 0;
-    for (int it = 0; it < total; ++it) {
-        int best = -1;
-        double wbest = 0;
-        int k = 0;
-        for (int i = 0; i < n_alive; ++i) {
-            const int x = hid[i];
-            if (!alive[x]) continue;
-            hid[k++] = x;
-            const double wx = miss[x] * 64.0 + ws[x];
-            if (best < 0 || wx < wbest - 1e-12 ||
-                (std::fabs(wx - wbest) <= 1e-12 &&
-                 (net.depth[x] < net.depth[best] || (net.depth[x] == net.depth[best] && x < best)))) {
-                best = x;
-                wbest = wx;
-            }
-        }
-        n_alive = k;
-        order.push_back(best);
-        alive[best] = false;
-        created += std::exp2(ws[best]);  // cells of the factor this elimination creates (its scope = the neighbours)
-        if (16.0 * created > abort_above) return false;
-        const B2 nb = adj[best];
-        b2_each(nb, [&](int y) {
-            B2 fresh{nb.a & ~adj[y].a, nb.b & ~adj[y].b};  // members of nb not yet adjacent to y
-            fresh.clr(y);
-            b2_each(fresh, [&](int u) {
-                if (u < y) return;
-                B2 common{adj[y].a & adj[u].a & ~nb.a, adj[y].b & adj[u].b & ~nb.b};
-                common.clr(best);
-                b2_each(common, [&](int z) { miss[z] -= 2; });
-            });
-        });
-        b2_each(nb, [&](int y) {
-            adj[y].a |= nb.a;
-            adj[y].b |= nb.b;
-            adj[y].clr(best);
-            adj[y].clr(y);
-        });
-        b2_each(nb, [&](int y) { if (alive[y]) full(y); });
-    }
-    return true;
-}
-
+// Networks of more than 128 variables (order_search.h handles the others, on the host and on the device).
 // Greedy min-fill elimination order on the interaction graph: eliminate the vertex whose elimination adds the
 // fewest edges, ties by the size of the factor it creates, then by depth and id.  The fill counts are maintained
 // incrementally: eliminating a vertex changes the neighbourhood of its neighbours (recomputed) and connects pairs
 // of them - every common neighbour of a newly connected pair loses that pair from its fill count.
 bool greedy_order(const Network &net, const std::vector<Bits> &f, const Bits &hidden, std::vector<int32_t> &order, double abort_above) {
     const int n = net.n_vars, nw = net.nw;
-    if (n <= 128) return greedy_order_128(net, f, hidden, order, abort_above);
+    (void)abort_above;  // (networks above 128 variables: the generic bit sets, no lower-bound abort)
     Scratch &S = scratch();
     S.adj.assign(n, Bits{});
     for (auto &a : S.adj) a.nw = nw;
@@ -1266,8 +1148,10 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
         f.src = v;
         f.cells = cells;
         live.push_back((int)pool.size() - 1);
-        scopes.push_back(f.scope);
-        scells.push_back((double)cells);
+        if (net.n_vars > 128) {
+            scopes.push_back(f.scope);
+            scells.push_back((double)cells);
+        }
     });
     if (!err.empty()) return err;
     // single-state variables carry no information: they are never axes, never eliminated
@@ -1284,7 +1168,15 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
         const double c = simulate(net, scopes, scells, cand, best_cost);
         if (c < best_cost) { best_cost = c; best.swap(cand); }
     };
-    if (hidden.any()) {
+    if (rq.n_order >= 0) {
+        // the order was found by the device order search (same code, order_search.h)
+        best.assign(rq.order, rq.order + rq.n_order);
+    } else if (net.n_vars <= 128) {
+        PROF(1);
+        OrderScratch &OS = order_scratch();
+        order_search(net.order_view(), OS, rq.nq, rq.qvars, rq.ne, rq.evars, rq.no_prune);
+        best.assign(OS.best, OS.best + OS.n_best);
+    } else if (hidden.any()) {
         int qdepth = std::numeric_limits<int>::max();
         for (int i = 0; i < rq.nq; ++i) qdepth = std::min(qdepth, (int)net.depth[rq.qvars[i]]);
         // the candidate sweeps are the hidden variables in the order of a per-network sorted list (Network::set /
@@ -1486,6 +1378,18 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
 // Byte model of the cheaper sweep order of one request (no emission, no min-fill search): what mibn_estimate_costs
 // reports for shard balancing.
 static double sweep_cost(const Network &net, const Request &rq) {
+    if (net.n_vars <= 128) {
+        OrderScratch &OS = order_scratch();
+        const OrderNet on = net.order_view();
+        B2 rel, hidden;
+        order_prepare(on, OS, rq.nq, rq.qvars, rq.ne, rq.evars, rq.no_prune, rel, hidden);
+        int qdepth = std::numeric_limits<int>::max();
+        for (int i = 0; i < rq.nq; ++i) qdepth = std::min(qdepth, (int)net.depth[rq.qvars[i]]);
+        order_sweep(on, OS, hidden, qdepth, 0);
+        double best = order_simulate(on, OS, OS.cand, OS.n_cand, std::numeric_limits<double>::infinity());
+        order_sweep(on, OS, hidden, qdepth, 1);
+        return std::min(best, order_simulate(on, OS, OS.cand, OS.n_cand, best));
+    }
     Scratch &S = scratch();
     Bits rel, qb, eb;
     rel.nw = qb.nw = eb.nw = net.nw;
@@ -1762,7 +1666,8 @@ PlanCache &plan_cache(const TemplateStore *ts) {
 
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
-                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck, bool no_prune) {
+                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck, bool no_prune,
+                const uint8_t *orders, const int32_t *order_len) {
     const int64_t n = b1 - b0;
     const int T = pool.size();
     if ((int)bufs.size() < T) bufs.resize(T);
@@ -1809,6 +1714,7 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             rq.ecodes = e_codes + e_off[b];
             rq.out_off = out_off[b] - out_off[b0];
             rq.no_prune = no_prune;
+            if (orders) { rq.order = orders + (size_t)i * 128; rq.n_order = order_len[i]; }
             PlanStats st;
             // plan templates (see above): probe at the start of every window, stay on while shapes repeat
             PlanCache *pc = store ? &plan_cache(store) : nullptr;

@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include "order_search.h"
+
 namespace mibn {
 
 constexpr int kMaxVars = 1024;            // bitset capacity
@@ -57,6 +59,10 @@ struct Network {
     std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier); install with set_hints()
     std::vector<std::vector<int32_t>> hint_sorted;  // every hint as a variable list in ascending (priority, id) order
     std::vector<int32_t> topo_asc, topo_desc;    // all variables by (depth ascending, id) / (depth descending, id)
+    // networks of up to 128 variables: what the shared host / device order search reads (order_search.h)
+    std::vector<B2> anc2, scope2;
+    std::vector<int32_t> hint_flat;
+    OrderNet order_view() const;
     int nw = 1;
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
@@ -84,6 +90,8 @@ struct Request {
     const int32_t *ecodes = nullptr;  // may be null for plan-only statistics
     int64_t out_off = 0;              // offset (doubles) into the batch result buffer
     bool no_prune = false;            // MIBN_Q_NOPRUNE: every CPT takes part (full_joint_dist / predict_proba, bayes_net.py:460)
+    const uint8_t *order = nullptr;   // elimination order found elsewhere (the device order search), n_order entries
+    int32_t n_order = -1;             // -1: search on the host
 };
 
 struct PlanStats {
@@ -212,7 +220,8 @@ struct BatchPlan {
 };
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
-                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &bp, bool no_prune = false);
+                const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &bp, bool no_prune = false,
+                const uint8_t *orders = nullptr, const int32_t *order_len = nullptr);  // orders[(b - b0) * 128 ..]: device order search
 
 // Shard-balancing estimate (mibn_estimate_costs): section-8(d) bytes of the cheaper of the two sweep orders of every
 // request of a CSR batch - the byte model only, nothing is emitted.

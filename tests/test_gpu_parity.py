@@ -271,6 +271,44 @@ def test_schedule_and_effort_options_do_not_change_answers(amd):
     assert float(np.max(np.abs(sweeps - base))) <= 1e-12
 
 
+def test_device_order_search_reproduces_the_host_search(amd):
+    """Option gpu_search: the elimination-order search runs as a kernel (order_kernel: one request per lane, the very
+    code of csrc/order_search.h that the host runs).  Same orders => same programs => the same posteriors bit for bit
+    and the same planned bytes - on the C3 stream and on random DAGs with mixed cardinalities (non-power-of-two cards:
+    the floating-point tie-breaks of the min-fill search must agree too)."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 8192, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    host = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    host_bytes = be.engine.stats()["alg_bytes"]
+    for mode, chunk in ((2, 16384), (1, 2048)):  # 2: every chunk on the device; 1: first chunk on the host, the rest by one launch
+        be.engine.set_option("gpu_search", mode)
+        be.engine.set_option("chunk", chunk)
+        dev = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+        assert be.engine.stats()["alg_bytes"] == host_bytes
+        assert np.array_equal(dev, host), mode
+    be.engine.set_option("chunk", 16384)
+    be.engine.set_option("gpu_search", 2)
+    # two query variables, no-prune flag
+    from sorobn_amd import _capi
+    two = be.engine.query_fixed(to_var[np.stack([q[:512], ev[:512, 0]], 1)], to_var[ev[:512, 1:]], ec[:512, 1:], flags=_capi.Q_NOPRUNE)
+    be.engine.set_option("gpu_search", 0)
+    assert np.array_equal(two, be.engine.query_fixed(to_var[np.stack([q[:512], ev[:512, 0]], 1)], to_var[ev[:512, 1:]], ec[:512, 1:], flags=_capi.Q_NOPRUNE))
+    for fname in ("random_dags.json", "wide_cards.json"):
+        for net in gu.load(fname):
+            b = netspec.build(net["spec"], amd.BayesNet)
+            b.backend.engine.set_option("tiny", 0)
+            reqs = [(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in net["requests"]]
+            want = b.query_many(reqs)
+            b.backend.engine.set_option("gpu_search", 2)
+            got = b.query_many(reqs)
+            for a, w in zip(got, want):
+                assert a.index.equals(w.index) and np.array_equal(a.to_numpy(), w.to_numpy())
+            _check_requests(b, net["requests"], net["spec"]["name"] + " gpu_search")
+
+
 def test_plan_templates_same_posteriors(amd):
     """A stream that repeats 40 request shapes with changing evidence values: answered from plan templates (default)
     and with every request planned (plan_cache=0) - the same programs, so the same posteriors bit for bit."""
