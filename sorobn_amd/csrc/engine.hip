@@ -732,7 +732,10 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     if (h->adaptive) {
         // over the calls since the last adjustment: host planning wall time against GPU kernel time (retired launches)
         const double dp = h->total.plan_ms - h->seen_plan_ms, dk = h->total.kernel_ms - h->seen_kernel_ms;
-        if (dp > 20.0 && dk > 20.0) {
+        if (h->call_id <= 2) {  // the first calls pay one-time costs (thread pool, pinned buffers, first kernel load): not a trend
+            h->seen_plan_ms = h->total.plan_ms;
+            h->seen_kernel_ms = h->total.kernel_ms;
+        } else if (dp > 20.0 && dk > 20.0) {
             if (dp > 1.15 * dk) {
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
                 // not cover give up the min-fill search for ever more expensive requests instead

@@ -1016,8 +1016,8 @@ struct Emitter {
     // written to `out`.  fiber_only: emit nothing and return false unless the step fits the FIBER form (used to try
     // the joint elimination of two variables).
     bool emit(const PF *const *ins, int n_in, const int *X, int nx, bool final_, int64_t final_off, PF &out, bool fiber_only) {
-        out.scope = Bits{};
-        out.scope.nw = net.nw;
+        out.scope.nw = net.nw;  // (only the words the network uses: the rest of a pool entry's scope is never read)
+        for (int k = 0; k < net.nw; ++k) out.scope.w[k] = 0;
         for (int j = 0; j < n_in; ++j) out.scope.or_(ins[j]->scope);
         for (int k = 0; k < nx; ++k) out.scope.clr(X[k]);
         int na = 0;
@@ -1262,6 +1262,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
                 if (!f(k * 64 + __builtin_ctzll(m))) return;
         }
     };
+    const double log2_small = std::log2((double)net.small_cells), log2_big = std::log2((double)net.big_iters);
     auto consume = [&](const PF *f) {
         const int idx = (int)(f - pool.data());
         alive[idx >> 6] &= ~(1ull << (idx & 63));
@@ -1318,7 +1319,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
             u.nw = net.nw;
             for (int j = 0; j < n_in; ++j) { link = link || ins[j]->scope.test(x2); u.or_(ins[j]->scope); }
             if (link && net.card[x] * net.card[x2] <= kMaxCx &&
-                scope_log2(net, u) - net.log2card[x] > std::log2((double)net.small_cells)) {
+                scope_log2(net, u) - net.log2card[x] > log2_small) {
                 int n2 = n_in;
                 bool fits = true;
                 each_with(x2, -1, [&](int idx) {
@@ -1340,7 +1341,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
                     double nc = 1;
                     nvars.for_each([&](int v) { if (v != x && v != x2 && nc * net.card[v] <= kMaxNC) nc *= net.card[v]; });
                     const double out_log2 = scope_log2(net, u) - net.log2card[x] - net.log2card[x2];
-                    if (nbig < 1 || nbig > 2 || out_log2 < std::log2((double)net.big_iters)) fits = false;
+                    if (nbig < 1 || nbig > 2 || out_log2 < log2_big) fits = false;
                 }
                 if (fits) {
                     const int X[2] = {x, x2};
