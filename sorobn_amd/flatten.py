@@ -18,11 +18,33 @@ import pandas as pd
 
 class FlatNetwork:
     __slots__ = ("names", "id", "domains", "dom_index", "card", "scope", "scope_off",
-                 "scope_vars", "value_off", "values", "present", "hints", "missing", "parents")
+                 "scope_vars", "value_off", "values", "present", "hints", "missing", "parents", "_lut")
 
     def code_of(self, var_id, label):
         """Evidence labels match by Python equality (`get_level_values(var) == val`,
         bayes_net.py:774), so 1 matches True; -1 when the label is outside the domain."""
+        # hashable labels: one dict lookup (equal labels hash equally - 1, 1.0 and True share a slot); anything the
+        # dict cannot answer falls through to the equality scan
+        try:
+            lut = self._lut
+        except AttributeError:
+            lut = self._lut = {}
+        table = lut.get(var_id)
+        if table is None:
+            table = {}
+            try:
+                for i, d in enumerate(self.domains[var_id]):
+                    table.setdefault(d, i)
+            except TypeError:
+                table = False
+            lut[var_id] = table
+        if table is not False:
+            try:
+                hit = table.get(label)
+                if hit is not None:
+                    return hit
+            except TypeError:
+                pass
         for i, d in enumerate(self.domains[var_id]):
             try:
                 if d == label:
