@@ -295,10 +295,15 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
     return 0;
 }
 
-extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
-                              const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
-                              int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars, const int32_t *ecodes,
-                              double *out, double *stats /* bytes, flops, steps, max_cells, arena_cells */) {
+// A CSR batch of requests through the product's batch planner (`threads` workers) and level-synchronous scheduler
+// (`stagger` groups), executed exactly as the level kernel sees it: level by level, workgroup by workgroup, every
+// workgroup looking its item up in wg_item and deriving its tile from (workgroup index - Item::b); every request in its
+// own arena.  out[out_off[b] ..) receives the dense posterior of request b.
+extern "C" int plan_sim_query_batch(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                                    const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
+                                    int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
+                                    const int32_t *e_codes, const int64_t *out_off, double *out, int32_t stagger, int32_t threads,
+                                    double *stats /* bytes, flops, steps, max_cells, arena_cells */) {
     Network net;
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
@@ -308,58 +313,70 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
     net.fuse = g_fuse;
     net.chain = g_chain;
     net.prune = g_prune;
+    net.stagger = stagger;
     net.set_hints(n_hints, hints);
-    // one-request batch through the product's batch planner and level-synchronous scheduler
-    int64_t q_off[2] = {0, nq}, e_off[2] = {0, ne}, out_off[2] = {0, 1};
-    for (int i = 0; i < nq; ++i) out_off[1] *= card[qvars[i]];
-    Request rq;
-    rq.nq = nq; rq.qvars = qvars; rq.ne = ne; rq.evars = evars;
-    g_err = validate_request(net, rq);
-    if (!g_err.empty()) return -1;
-    for (int64_t i = 0; i < out_off[1]; ++i) out[i] = 0.0;
-    char skip = 0;
-    for (int i = 0; i < ne; ++i)
-        if (ecodes[i] < 0 || ecodes[i] >= card[evars[i]]) skip = 1;  // label outside the domain: empty posterior
-    ThreadPool pool(1);
+    std::vector<char> skip((size_t)B, 0);
+    for (int64_t b = 0; b < B; ++b) {
+        Request rq;
+        rq.nq = (int32_t)(q_off[b + 1] - q_off[b]); rq.qvars = q_vars + q_off[b];
+        rq.ne = (int32_t)(e_off[b + 1] - e_off[b]); rq.evars = e_vars + e_off[b];
+        g_err = validate_request(net, rq);
+        if (!g_err.empty()) return -1;
+        for (int i = 0; i < rq.ne; ++i) {
+            const int32_t c = e_codes[e_off[b] + i];
+            if (c < 0 || c >= card[rq.evars[i]]) skip[(size_t)b] = 1;  // label outside the domain: empty posterior
+        }
+    }
+    for (int64_t i = out_off[0]; i < out_off[B]; ++i) out[i] = 0.0;
+    ThreadPool pool(std::max(1, threads));
     std::vector<ProgBuf> bufs;
     BatchPlan bp;
-    const int32_t zero = 0;
-    plan_batch(net, pool, bufs, 0, 1, q_off, qvars, e_off, ne ? evars : &zero, ne ? ecodes : &zero, out_off, &skip, bp);
+    plan_batch(net, pool, bufs, 0, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), bp);
     g_err = bp.err;
     if (!g_err.empty()) { for (auto &b : bufs) b.release(); return -6; }
     if (stats) { stats[0] = bp.st.alg_bytes; stats[1] = bp.st.alg_flops; stats[2] = bp.st.n_steps; stats[3] = bp.st.max_step_cells; stats[4] = (double)bp.arena_cells; }
     Schedule sc;
-    build_schedule(net, bp, bufs, 0, 1, sc);
+    build_schedule(net, bp, bufs, 0, B, sc);
     std::vector<double> arena((size_t)sc.arena_cells + 16, -1e300);  // poison: reading unwritten scratch shows up
-    const uint32_t *prog = bufs[0].data + bp.local_off[0];
+    double *res = out + out_off[0];  // the programs address the result buffer relative to the batch's first cell
     int rc = 0;
     double bytes_check = 0;
-    // Execute the schedule exactly as the level kernel sees it: level by level, workgroup by workgroup, every
-    // workgroup looking its item up in wg_item and deriving its tile from (workgroup index - Item::b).
     size_t wg_seen = 0;
+    int last_level = -1;
+    std::vector<int> req_level((size_t)B, -1);  // dependencies: the items of a request run in strictly increasing levels
     for (const Launch &L : sc.launches) {
         bytes_check += L.alg_bytes;
         if (L.wg_first != wg_seen) { g_err = "launches do not tile wg_item"; rc = -11; break; }
+        if (L.level < last_level) { g_err = "launches out of level order"; rc = -11; break; }
+        last_level = L.level;
         wg_seen += L.grid;
         for (size_t wgi = L.wg_first; wgi < L.wg_first + L.grid && rc == 0; ++wgi) {
             const uint32_t k = sc.wg_item[wgi];
             if (k < L.first || k >= L.first + L.count) { g_err = "workgroup mapped to an item of another launch"; rc = -11; break; }
             const Item &it = sc.items[k];
+            if (it.req >= (uint32_t)B) { g_err = "item of an unknown request"; rc = -11; break; }
             const uint32_t wg = (uint32_t)(wgi - L.wg_level);  // level-relative index = blockIdx.x + wg_base
+            const uint32_t *prog = bufs[(size_t)bp.thread_of[it.req]].data + bp.local_off[it.req];
             const uint32_t *p = prog + it.rel_off;
+            const int64_t need = bp.arena_need[it.req];
+            const bool first_wg = (it.a & kItemSegment) || wg == it.b;
+            if (first_wg) {
+                if (req_level[it.req] >= L.level) { g_err = "two items of a request in one level"; rc = -11; break; }
+                req_level[it.req] = L.level;
+            }
             if (it.a & kItemSegment) {
                 if (L.kid != kKidSeg || it.b != wg) { g_err = "segment item inconsistent"; rc = -11; break; }
                 const uint32_t n_steps = it.a & ~kItemSegment;
                 for (uint32_t s = 0; s < n_steps && rc == 0; ++s) {
                     if ((p[0] & 0xff) != kKindGeneric) { g_err = "FIBER step inside a segment"; rc = -10; break; }
-                    rc = exec_step(net, p, 0, p[3], arena, (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
+                    rc = exec_step(net, p, 0, p[3], arena, (int64_t)sc.arena_off[it.req], need, res);
                     if (rc == 0 && ((p[1] >> 16) & kFlagFinal)) {
                         const uint64_t oo = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
                         const int64_t cells = (int64_t)p[2] * (int64_t)p[3];
                         double total = 0;
-                        for (int64_t i = 0; i < cells; ++i) total += out[oo + i];
+                        for (int64_t i = 0; i < cells; ++i) total += res[oo + i];
                         if (total > 0)
-                            for (int64_t i = 0; i < cells; ++i) out[oo + i] /= total;
+                            for (int64_t i = 0; i < cells; ++i) res[oo + i] /= total;
                     }
                     p += p[6];
                 }
@@ -376,17 +393,29 @@ extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t
                         if (wgi + t >= sc.wg_item.size() || sc.wg_item[wgi + t] != k) { g_err = "item does not own all of its tiles"; rc = -11; break; }
                     if (rc == 0 && wgi + tiles < L.wg_first + L.grid && sc.wg_item[wgi + tiles] == k) { g_err = "item owns too many workgroups"; rc = -11; }
                 }
-                if (rc == 0) rc = exec_step(net, p, h0, h1, arena, (int64_t)sc.arena_off[it.req], bp.arena_need[0], out);
+                if (rc == 0) rc = exec_step(net, p, h0, h1, arena, (int64_t)sc.arena_off[it.req], need, res);
             }
         }
     }
     if (rc == 0 && wg_seen != sc.wg_item.size()) { g_err = "launches do not cover wg_item"; rc = -11; }
-    if (rc == 0 && !skip && std::fabs(bytes_check - bp.st.alg_bytes) > 64.0 * bp.st.n_steps + 1e-9 * bp.st.alg_bytes) {
+    if (rc == 0 && std::fabs(bytes_check - bp.st.alg_bytes) > 64.0 * bp.st.n_steps + 1e-9 * bp.st.alg_bytes) {
         g_err = "schedule bytes do not add up to the plan's algorithmic bytes";
         rc = -12;
     }
     for (auto &b : bufs) b.release();
     return rc;
+}
+
+extern "C" int plan_sim_query(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                              const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
+                              int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars, const int32_t *ecodes,
+                              double *out, double *stats /* bytes, flops, steps, max_cells, arena_cells */) {
+    // a one-request batch
+    int64_t q_off[2] = {0, nq}, e_off[2] = {0, ne}, out_off[2] = {0, 1};
+    for (int i = 0; i < nq; ++i) out_off[1] *= card[qvars[i]];
+    const int32_t zero = 0;
+    return plan_sim_query_batch(n_vars, card, scope_off, scope_vars, value_off, values, n_hints, hints, 1, q_off, qvars, e_off,
+                                ne ? evars : &zero, ne ? ecodes : &zero, out_off, out, 1, 1, stats);
 }
 
 // debugging aid: return the raw step program of one request (words copied into `out`, count returned)

@@ -26,6 +26,8 @@ def lib():
         i32p, i64p, f64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
         L.plan_sim_query.argtypes = [C.c_int32, i32p, i64p, i32p, i64p, f64p, C.c_int32, i32p,
                                      C.c_int32, i32p, C.c_int32, i32p, i32p, f64p, f64p]
+        L.plan_sim_query_batch.argtypes = [C.c_int32, i32p, i64p, i32p, i64p, f64p, C.c_int32, i32p, C.c_int64, i64p, i32p, i64p,
+                                           i32p, i32p, i64p, f64p, C.c_int32, C.c_int32, f64p]
         L.plan_sim_error.restype = C.c_char_p
         L.plan_sim_set_small_cells.argtypes = [C.c_int]
         L.plan_sim_set_tiling.argtypes = [C.c_int, C.c_int]
@@ -75,6 +77,41 @@ class SimEngine:
             raise RuntimeError(f"plan_sim_query rc={rc}: {L.plan_sim_error().decode()}")
         self.last_stats = stats
         return out
+
+    def batch(self, qvars, evars, ecodes, stagger=1, threads=1):
+        """Fixed-shape batch through ONE plan_batch + build_schedule (multi-request levels, `stagger` groups, `threads`
+        planning workers), executed level by level like the kernel: posteriors [B, cells]."""
+        f = self.f
+        L = lib()
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        qvars = np.ascontiguousarray(qvars, np.int32).reshape(len(qvars), -1)
+        B, nq = qvars.shape
+        evars = np.ascontiguousarray(evars, np.int32).reshape(B, -1)
+        ecodes = np.ascontiguousarray(ecodes, np.int32).reshape(B, -1)
+        ne = evars.shape[1]
+        q_off = np.arange(B + 1, dtype=np.int64) * nq
+        e_off = np.arange(B + 1, dtype=np.int64) * ne
+        cells = np.prod(f.card[qvars].astype(np.int64), axis=1)
+        out_off = np.concatenate([[0], np.cumsum(cells)]).astype(np.int64)
+        out = np.zeros(int(out_off[-1]), np.float64)
+        stats = np.zeros(5, np.float64)
+        hints = np.ascontiguousarray(self.hints.reshape(-1) if self.hints.size else [0], np.int32)
+        L.plan_sim_set_small_cells(int(self.small_cells))
+        L.plan_sim_set_tiling(int(self.tiling[0]), int(self.tiling[1]))
+        L.plan_sim_set_fuse(int(self.fuse))
+        L.plan_sim_set_prune(int(self.prune))
+        L.plan_sim_set_chain(int(self.chain))
+        ev_ = evars.reshape(-1) if ne else np.zeros(1, np.int32)
+        ec_ = ecodes.reshape(-1) if ne else np.zeros(1, np.int32)
+        rc = L.plan_sim_query_batch(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64), p(f.scope_vars, C.c_int32),
+                                    p(f.value_off, C.c_int64), p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
+                                    B, p(q_off, C.c_int64), p(qvars.reshape(-1), C.c_int32), p(e_off, C.c_int64), p(ev_, C.c_int32),
+                                    p(ec_, C.c_int32), p(out_off, C.c_int64), p(out, C.c_double), int(stagger), int(threads),
+                                    p(stats, C.c_double))
+        if rc != 0:
+            raise RuntimeError(f"plan_sim_query_batch rc={rc}: {L.plan_sim_error().decode()}")
+        self.last_stats = stats
+        return out.reshape(B, -1)
 
     def set_option(self, name, value):
         if name == "prune":

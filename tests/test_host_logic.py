@@ -713,3 +713,30 @@ def test_examples_module_and_graph_helpers_match_the_reference():
     wiki = [(0, 3), (1, 4), (2, 5), (3, 6), (4, 6), (5, 8), (6, 8), (6, 9), (7, 9), (7, 10), (8, 11), (8, 12)]
     assert sorobn_amd.BayesNet(*wiki).markov_boundary(6) == [3, 4, 5, 7, 8, 9]  # bayes_net.py:1015-1031
     assert sorobn_amd.BayesNet(("a", "b"), ("a", "c")).is_tree and not sorobn_amd.BayesNet(("a", "c"), ("b", "c")).is_tree
+
+
+def test_multi_request_schedule_stagger_and_threads_on_the_simulator():
+    """The level-synchronous schedule of a whole chunk - items of many requests bucketed per (level, class of work),
+    the workgroup -> item table, private arenas - executed by the simulator the way the level kernel sees it, with the
+    invariants checked (one item of a request per level, tiles covered exactly once, bytes add up): with the requests in
+    phase, with 2 / 3 / 5 staggered groups (option `stagger`) and planned by 1 or 3 workers - always the posteriors of
+    the one-request-at-a-time path, bit for bit (same programs, another launch order)."""
+    for R, C, small_cells, tiling in ((6, 6, 1024, (4096, 0)), (6, 6, 20, (64, 2)), (5, 7, 3, (4, 1))):
+        spec = netspec.grid_spec(R, C, 4, seed=R * 10 + C)
+        bn = netspec.build(spec, sorobn_amd.BayesNet)
+        f = flatten(bn)
+        n = R * C
+        sim = simengine.SimEngine(f, small_cells=small_cells, tiling=tiling)
+        q, ev, ec = netspec.c3_requests(n, 4, 96, 3, seed=2)
+        to_var = np.array([f.id[f"{i:03d}"] for i in range(n)], np.int32)
+        Q, E = to_var[q][:, None], to_var[ev]
+        one_by_one = sim.query_fixed(Q, E, ec)
+        assert np.allclose(one_by_one.sum(1), 1.0, atol=1e-12)
+        for stagger, threads in ((1, 1), (2, 1), (3, 3), (5, 2)):
+            got = sim.batch(Q, E, ec, stagger=stagger, threads=threads)
+            assert np.array_equal(got, one_by_one), (R, C, small_cells, stagger, threads)
+    # out-of-domain evidence inside a batch: that request's posterior stays all-zero, its neighbours are untouched
+    ec2 = ec.copy()
+    ec2[5, 0] = 7
+    got = sim.batch(Q, E, ec2, stagger=2, threads=2)
+    assert not got[5].any() and np.array_equal(np.delete(got, 5, 0), np.delete(one_by_one, 5, 0))
