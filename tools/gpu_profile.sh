@@ -7,7 +7,7 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-configs"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-configs --no-adaptive"
 nproc > $OUT/${TAG}_nproc.txt; lscpu | head -20 >> $OUT/${TAG}_nproc.txt
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o trace -- $CMD > $OUT/${TAG}_trace.log 2>&1
