@@ -9,8 +9,11 @@
 // the table offset, the variable's stride and the (other variable, stride) pairs.  An update computes each
 // factor's base offset once from the chain state and then the card x n_factors table values as independent
 // loads, the weights stay in registers (cards up to 16; larger cards take a two-pass loop).  The kernel is
-// latency-bound by construction (config 5 = 128 chains = 2 waves per GPU).  Random numbers: Philox4x32-10 keyed
-// by (seed, chain), counter = update index; statistical parity only (see include/mibn.h).
+// latency-bound by construction (config 5 = 128 chains = 2 waves per GPU): what counts is the number of dependent
+// memory round trips per update.  Tables, update programs and chain state all sit in LDS when they fit, and grids take
+// the FAST form - fixed-size update records fetched one iteration ahead, the state reads of all factors issued
+// together, then all table reads (config 5: 2.38 -> 1.16 us per update, same counts bit for bit).  Random numbers:
+// Philox4x32-10 keyed by (seed, chain), counter = update index; statistical parity only (see include/mibn.h).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -61,12 +64,15 @@ struct GibbsArgs {
     unsigned long long *counts;   // global histogram
     int32_t n_vars, n_cycle, n_q, hist_cells;
     int32_t pool_cells;           // doubles in `pool` (the LDS-resident variant copies them all)
+    int32_t prog_words;           // words of uprog + uprog_off + cycle when they are copied to LDS too (else 0)
+    int32_t uprog_words;          // words of uprog alone
     int64_t n_chains, n_iterations;
     int64_t chain_first;          // global index of this launch's first chain (shards of one stream: mibn_gibbs_shard)
     uint64_t seed;
 };
 
 constexpr int kGibbsWaves = 1;  // waves per workgroup (each wave = 64 independent chains)
+constexpr int kFastWords = 28;  // words of one cycle position's update record in the FAST format (gibbs_kernel)
 
 // weight of value x of variable v given the rest of the lane's state
 template <typename PoolPtr>
@@ -94,7 +100,13 @@ __device__ __forceinline__ double gibbs_weight(const GibbsArgs &A, PoolPtr pool,
 // POOL_LDS: every CPT is copied into LDS first (config 5: 154 KB of tables + 3 KB of chain state in the 160 KB of a
 // CU), so the card x n_factors table reads of an update are ds_read_b64 instead of L2 round trips - the update chain is
 // latency-bound and few chains (config 5: 2 waves per GPU) cannot hide it with occupancy.
-template <bool POOL_LDS>
+// PROG_LDS: the update programs, their offsets and the cycle are copied into LDS as well (config 5: 4.4 KB beside the
+// 154 KB of tables) - read from global memory they are a chain of dependent scalar loads per factor, most of the 2.4 us
+// an update took; from LDS the same words cost a broadcast read each.
+// FAST (with POOL_LDS and PROG_LDS; every variable of the cycle has at most 8 states, 4 factors and factors with at most
+// two other variables - grids): fixed-size update records, so that the state reads of all factors, then all their table
+// reads, are issued together instead of factor after factor - the update is a handful of dependent LDS round trips.
+template <bool POOL_LDS, bool PROG_LDS, bool FAST = false>
 __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -103,6 +115,20 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
     double *lds_pool = (double *)(smem + ((((A.n_vars * 64 + 15) & ~15) + A.hist_cells * 4 + 15) & ~15));
     if (POOL_LDS)
         for (int i = threadIdx.x; i < A.pool_cells; i += blockDim.x) lds_pool[i] = A.pool[i];
+    if (FAST && threadIdx.x == 0) lds_pool[A.pool_cells] = 1.0;  // the table of an unused factor slot
+    // uprog | uprog_off | cycle (FAST: 16-byte aligned records of kFastWords words, one per cycle position, nothing else)
+    int32_t *lds_prog = FAST ? (int32_t *)((unsigned char *)lds_pool + (((size_t)(A.pool_cells + 1) * 8 + 15) & ~size_t(15)))
+                             : (int32_t *)(lds_pool + (POOL_LDS ? A.pool_cells : 0));
+    if (PROG_LDS) {
+        for (int i = threadIdx.x; i < A.uprog_words; i += blockDim.x) lds_prog[i] = A.uprog[i];
+        for (int i = threadIdx.x; i < (FAST ? 0 : A.n_cycle); i += blockDim.x) {
+            lds_prog[A.uprog_words + i] = A.uprog_off[i];
+            lds_prog[A.uprog_words + A.n_cycle + i] = A.cycle[i];
+        }
+    }
+    const int32_t *uprog = PROG_LDS ? lds_prog : A.uprog;
+    const int32_t *uprog_off = PROG_LDS ? lds_prog + A.uprog_words : A.uprog_off;
+    const int32_t *cycle = PROG_LDS ? lds_prog + A.uprog_words + A.n_cycle : A.cycle;
     const int64_t local = (int64_t)blockIdx.x * 64 + lane;
     const int64_t chain = A.chain_first + local;  // the Philox key follows the global index: shards reproduce the whole
     const bool active = local < A.n_chains;
@@ -132,20 +158,85 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
     }
     __syncthreads();
 
+    int qv4[4] = {0, 0, 0, 0}, qs4[4] = {0, 0, 0, 0};  // (unused slots: variable 0 with stride 0)
+    for (int q = 0; q < 4 && q < A.n_q; ++q) { qv4[q] = A.qvars[q]; qs4[q] = A.qstride[q]; }
     int cyc = 0;
     constexpr int kRegCard = 16;
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 cur[kFastWords / 4];  // FAST: the update record of this iteration, loaded one iteration ahead
+    if (FAST) {
+#pragma unroll
+        for (int q = 0; q < kFastWords / 4; ++q) cur[q] = reinterpret_cast<const i32x4 *>(lds_prog)[q];
+    }
     for (int64_t it = 0; it < A.n_iterations; ++it) {
-        const int v = A.cycle[cyc];
-        const int32_t *up = A.uprog + A.uprog_off[cyc];
-        cyc = cyc + 1 == A.n_cycle ? 0 : cyc + 1;
-        const int card = up[0], nf = up[1];
-        up += 2;
-        if (card <= kRegCard) {
+        int v, card, nf = 0;
+        const int32_t *up = nullptr;
+        i32x4 rec[kFastWords / 4];
+        if (FAST) {
+            // [v, card, nf, -, then four records of (table base, stride of v, other variable 0, its stride, other variable 1,
+            // its stride)]; an unused slot points at the 1.0 behind the tables with all strides 0.  The next position's
+            // record is requested now - before this update's state write, which the compiler must assume aliases it.
+#pragma unroll
+            for (int q = 0; q < kFastWords / 4; ++q) rec[q] = cur[q];
+            cyc = cyc + 1 == A.n_cycle ? 0 : cyc + 1;
+#pragma unroll
+            for (int q = 0; q < kFastWords / 4; ++q) cur[q] = reinterpret_cast<const i32x4 *>(lds_prog + cyc * kFastWords)[q];
+            v = __builtin_amdgcn_readfirstlane(rec[0][0]);
+            card = __builtin_amdgcn_readfirstlane(rec[0][1]);
+        } else {
+            // (LDS reads return the same word in every lane: readfirstlane keeps the control flow scalar)
+            v = PROG_LDS ? __builtin_amdgcn_readfirstlane(cycle[cyc]) : cycle[cyc];
+            up = uprog + (PROG_LDS ? __builtin_amdgcn_readfirstlane(uprog_off[cyc]) : uprog_off[cyc]);
+            cyc = cyc + 1 == A.n_cycle ? 0 : cyc + 1;
+            card = PROG_LDS ? __builtin_amdgcn_readfirstlane(up[0]) : up[0];
+            nf = PROG_LDS ? __builtin_amdgcn_readfirstlane(up[1]) : up[1];
+            up += 2;
+        }
+        if (FAST) {
+            // the uniform of this update does not depend on the state: computed first, its ~500 integer operations run
+            // under the LDS round trips below instead of after them
+            const double u01 = philox_uniform((uint64_t)it, 0u, k0, k1);
+            int base[4], sv[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int w0 = 4 + 6 * f;
+                auto R = [&](int k) { return rec[(w0 + k) >> 2][(w0 + k) & 3]; };
+                base[f] = R(0) + (int)st[R(2) * 64 + lane] * R(3) + (int)st[R(4) * 64 + lane] * R(5);
+                sv[f] = R(1);
+            }
+            double w[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const bool on = x < card;
+                double p = lds_pool[on ? base[0] + x * sv[0] : A.pool_cells];
+#pragma unroll
+                for (int f = 1; f < 4; ++f) p *= lds_pool[on ? base[f] + x * sv[f] : A.pool_cells];
+                w[x] = p;
+            }
+            double total = 0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                if (x < card) total += w[x];
+            if (total > 0) {
+                const double u = u01 * total;
+                double acc = 0;
+                int val = -1, last = 0;
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+                    if (x < card) {
+                        if (w[x] > 0) last = x;
+                        acc += w[x];
+                        if (val < 0 && u < acc) val = x;
+                    }
+                st[v * 64 + lane] = (uint8_t)(val < 0 ? last : val);
+            }
+        } else if (card <= kRegCard) {
             double w[kRegCard];
 #pragma unroll
             for (int x = 0; x < kRegCard; ++x) w[x] = 1.0;
             for (int f = 0; f < nf; ++f) {
-                const int sv = up[1], no = up[2];
+                const int sv = up[1];
+                const int no = PROG_LDS ? __builtin_amdgcn_readfirstlane(up[2]) : up[2];
                 int base = up[0];
                 for (int k = 0; k < no; ++k) base += (int)st[up[3 + 2 * k] * 64 + lane] * up[4 + 2 * k];
                 up += 3 + 2 * no;
@@ -194,7 +285,12 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
         // record the joint query state (bayes_net.py:732-733: every iteration, no burn-in)
         if (active) {
             int cell = 0;
-            for (int q = 0; q < A.n_q; ++q) cell += (int)st[A.qvars[q] * 64 + lane] * A.qstride[q];
+            if (A.n_q <= 4) {  // the usual case: query variables and strides preloaded (no global loads in the loop)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cell += (int)st[qv4[q] * 64 + lane] * qs4[q];
+            } else {
+                for (int q = 0; q < A.n_q; ++q) cell += (int)st[A.qvars[q] * 64 + lane] * A.qstride[q];
+            }
             atomicAdd(&hist[cell], 1u);
         }
         if ((it & 0xffffff) == 0xffffff) {  // flush before a 32-bit LDS counter can overflow
@@ -289,6 +385,42 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     const size_t lds_with_pool = (lds + 15) / 16 * 16 + pool_cells * 8;
     const bool pool_lds = allow_lds && lds_with_pool <= 160 * 1024 && (n_chains + 63) / 64 <= 512;
     if (pool_lds) lds = lds_with_pool;
+    // fixed-size update records (gibbs_kernel<.., FAST>) when every variable of the cycle qualifies and they still fit
+    bool fast = pool_lds;
+    std::vector<int32_t> fprog;
+    for (size_t ci = 0; ci < cycle.size() && fast; ++ci) {
+        const int v = cycle[ci];
+        if (net.card[v] > 8 || 1 + ch[v].size() > 4) { fast = false; break; }
+        const int32_t head[4] = {v, net.card[v], 1 + (int32_t)ch[v].size(), 0};
+        fprog.insert(fprog.end(), head, head + 4);
+        int slots = 0;
+        auto record = [&](int c) {
+            int32_t rec[6] = {(int32_t)net.pool_off[c], 0, 0, 0, 0, 0};
+            int n_other = 0;
+            for (size_t k = 0; k < net.scope[c].size(); ++k) {
+                const int u = net.scope[c][k];
+                if (u == v) rec[1] = (int32_t)net.cstride[c][k];
+                else if (n_other < 2) { rec[2 + 2 * n_other] = u; rec[3 + 2 * n_other] = (int32_t)net.cstride[c][k]; ++n_other; }
+                else fast = false;
+            }
+            fprog.insert(fprog.end(), rec, rec + 6);
+            ++slots;
+        };
+        record(v);
+        for (int c : ch[v]) record(c);
+        for (; slots < 4; ++slots) {  // unused slots: the 1.0 behind the tables, strides 0
+            const int32_t rec[6] = {(int32_t)pool_cells, 0, 0, 0, 0, 0};
+            fprog.insert(fprog.end(), rec, rec + 6);
+        }
+    }
+    if (fast && (lds + 8 + 15) / 16 * 16 + fprog.size() * 4 > 160 * 1024) fast = false;
+    if (fast) {
+        uprog = fprog;
+        lds += 8;
+    }
+    const size_t prog_words = fast ? uprog.size() : uprog.size() + 2 * cycle.size();
+    const bool prog_lds = fast || (allow_lds && (lds + 15) / 16 * 16 + prog_words * 4 <= 160 * 1024 && (n_chains + 63) / 64 <= 512);
+    if (prog_lds) lds = (lds + 15) / 16 * 16 + prog_words * 4;
 
     GibbsVar *d_vars = nullptr;
     int32_t *d_i32 = nullptr;
@@ -320,6 +452,8 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     A.counts = d_counts;
     A.n_vars = n;
     A.pool_cells = (int32_t)pool_cells;
+    A.uprog_words = (int32_t)uprog.size();
+    A.prog_words = prog_lds ? (int32_t)prog_words : 0;
     A.n_cycle = (int32_t)cycle.size();
     A.n_q = n_q;
     A.hist_cells = (int32_t)cells;
@@ -331,7 +465,9 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const unsigned blocks = (unsigned)((n_chains + 63) / 64);
-    auto kernel = pool_lds ? gibbs_kernel<true> : gibbs_kernel<false>;
+    auto kernel = fast ? gibbs_kernel<true, true, true>
+                       : pool_lds ? (prog_lds ? gibbs_kernel<true, true> : gibbs_kernel<true, false>)
+                                  : (prog_lds ? gibbs_kernel<false, true> : gibbs_kernel<false, false>);
     if (lds > 64 * 1024) {
         if ((e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return fail(e);
     }
