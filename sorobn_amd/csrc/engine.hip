@@ -59,6 +59,12 @@ __global__ __launch_bounds__(64) void order_kernel(const OrderArgs A) {
     A.order_len[b] = S.n_best;
 }
 
+// Chunk sets (pinned program buffers, device copies, schedule, launch events): the host plans chunk k + kChunkSets - 1 at
+// the earliest when chunk k has completed.  With two sets and a call of three chunks the second chunk of a call could only
+// be planned once the previous call had finished - while the GPU ran the short first chunk and then idled 5-12 ms per
+// call (the "[mibn gap]" lines of option trace); with three the planner stays a full chunk ahead.
+constexpr int kChunkSets = 3;
+
 struct mibn_ctx {
     Network net;
     bool has_net = false;
@@ -79,7 +85,7 @@ struct mibn_ctx {
         hipEvent_t done = nullptr;
     } pend[2];
     int next_slot = 0;
-    // double-buffered chunk pipeline: workers plan chunk i+1 into pinned buffers while the GPU runs chunk i
+    // chunk pipeline: workers plan the next chunks into pinned buffers while the GPU runs chunk i
     ThreadPool *pool = nullptr;
     struct Staging {  // pinned host staging: pageable sources would make hipMemcpyAsync block on the stream
         char *p = nullptr;
@@ -104,9 +110,10 @@ struct mibn_ctx {
         std::vector<Timed> timed;
         size_t ev_used = 0;
         bool busy = false;
+        int gap_from = -1;  // trace: index (in mibn_ctx::gap_ev) of the event that closed the previous wave
         BatchPlan plan;
         Schedule sched;
-    } set[2];
+    } set[kChunkSets];
     Staging res_stage[2];  // pinned landing buffers of asynchronous calls
     // small-network specialisation (tiny_kernel.hip.h): one lane per request, no planning
     bool tiny_ok = false;
@@ -140,6 +147,8 @@ struct mibn_ctx {
     size_t order_scratch_cap = 0;
     Staging search_in, search_out;   // pinned: request arrays in, orders + lengths out
     double search_ms = 0;            // host wall time spent waiting for the device search (last call)
+    hipEvent_t gap_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // trace: ends of the last waves (GPU idle time between waves)
+    uint64_t n_waves = 0;
     int set_cursor = 0;    // the chunk set the next chunk plans into: alternates across calls, so that a call of one chunk
                            // plans into the idle set while the previous call's kernels still run from the other one
     uint64_t call_id = 0;  // kernel time retired later is booked to the call that launched it
@@ -502,6 +511,12 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         }
         if (h->trace) std::fprintf(stderr, "[mibn launch] %-32s wgs %8.0f MB %10.2f ms %8.4f -> %7.1f GB/s\n", h->kstats[t.kid].name, t.items, t.bytes / 1e6, ms, t.bytes / ms / 1e6);
     }
+    if (h->trace && st.gap_from >= 0 && st.ev_used > 0) {
+        float gap = 0;
+        if (hipEventElapsedTime(&gap, h->gap_ev[st.gap_from], st.ev[0]) == hipSuccess)
+            std::fprintf(stderr, "[mibn gap] %.3f ms between the end of the previous wave and the first launch of this one\n", gap);
+        st.gap_from = -1;
+    }
     st.timed.clear();
     st.ev_used = 0;
     st.busy = false;
@@ -766,7 +781,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
         const int64_t n = b1 - b0;
         mibn_ctx::Set &st = h->set[h->set_cursor];
-        h->set_cursor ^= 1;
+        h->set_cursor = (h->set_cursor + 1) % kChunkSets;
         if ((rc = retire(h, st))) return rc;  // its buffers are about to be rewritten
         double t0 = now_ms();
         // device order search: the first (short) chunk of a call is searched on the host while one launch searches the
@@ -852,6 +867,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             A.results = d_results + (out_off[b0] - out_off[0]);
             size_t e_prev = 0;
             double n_wg = 0;
+            if (h->trace) st.gap_from = h->n_waves ? (int)((h->n_waves - 1) & 3) : -1;
             if ((rc = next_event(h, st, e_prev))) return rc;
             A.items = st.d_items;
             for (size_t li = 0; li < sc.launches.size();) {
@@ -876,6 +892,12 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 li = lj;
             }
             HIP_TRY(h, hipGetLastError());
+            if (h->trace) {
+                hipEvent_t &ge = h->gap_ev[h->n_waves & 3];
+                if (!ge) HIP_TRY(h, hipEventCreate(&ge));
+                HIP_TRY(h, hipEventRecord(ge, h->stream));
+            }
+            ++h->n_waves;
             st.busy = true;
             h->stats.arena_bytes = std::max(h->stats.arena_bytes, (double)need_bytes);
             h->stats.n_workgroups += n_wg;
