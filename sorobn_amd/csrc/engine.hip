@@ -324,6 +324,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "chunk") h->chunk = std::max<int64_t>(1, (int64_t)value);
     else if (n == "big_iters") h->net.big_iters = std::max<int64_t>(1, (int64_t)value);  // test hooks: force tiling
     else if (n == "tile_h") h->net.tile_h = std::max(0, std::min(kTileMax, (int)value));  // 0 = sized by traffic
+    else if (n == "tile_kb") h->net.tile_bytes = std::max<int64_t>(16, (int64_t)value) << 10;  // traffic per tile when tile_h = 0
     else if (n == "trace") h->trace = (int)value;
     else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;

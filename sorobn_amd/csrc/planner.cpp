@@ -1635,7 +1635,7 @@ uint64_t option_signature(const Network &net) {
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
     mix((uint64_t)net.chain); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
-    mix((uint64_t)net.hints.size());
+    mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }
 
@@ -1883,7 +1883,7 @@ int step_tile_h(const Network &net, const uint32_t *w) {
     // are cache hits, they do not count)
     const int64_t per_iter = std::max<int64_t>(1, step_cost_bytes(w) / std::max<int64_t>(1, (int64_t)w[3]));
     // (CHAIN steps - 256 KiB per iteration - end up with one iteration per tile; 4 per tile measured 11 % slower)
-    return (int)std::max<int64_t>(1, std::min<int64_t>(kTileMax, kTileBytes / per_iter));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(kTileMax, net.tile_bytes / per_iter));
 }
 
 // Order of the classes of work inside a level's launch (workgroups are dispatched in this order): the classes whose

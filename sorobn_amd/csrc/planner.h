@@ -66,7 +66,8 @@ struct Network {
     int nw = 1;
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
-    int tile_h = 0;          // hi iterations per tile; 0 = sized for kTileBytes of traffic per tile
+    int tile_h = 0;          // hi iterations per tile; 0 = sized for tile_bytes of traffic per tile
+    int64_t tile_bytes = 512 << 10;  // traffic one tile should move (tile_h = 0)
     double minfill_above = 2e7;  // run the greedy min-fill order search only if the sweep orders cost more bytes than this
     int prune = 1;           // restrict a request to the ancestors of its query / evidence variables (bayes_net.py:763-765)
     int outer = 1;           // OUTER form (fp64 MFMA) for products of two big tables
@@ -163,7 +164,6 @@ constexpr int kFiberLoMax = 256;    // R cells in the lane-varying block of a FI
 constexpr int kMaxCx = 16;          // eliminated combinations of a FIBER step (register fiber of loads)
 constexpr int kMaxStepWords = 384;  // LDS copy of one step descriptor
 constexpr int kTileMax = 64;        // hi iterations per tile (their offsets are decoded in one go)
-constexpr int64_t kTileBytes = 512 << 10;  // traffic one tile should move (tile_h = 0)
 
 // Growable word buffer the planner appends programs to.  The engine backs it with pinned host memory
 // (so the upload is a true async DMA) and keeps it across calls; the default backing is malloc.
