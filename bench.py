@@ -221,12 +221,24 @@ def other_configs(device):
 # ------------------------------------------------------------------------------------------------ transports
 
 def make_comm(backend, world, rank, local_rank, engine):
+    """-> (comm, transport name).  "rccl" = the C-ABI's mibn_comm_* (no PyTorch); should its initialisation fail on this
+    node (every rank sees the same error: the call is collective) the ranks fall back to RCCL through torch.distributed
+    rather than lose the run, and the JSON line says so."""
     from sorobn_amd import sharding
     if world == 1:
-        return sharding.SoloComm()
+        return sharding.SoloComm(), "none"
     if backend == "rccl":
-        return sharding.RcclComm(engine, rank, world)
-    return sharding.TorchComm()
+        try:
+            return sharding.RcclComm(engine, rank, world), "rccl"
+        except Exception as e:  # noqa: BLE001 - anything from dlopen to ncclCommInitRank
+            print(f"[bench] rank {rank}: mibn_comm_* unavailable ({e!r}); falling back to torch.distributed nccl", file=sys.stderr, flush=True)
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            return sharding.TorchComm(), "nccl-fallback"
+    return sharding.TorchComm(), backend
 
 
 def main():
@@ -300,7 +312,7 @@ def main():
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, float(v))
-    comm = make_comm(backend, world, rank, local_rank, eng)
+    comm, transport = make_comm(backend, world, rank, local_rank, eng)
 
     total_steps = a.warmup + a.steps
     n_req = total_steps * world * a.batch
@@ -393,9 +405,10 @@ def main():
             "config": {"workload": "C3: 10x10 grid BN, 4 states/node, Dirichlet(1) CPTs rng(0); requests = "
                                    f"1 query + {a.n_evidence} evidence nodes, rng(1) stream",
                        "requests_per_step_per_gpu": a.batch, "parallelism": f"dp{world} (independent shards)",
-                       "gather": "none" if world == 1 else {"rccl": "RCCL via the C-ABI (mibn_comm_allgather_f64), no PyTorch",
-                                                            "nccl": "RCCL via torch.distributed (hook)",
-                                                            "gloo": "gloo via torch.distributed (test hook)"}[backend],
+                       "gather": {"none": "none", "rccl": "RCCL via the C-ABI (mibn_comm_allgather_f64), no PyTorch",
+                                  "nccl": "RCCL via torch.distributed (hook)",
+                                  "nccl-fallback": "RCCL via torch.distributed (mibn_comm_init failed on this node: see stderr)",
+                                  "gloo": "gloo via torch.distributed (test hook)"}[transport],
                        "shard_balance": a.balance, "planner_threads": a.threads or "auto (cgroup quota / ranks)",
                        "adaptive_planning": not a.no_adaptive},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -450,7 +463,7 @@ def main():
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()
-    if world > 1 and backend != "rccl":
+    if world > 1 and transport != "rccl":
         import torch.distributed as dist
         dist.destroy_process_group()
 
@@ -467,7 +480,7 @@ def run_c5(a, rank, world, local_rank, device, backend):
     bn5 = netspec.build(spec5, sorobn_amd.BayesNet).use_device(device)
     be = bn5.backend
     eng = be.engine
-    comm = make_comm(backend, world, rank, local_rank, eng)
+    comm, transport = make_comm(backend, world, rank, local_rank, eng)
     rng = np.random.default_rng(1)
     ev5 = {f"{k:03d}": int(rng.integers(0, 8)) for k in (0, 9, 40, 49, 22)}
     q, evs, codes = be.encode(("025",), ev5)
@@ -508,7 +521,7 @@ def run_c5(a, rank, world, local_rank, device, backend):
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()
-    if world > 1 and backend != "rccl":
+    if world > 1 and transport != "rccl":
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -88,7 +88,7 @@ def _id_file():
     return os.path.join(os.environ.get("MIBN_COMM_DIR") or tempfile.gettempdir(), f"mibn_comm_{tag}.id")
 
 
-def exchange_id(rank, world, make_id, path=None, timeout_s=300.0):
+def exchange_id(rank, world, make_id, path=None, timeout_s=120.0):
     """Rank 0 calls make_id() and publishes the bytes (atomic rename); the others wait for the file."""
     path = path or _id_file()
     if rank == 0:
