@@ -59,10 +59,12 @@ __global__ __launch_bounds__(64) void order_kernel(const OrderArgs A) {
     A.order_len[b] = S.n_best;
 }
 
-// Chunk sets (pinned program buffers, device copies, schedule, launch events): the host plans chunk k + kChunkSets - 1 at
-// the earliest when chunk k has completed.  With two sets and a call of three chunks the second chunk of a call could only
-// be planned once the previous call had finished - while the GPU ran the short first chunk and then idled 5-12 ms per
-// call (the "[mibn gap]" lines of option trace); with three the planner stays a full chunk ahead.
+// Chunk sets (pinned program buffers, device copies, schedule, launch events): with n sets in use the host plans chunk
+// k + n - 1 at the earliest when chunk k has completed.  Two by default.  With two sets and a call of three chunks the
+// second chunk of a call can only be planned once the previous call has finished - the GPU runs the short first chunk and
+// then idles 5-12 ms (the "[mibn gap]" lines of option trace); a third set (option chunk_sets=3) closes those gaps but
+// proved erratic end to end (planning wall time doubles, runs between 155 k and 204 k queries/s against a steady
+// 194-204 k with two: profiles/r02_q_chunk_sets.log), so it stays an experiment.
 constexpr int kChunkSets = 3;
 
 struct mibn_ctx {
@@ -149,6 +151,7 @@ struct mibn_ctx {
     double search_ms = 0;            // host wall time spent waiting for the device search (last call)
     hipEvent_t gap_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // trace: ends of the last waves (GPU idle time between waves)
     uint64_t n_waves = 0;
+    int n_sets = 2;           // chunk sets in use (option "chunk_sets": 2 or 3)
     int set_cursor = 0;    // the chunk set the next chunk plans into: alternates across calls, so that a call of one chunk
                            // plans into the idle set while the previous call's kernels still run from the other one
     uint64_t call_id = 0;  // kernel time retired later is booked to the call that launched it
@@ -325,6 +328,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "big_iters") h->net.big_iters = std::max<int64_t>(1, (int64_t)value);  // test hooks: force tiling
     else if (n == "tile_h") h->net.tile_h = std::max(0, std::min(kTileMax, (int)value));  // 0 = sized by traffic
     else if (n == "tile_kb") h->net.tile_bytes = std::max<int64_t>(16, (int64_t)value) << 10;  // traffic per tile when tile_h = 0
+    else if (n == "chunk_sets") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_sets = std::max(2, std::min(kChunkSets, (int)value)); h->set_cursor = 0; }
     else if (n == "trace") h->trace = (int)value;
     else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
@@ -782,7 +786,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
         const int64_t n = b1 - b0;
         mibn_ctx::Set &st = h->set[h->set_cursor];
-        h->set_cursor = (h->set_cursor + 1) % kChunkSets;
+        h->set_cursor = (h->set_cursor + 1) % h->n_sets;
         if ((rc = retire(h, st))) return rc;  // its buffers are about to be rewritten
         double t0 = now_ms();
         // device order search: the first (short) chunk of a call is searched on the host while one launch searches the
