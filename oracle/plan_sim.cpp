@@ -24,11 +24,12 @@
 using namespace mibn;
 
 static std::string g_err;
-static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1, g_chain = 1;
+static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1, g_chain = 1, g_sweep = 5;
 extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
 extern "C" void plan_sim_set_tiling(int big_iters, int tile_h) { g_big_iters = big_iters; g_tile_h = tile_h; }
 extern "C" void plan_sim_set_fuse(int fuse) { g_fuse = fuse; }
 extern "C" void plan_sim_set_chain(int chain) { g_chain = chain; }
+extern "C" void plan_sim_set_sweep(int sweep) { g_sweep = sweep; }
 extern "C" void plan_sim_set_prune(int prune) { g_prune = prune; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
@@ -76,6 +77,124 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
             tmp[(size_t)(o - it0)] = acc;
         }
         std::memcpy(outp + it0, tmp.data(), sizeof(double) * tmp.size());
+        return 0;
+    }
+    if (kind == kKindSweep) {
+        // SWEEP (planner.h): tiles [h_begin, h_end) of Rt consecutive R cells x all 4^k combinations of the eliminated
+        // variables, the k stages applied in place on a tile-sized scratch - what ve_sweep_kernel does in LDS
+        const int k = na, rb = (w0 >> 24) & 0xff;
+        const int64_t Rt = int64_t(1) << rb, tiles = p[3], Rcells = tiles * Rt;
+        if (k < 3 || k > 5 || rb != 13 - 2 * k || lo != kSweepTileCells || cx != (1 << (2 * k))) { g_err = "malformed SWEEP header"; return -9; }
+        const int kout = (int)(p[7] & 0xffff), t_total = (int)(p[7] >> 16);
+        if (kout > k || t_total > kSweepMaxT) { g_err = "SWEEP: bad output rank or T size"; return -9; }
+        const uint32_t *q = p + kHdrWords;
+        const uint64_t f_off = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+        if (f_off & kConstFlag) { g_err = "SWEEP: the big input is a constant"; return -9; }
+        const double *F = slot + f_off;
+        if ((int64_t)f_off + (Rcells << (2 * k)) > arena_cells) { g_err = "SWEEP reads outside its arena"; return -7; }
+        if ((int64_t)out_off + (Rcells << (2 * kout)) > arena_cells) { g_err = "SWEEP writes outside its arena"; return -7; }
+        q += 2;
+        const uint32_t *stage = q;
+        const uint32_t *small = q + k * kSweepStageWords;
+        // T tables
+        std::vector<double> T((size_t)t_total, 0.0);
+        {
+            const uint32_t *sm = small;
+            bool live[5] = {true, true, true, true, true}, seen[5] = {};
+            int t_expect = 0;
+            for (int j = 0; j < k; ++j) {
+                const uint32_t s0 = stage[j * kSweepStageWords], s1 = stage[j * kSweepStageWords + 1];
+                const int dig = s0 & 15, cout = (s0 >> 4) & 15, ns = (s0 >> 8) & 15, nctrl = (s0 >> 12) & 15;
+                const int t_off = (int)(s1 & 0xffff), t_cells = (int)(s1 >> 16);
+                if (dig >= k || seen[dig] || (cout != 1 && cout != 4) || nctrl > 3 || t_off != t_expect || t_cells != (cout * 4 << (2 * nctrl)) ||
+                    t_off + t_cells > t_total) { g_err = "SWEEP: malformed stage"; return -9; }
+                seen[dig] = true;
+                t_expect += t_cells;
+                for (int c = 0; c < nctrl; ++c) {
+                    const uint32_t cw = stage[j * kSweepStageWords + 2 + c];
+                    const int src = cw & 0xff, ts = (int)(cw >> 8);
+                    if (ts != (cout * 4 << (2 * c))) { g_err = "SWEEP: ctrl stride"; return -9; }
+                    if (src < 8 && (src >= k || src == dig || !live[src])) { g_err = "SWEEP: ctrl on a dead or contracted digit"; return -9; }
+                    if (src >= 8 && (int64_t(4) << (src - 8)) > Rcells) { g_err = "SWEEP: ctrl bits beyond the R cells"; return -9; }
+                }
+                for (int t = 0; t < t_cells; ++t) {
+                    const int n = t % cout, x = (t / cout) & 3;
+                    int cc = t / (cout * 4);
+                    int cv[3];
+                    for (int c = 0; c < 3; ++c) { cv[c] = cc & 3; cc >>= 2; }
+                    double v = 1.0;
+                    for (int i = 0; i < ns; ++i) {
+                        const uint32_t *rec = sm + i * kSweepSmallWords;
+                        const double *tab = table((uint64_t)rec[0] | ((uint64_t)rec[1] << 32));
+                        int64_t off = (int64_t)n * (int32_t)rec[2] + (int64_t)x * (int32_t)rec[3];
+                        for (int c = 0; c < nctrl; ++c) off += (int64_t)cv[c] * (int32_t)rec[4 + c];
+                        v *= tab[off];
+                    }
+                    T[(size_t)(t_off + t)] = v;
+                }
+                sm += ns * kSweepSmallWords;
+                if (cout == 1) live[dig] = false;
+            }
+            int surv = 0;
+            for (int d = 0; d < k; ++d)
+                if (live[d]) { if (((p[8] >> (4 * surv)) & 15) != (uint32_t)d) { g_err = "SWEEP: surviving digits"; return -9; } ++surv; }
+            if (surv != kout) { g_err = "SWEEP: output rank"; return -9; }
+        }
+        std::vector<double> L((size_t)kSweepTileCells);
+        for (int64_t tile = h_begin; tile < h_end; ++tile) {
+            for (int64_t c = 0; c < kSweepTileCells; ++c) {
+                const int64_t r = c & (Rt - 1), xc = c >> rb;
+                L[(size_t)c] = F[xc * Rcells + tile * Rt + r];
+            }
+            for (int j = 0; j < k; ++j) {
+                const uint32_t *sj = stage + j * kSweepStageWords;
+                const int dig = sj[0] & 15, cout = (sj[0] >> 4) & 15, nctrl = (sj[0] >> 12) & 15;
+                const int t_off = (int)(sj[1] & 0xffff);
+                const int64_t sx = Rt << (2 * dig);
+                // every fiber along `dig`: the thread-field / loop-digit split of the kernel must enumerate each exactly once
+                const int loop = (sj[0] >> 16) & 15, fld[3] = {(int)((sj[0] >> 20) & 15), (int)((sj[0] >> 24) & 15), (int)((sj[0] >> 28) & 15)};
+                std::vector<char> done((size_t)kSweepTileCells / 4, 0);
+                for (int tid = 0; tid < kSweepWG; ++tid)
+                    for (int l = 0; l < 4; ++l) {
+                        int64_t base = tid & (Rt - 1);
+                        int bits = tid >> rb;
+                        for (int f = 0; f < 3; ++f)
+                            if (fld[f] != 7) { base += (int64_t)(bits & 3) * (Rt << (2 * fld[f])); bits >>= 2; }
+                        if (bits) { g_err = "SWEEP: thread fields do not use up the lane bits"; return -9; }
+                        base += (int64_t)l * (Rt << (2 * loop));
+                        if (loop == dig || loop >= k) { g_err = "SWEEP: loop digit"; return -9; }
+                        const int64_t rg = tile * Rt + (base & (Rt - 1));
+                        int toff = t_off;
+                        for (int c = 0; c < nctrl; ++c) {
+                            const uint32_t cw = sj[2 + c];
+                            const int src = cw & 0xff, ts = (int)(cw >> 8);
+                            const int val = src >= 8 ? (int)((rg >> (src - 8)) & 3) : (int)((base >> (rb + 2 * src)) & 3);
+                            toff += val * ts;
+                        }
+                        // fiber id = base without the contracted digit
+                        if ((base >> (rb + 2 * dig)) & 3) { g_err = "SWEEP: fiber base on the contracted digit"; return -9; }
+                        const int64_t lowmask = (Rt << (2 * dig)) - 1;
+                        const int64_t fid = (base & lowmask) | ((base >> 2) & ~lowmask);
+                        if (done[(size_t)fid]) { g_err = "SWEEP: a fiber is visited twice"; return -9; }
+                        done[(size_t)fid] = 1;
+                        double f[4], o[4];
+                        for (int x = 0; x < 4; ++x) f[x] = L[(size_t)(base + x * sx)];
+                        for (int n = 0; n < cout; ++n) {
+                            double sacc = 0.0;
+                            for (int x = 0; x < 4; ++x) sacc += f[x] * T[(size_t)(toff + n + cout * x)];
+                            o[n] = sacc;
+                        }
+                        for (int n = 0; n < cout; ++n) L[(size_t)(base + n * sx)] = o[n];
+                    }
+            }
+            const int64_t ocells = Rt << (2 * kout);
+            for (int64_t c = 0; c < ocells; ++c) {
+                const int64_t lo_ = c & ((int64_t(1) << (2 * kout)) - 1), r = c >> (2 * kout);
+                int64_t idx = r;
+                for (int qd = 0; qd < kout; ++qd) idx += ((lo_ >> (2 * qd)) & 3) * (Rt << (2 * ((p[8] >> (4 * qd)) & 15)));
+                outp[lo_ + ((tile * Rt + r) << (2 * kout))] = L[(size_t)idx];
+            }
+        }
         return 0;
     }
     // FIBER
@@ -312,6 +431,7 @@ extern "C" int plan_sim_query_batch(int32_t n_vars, const int32_t *card, const i
     net.tile_h = g_tile_h;
     net.fuse = g_fuse;
     net.chain = g_chain;
+    net.sweep = g_sweep;
     net.prune = g_prune;
     net.stagger = stagger;
     net.set_hints(n_hints, hints);
@@ -368,7 +488,7 @@ extern "C" int plan_sim_query_batch(int32_t n_vars, const int32_t *card, const i
                 if (L.kid != kKidSeg || it.b != wg) { g_err = "segment item inconsistent"; rc = -11; break; }
                 const uint32_t n_steps = it.a & ~kItemSegment;
                 for (uint32_t s = 0; s < n_steps && rc == 0; ++s) {
-                    if ((p[0] & 0xff) != kKindGeneric) { g_err = "FIBER step inside a segment"; rc = -10; break; }
+                    if ((p[0] & 0xff) != kKindGeneric) { g_err = "FIBER / SWEEP step inside a segment"; rc = -10; break; }
                     rc = exec_step(net, p, 0, p[3], arena, (int64_t)sc.arena_off[it.req], need, res);
                     if (rc == 0 && ((p[1] >> 16) & kFlagFinal)) {
                         const uint64_t oo = (uint64_t)p[4] | ((uint64_t)p[5] << 32);
@@ -435,6 +555,7 @@ extern "C" int64_t plan_sim_cache_check(int32_t n_vars, const int32_t *card, con
     net.tile_h = g_tile_h;
     net.fuse = g_fuse;
     net.chain = g_chain;
+    net.sweep = g_sweep;
     net.prune = g_prune;
     std::vector<int64_t> out_off(B + 1, 0);
     for (int64_t b = 0; b < B; ++b) {
@@ -484,6 +605,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     net.tile_h = g_tile_h;
     net.fuse = g_fuse;
     net.chain = g_chain;
+    net.sweep = g_sweep;
     net.prune = g_prune;
     net.set_hints(n_hints, hints);
     Request rq;
@@ -506,6 +628,7 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!g_err.empty()) return -1;
     net.chain = g_chain;
+    net.sweep = g_sweep;
     net.set_hints(n_hints, hints);
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
     for (int64_t b = 0; b <= B; ++b) { q_off[b] = b * nq; e_off[b] = b * ne; out_off[b] = b * 4; }

@@ -1012,6 +1012,181 @@ struct Emitter {
         return true;
     }
 
+    // SWEEP form (planner.h): k = 3..5 four-state variables X[0..k) - in elimination order - of the one big input, the
+    // tile resident in LDS.  Does its own bookkeeping (layout of the output, arena, statistics); returns false - nothing
+    // emitted, nothing allocated - when the step does not fit.
+    bool emit_sweep(const PF *const *ins, int n_in, const int *X, int k, PF &out) {
+        if (k < 3 || k > 5 || n_in - 1 > kSweepMaxSmall) return false;
+        const PF *F = nullptr;
+        for (int j = 0; j < n_in; ++j)
+            if (ins[j]->cells > net.small_cells) {
+                if (F) return false;
+                F = ins[j];
+            }
+        if (!F || (F->off & kConstFlag)) return false;
+        const int rb = 13 - 2 * k;
+        const int64_t Rt = int64_t(1) << rb;
+        if (F->cells & ((int64_t(1) << (2 * k)) - 1)) return false;
+        const int64_t Rcells = F->cells >> (2 * k);
+        if (Rcells < Rt || (Rcells & (Rt - 1))) return false;
+        // digits: x_j must sit on one of F's k slowest axes
+        int dig[5], var_on[5] = {-1, -1, -1, -1, -1};
+        for (int j = 0; j < k; ++j) {
+            if (net.card[X[j]] != 4) return false;
+            int d = -1;
+            for (int a = 0; a < F->n; ++a)
+                if (F->vars[a] == X[j]) {
+                    for (int q = 0; q < k; ++q)
+                        if (F->strides[a] == Rcells << (2 * q)) d = q;
+                }
+            if (d < 0 || var_on[d] >= 0) return false;
+            dig[j] = d;
+            var_on[d] = X[j];
+        }
+        // stages: a small input belongs to the first eliminated variable it mentions
+        struct Stage { int cout, ns, nctrl, loop, f[3], t_off, t_cells, src[3], newv; const PF *in[kSweepMaxSmall]; int cvar[3]; } S[5];
+        bool used[kSweepMaxSmall + 1] = {};
+        Bits introduced;
+        introduced.nw = net.nw;
+        int t_total = 0, ns_total = 0;
+        double in_cells = (double)F->cells;
+        for (int j = 0; j < k; ++j) {
+            Stage &g = S[j];
+            g.ns = 0;
+            Bits U;
+            U.nw = net.nw;
+            for (int i = 0; i < n_in; ++i) {
+                if (ins[i] == F || used[i] || !ins[i]->scope.test(X[j])) continue;
+                used[i] = true;
+                g.in[g.ns++] = ins[i];
+                U.or_(ins[i]->scope);
+                in_cells += (double)ins[i]->cells;
+            }
+            ns_total += g.ns;
+            Bits fresh = U;
+            fresh.andnot(F->scope);
+            fresh.andnot(introduced);
+            const int nnew = fresh.count();
+            if (nnew > 1) return false;
+            g.newv = -1;
+            if (nnew == 1) {
+                fresh.for_each([&](int v) { g.newv = v; });
+                if (net.card[g.newv] != 4) return false;
+                introduced.set(g.newv);
+            }
+            g.cout = nnew ? 4 : 1;
+            g.nctrl = 0;
+            bool ok = true;
+            U.for_each([&](int v) {
+                if (!ok || v == X[j] || v == g.newv) return;
+                int src = -1;
+                for (int d = 0; d < k; ++d)
+                    if (var_on[d] == v && d != dig[j]) src = d;
+                if (src < 0) {
+                    // an R axis of F: four states, power-of-two stride
+                    for (int a = 0; a < F->n; ++a)
+                        if (F->vars[a] == v && F->strides[a] < Rcells) {
+                            const int64_t st_ = F->strides[a];
+                            if (net.card[v] == 4 && (st_ & (st_ - 1)) == 0) src = 8 + __builtin_ctzll((unsigned long long)st_);
+                        }
+                }
+                if (src < 0 || g.nctrl >= 3) { ok = false; return; }
+                g.src[g.nctrl] = src;
+                g.cvar[g.nctrl] = v;
+                ++g.nctrl;
+            });
+            if (!ok) return false;
+            g.t_cells = g.cout * 4 << (2 * g.nctrl);
+            g.t_off = t_total;
+            t_total += g.t_cells;
+            if (t_total > kSweepMaxT) return false;
+            // thread fields / loop digit: the free digits ascending, the loop digit = the highest one that is no ctrl
+            int free_[4], nf = 0;
+            for (int d = 0; d < k; ++d)
+                if (d != dig[j]) free_[nf++] = d;
+            int loop = -1;
+            for (int q = nf - 1; q >= 0 && loop < 0; --q) {
+                bool is_ctrl = false;
+                for (int c = 0; c < g.nctrl; ++c) is_ctrl = is_ctrl || g.src[c] == free_[q];
+                if (!is_ctrl) loop = free_[q];
+            }
+            if (loop < 0) loop = free_[nf - 1];
+            g.loop = loop;
+            g.f[0] = g.f[1] = g.f[2] = 7;
+            for (int q = 0, m = 0; q < nf; ++q)
+                if (free_[q] != loop) g.f[m++] = free_[q];
+            var_on[dig[j]] = g.newv;  // (-1: the digit is dead from here on)
+        }
+        for (int i = 0; i < n_in; ++i)
+            if (ins[i] != F && !used[i]) return false;  // (a small input that mentions none of the eliminated variables)
+        // output: surviving digits (ascending) fastest, then F's R axes in F's order
+        int kout = 0, surv[5];
+        for (int d = 0; d < k; ++d)
+            if (var_on[d] >= 0) surv[kout++] = d;
+        const int64_t out_cells = Rcells << (2 * kout);
+        if (out_cells >= (1ll << 31)) return false;
+        int na = 0;
+        out.scope.nw = net.nw;
+        for (int q = 0; q < net.nw; ++q) out.scope.w[q] = 0;
+        for (int q = 0; q < kout; ++q) {
+            out.vars[na] = var_on[surv[q]];
+            out.strides[na] = int64_t(1) << (2 * q);
+            out.scope.set(out.vars[na]);
+            ++na;
+        }
+        for (int a = 0; a < F->n; ++a) {
+            if (F->strides[a] >= Rcells) continue;  // (the eliminated variables)
+            if (na >= kRawAxes) return false;
+            out.vars[na] = F->vars[a];
+            out.strides[na] = F->strides[a] << (2 * kout);
+            out.scope.set(out.vars[na]);
+            ++na;
+        }
+        out.n = na;
+        out.cells = out_cells;
+        const int words = kHdrWords + 2 + k * kSweepStageWords + ns_total * kSweepSmallWords;
+        if (words > kMaxStepWords) return false;
+        out.off = (uint64_t)arena.alloc(out_cells);
+        out.alloc = out_cells;
+        out.src = -1;
+        uint32_t *w = prog.extend(words);
+        header(w, kKindSweep, n_in, k, rb, 1 << (2 * k), false, kSweepTileCells, Rcells / Rt, out.off, words);
+        w[7] = (uint32_t)kout | ((uint32_t)t_total << 16);
+        w[8] = 0;
+        for (int q = 0; q < kout; ++q) w[8] |= (uint32_t)surv[q] << (4 * q);
+        uint32_t *p = w + kHdrWords;
+        put_off(p, F);
+        for (int j = 0; j < k; ++j) {
+            const Stage &g = S[j];
+            *p++ = (uint32_t)dig[j] | ((uint32_t)g.cout << 4) | ((uint32_t)g.ns << 8) | ((uint32_t)g.nctrl << 12) | ((uint32_t)g.loop << 16) |
+                   ((uint32_t)g.f[0] << 20) | ((uint32_t)g.f[1] << 24) | ((uint32_t)g.f[2] << 28);
+            *p++ = (uint32_t)g.t_off | ((uint32_t)g.t_cells << 16);
+            for (int c = 0; c < 3; ++c) *p++ = c < g.nctrl ? ((uint32_t)g.src[c] | ((uint32_t)(g.cout * 4 << (2 * c)) << 8)) : 0u;
+        }
+        auto stride_of = [](const PF *f, int v) -> int64_t {
+            for (int a = 0; a < f->n; ++a)
+                if (f->vars[a] == v) return f->strides[a];
+            return 0;
+        };
+        for (int j = 0; j < k; ++j) {
+            const Stage &g = S[j];
+            for (int i = 0; i < g.ns; ++i) {
+                put_off(p, g.in[i]);
+                *p++ = (uint32_t)(int32_t)(g.newv >= 0 ? stride_of(g.in[i], g.newv) : 0);
+                *p++ = (uint32_t)(int32_t)stride_of(g.in[i], X[j]);
+                for (int c = 0; c < 3; ++c) *p++ = (uint32_t)(int32_t)(c < g.nctrl ? stride_of(g.in[i], g.cvar[c]) : 0);
+            }
+        }
+        w[9] = (uint32_t)(((int64_t)in_cells + out_cells + 2) >> 2);
+        st.alg_bytes += 8.0 * (in_cells + (double)out_cells);
+        st.alg_flops += (double)k * 4.0 * (double)F->cells;
+        st.max_step_cells = std::max(st.max_step_cells, (double)F->cells);
+        st.n_steps += 1;
+        for (int j = 0; j < n_in; ++j)
+            if (ins[j]->alloc) arena.release((int64_t)ins[j]->off, ins[j]->alloc);
+        return true;
+    }
+
     // Emit one step: multiply `ins`, sum out the nx (0..2) variables X (nx = 0: product only); the new factor is
     // written to `out`.  fiber_only: emit nothing and return false unless the step fits the FIBER form (used to try
     // the joint elimination of two variables).
@@ -1273,6 +1448,57 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
         int n_in = 0;
         each_with(x, -1, [&](int idx) { ins[n_in++] = &pool[idx]; return true; });
         for (int j = 0; j < n_in; ++j) consume(ins[j]);
+        // SWEEP: up to five consecutive 4-state variables of one big table in a single pass, the tile resident in LDS
+        // (planner.h).  sweep_max = how many of the next variables could join: all on the one big input, every other factor
+        // that mentions them small.  Four and five variables are tried first, three only after the CHAIN form below.
+        int sweep_max = 0, sweep_n[5] = {0, 0, 0, 0, 0};
+        const PF *sweep_ins[kSweepMaxSmall + 2];
+        if (net.fuse && net.sweep >= 3 && i + 2 < best.size() && net.card[x] == 4 && sw <= 16 && n_in - 1 <= kSweepMaxSmall &&
+            pool.size() + 1 <= pool.capacity()) {
+            int nbig = 0;
+            const PF *bigf = nullptr;
+            for (int j = 0; j < n_in; ++j)
+                if (ins[j]->cells > net.small_cells) { ++nbig; bigf = ins[j]; }
+            if (nbig == 1 && !(bigf->off & kConstFlag) && bigf->cells >= 16 * (int64_t)net.big_iters && bigf->cells >= 2 * kSweepTileCells) {
+                uint64_t taken[16];
+                for (int q = 0; q < sw; ++q) taken[q] = 0;
+                int n_all = n_in;
+                for (int j = 0; j < n_in; ++j) sweep_ins[j] = ins[j];
+                sweep_max = 1;
+                sweep_n[0] = n_in;
+                for (int j = 1; j < std::min(net.sweep, 5) && i + j < best.size(); ++j) {
+                    const int32_t xj = best[i + j];
+                    if (net.card[xj] != 4 || !bigf->scope.test(xj)) break;
+                    bool ok = true;
+                    each_with(xj, -1, [&](int idx) {
+                        if (taken[idx >> 6] >> (idx & 63) & 1) return true;
+                        if (pool[idx].cells > net.small_cells || n_all - 1 >= kSweepMaxSmall) { ok = false; return false; }
+                        taken[idx >> 6] |= 1ull << (idx & 63);
+                        sweep_ins[n_all++] = &pool[idx];
+                        return true;
+                    });
+                    if (!ok) break;
+                    sweep_n[j] = n_all;
+                    sweep_max = j + 1;
+                }
+            }
+        }
+        auto try_sweep = [&](int k_hi, int k_lo) -> bool {
+            for (int k = std::min(k_hi, sweep_max); k >= k_lo; --k) {
+                int X[5];
+                for (int j = 0; j < k; ++j) X[j] = best[i + j];
+                pool.emplace_back();
+                if (em.emit_sweep(sweep_ins, sweep_n[k - 1], X, k, pool.back())) {
+                    for (int j = n_in; j < sweep_n[k - 1]; ++j) consume(sweep_ins[j]);
+                    add_factor((int)pool.size() - 1);
+                    i += (size_t)k - 1;
+                    return true;
+                }
+                pool.pop_back();
+            }
+            return false;
+        };
+        if (sweep_max >= 4 && try_sweep(5, 4)) continue;
         // Joint elimination: if the factor this step creates is a big table that the very next step consumes, both
         // variables are summed out in one pass over the inputs and the intermediate never touches HBM.
         // CHAIN: three consecutive 4-state variables of one big table in a single pass (planner.h)
@@ -1312,6 +1538,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
                 }
             }
         }
+        if (sweep_max >= 3 && try_sweep(3, 3)) continue;
         if (net.fuse && i + 1 < best.size() && n_in < kMaxIn && pool.size() + 1 <= pool.capacity()) {
             const int32_t x2 = best[i + 1];
             bool link = false;
@@ -1634,7 +1861,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }
@@ -1834,6 +2061,7 @@ const char *kernel_name(int kid) {
                         "fiber<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
         names[kKidChain] = "fiber<1,cx64,chain-mfma>";  // (the slot of the impossible class <2,cxN,outer-mfma>)
         for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic<" + std::to_string(j + 1) + ">";
+        names[kKidSweep] = "sweep<lds>";
         init = true;
     }
     return kid >= 0 && kid < kNumKernels ? names[kid].c_str() : "?";
@@ -1859,6 +2087,7 @@ int fiber_nc_class(const uint32_t *w) {
 
 int kernel_id_of_step(const uint32_t *w) {
     const uint32_t kind = w[0] & 0xff;
+    if (kind == kKindSweep) return kKidSweep;
     if (kind == kKindFiber) {
         const int nb = w[7] & 0xf;
         if ((w[1] >> 16) & kFlagChain) return kKidChain;
@@ -1872,12 +2101,13 @@ int kernel_id_of_step(const uint32_t *w) {
 int64_t step_cost_bytes(const uint32_t *w) { return 32 * (int64_t)w[9]; }
 
 bool step_is_tiled(const Network &net, const uint32_t *w) {
-    if ((w[0] & 0xff) == kKindFiber) return true;  // FIBER steps are only emitted above big_iters
+    if ((w[0] & 0xff) == kKindFiber || (w[0] & 0xff) == kKindSweep) return true;  // FIBER / SWEEP steps are only emitted above big_iters
     const bool fin = (w[1] >> 16) & kFlagFinal;
     return !fin && (int64_t)w[2] * (int64_t)w[3] >= net.big_iters;
 }
 
 int step_tile_h(const Network &net, const uint32_t *w) {
+    if ((w[0] & 0xff) == kKindSweep) return kSweepIters;  // (tiles of 64 KiB in, <= 64 KiB out)
     if (net.tile_h > 0) return std::min(net.tile_h, kTileMax);
     // bytes one hi iteration moves = the step's section-8(d) traffic / hi (broadcast re-reads of a small "big" input
     // are cache hits, they do not count)

@@ -77,6 +77,7 @@ struct Network {
     mutable std::shared_ptr<void> templates;  // the template store of this network (planner.cpp)
     int chain = 1;           // CHAIN form: a third 4-state variable eliminated in the registers of the same pass
     int stagger = 1;         // build_schedule: groups of requests whose levels are staggered inside a chunk (1 = all in phase)
+    int sweep = 5;           // SWEEP form: up to this many 4-state variables of one big table per pass, tile resident in LDS (0 = off)
 
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
@@ -153,10 +154,38 @@ struct PlanStats {
 //      of T3, T3 cells, stride of x3 in F, stride of x3 in T12) and bstride[1][.] are the T3 strides of the R axes.
 //      After nout[]: n_small3, n_dims3 | (T3 depends on n12) << 8, tcard3[n_dims3], then per small-3 input: off lo,
 //      off hi, stride[n_dims3].
+//
+//   SWEEP (kind 2)  k = 3..5 four-state variables x_1..x_k of ONE big table F (+ CPT slices) eliminated in one pass with
+//      the tile resident in LDS (ve_sweep_kernel, sweep_kernel.hip.h).  The x_j are F's slowest axes, x_j on digit dig_j of
+//      xc:  F index = r + Rcells * xc,  xc = sum_d digit_d * 4^d.  A tile = all 4^k xc x Rt consecutive r (Rt = 8192 / 4^k
+//      cells: runs of Rt * 8 bytes in F), staged as L[r_local + Rt * xc].  Stage j, in elimination order, works in place
+//      along digit dig_j:
+//           L[.., n, ..] = sum_x L[.., x, ..] * T_j[n + cout_j * (x + 4 * (c0 + 4 * (c1 + 4 * c2)))]        n < cout_j
+//      cout_j = 4: the one new variable of the CPT slices that mention x_j takes over the digit; 1: the digit dies.  The
+//      ctrl values c0..c2 are four-state variables that are on a live digit right now (x_j' not yet eliminated, n_j'
+//      already introduced) or R axes of F with a power-of-two stride (bits of r).  T_j = product of the step's small
+//      inputs that mention x_j and none of x_1..x_{j-1}.  Output: the surviving digits (ascending) are the fastest axes,
+//      then F's R axes in F's order:  out index = sum_q val_q * 4^q + 4^kout * r.
+//      header: w0 = kind | n_in << 8 | k << 16 | log2(Rt) << 24;  w1 = 4^k | flags << 16;  w2 = 8192;  w3 = tiles = Rcells / Rt
+//              w7 = kout | T cells (all stages) << 16;  w8 = LDS digit of surviving rank q at bits 4q (q < kout)
+//      body:   F off lo, off hi
+//              per stage j < k (5 words): s0 = dig | cout << 4 | n_small << 8 | nctrl << 12 | loop digit << 16 |
+//                                              thread fields f0 << 20 | f1 << 24 | f2 << 28   (digits, unused = 7)
+//                                         s1 = T_j offset (cells) | T_j cells << 16
+//                                         ctrl c < 3:  src | tstride << 8     src 0..4 = digit, 8 + s = bits (r >> s) & 3
+//              per stage, per small input (7 words): off lo, off hi, stride of the new variable, of x_j, of ctrl 0..2
+//      A work item = kSweepIters consecutive tiles; one workgroup of kSweepWG lanes per item.
 constexpr uint32_t kFlagFinal = 1, kFlagContig = 2, kFlagOuter = 4, kFlagChain = 8;
+constexpr uint32_t kKindSweep = 2;
+constexpr int kSweepTileCells = 8192;  // 64 KiB of LDS
+constexpr int kSweepMaxT = 1024;       // T cells of all stages together (8 KiB)
+constexpr int kSweepMaxSmall = 16;     // small inputs of all stages together
+constexpr int kSweepIters = 8;         // tiles per workgroup
+constexpr int kSweepWG = 512;
+constexpr int kSweepStageWords = 5, kSweepSmallWords = 7;
 constexpr int kRowStrideShift = 20;  // w1 bits 20..27
 constexpr int kHdrWords = 10;
-constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;
+constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;  // (kKindSweep = 2 above)
 constexpr int kMaxNC = 16;         // N-fiber length held in registers
 constexpr int kMaxT = 2048;        // T cells (16 KiB of LDS)
 constexpr int kMaxSmall = 4;
@@ -255,7 +284,8 @@ constexpr int kKidSeg = 0;         // segments of small GENERIC steps
 constexpr int kKidFiber0 = 1;      // 36 FIBER tile classes: 1 + (n_big-1)*18 + cx_class*6 + nc_class
 constexpr int kKidChain = 36;      // CHAIN steps (takes the id of the impossible FIBER class <2, cxN, outer-mfma>)
 constexpr int kKidGeneric0 = 37;   // 6 GENERIC tile classes: 37 + (n_in - 1)
-constexpr int kNumKernels = 43;
+constexpr int kKidSweep = 43;      // SWEEP steps: a kernel of their own (ve_sweep_kernel), launched after the level kernel
+constexpr int kNumKernels = 44;
 const char *kernel_name(int kid);
 int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
 int fiber_cx_class(const uint32_t *w);     // 0: cx = 4   1: cx = 16 = 4 x 4   2: anything else (runtime loop)

@@ -225,6 +225,35 @@ def test_order_choice_never_worse_than_row_major():
     assert ours.mean() < 0.5 * rm.mean()
 
 
+def test_sweep_form_on_the_simulator():
+    """SWEEP steps (up to five variables per pass with the tile resident in LDS, option sweep=5, the default): the
+    planner's programs, executed by the simulator the way ve_sweep_kernel executes them (tiles, in-place stages, the lane /
+    loop split of the fibers), reproduce the reference's answers on the 10x10 grid, agree with the CHAIN / pair programs
+    to the last bits and move at least a fifth fewer bytes."""
+    entry = gu.load("grid10x10.json")
+    spec = gu.grid_spec_from_recipe(entry)
+    bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
+    assert bn.backend.engine.sweep == 5
+    _check_requests(bn, entry["requests"], spec["name"] + " sweep")
+    f = flatten(netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet))
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
+    q, ev, ec = netspec.c3_requests(100, 4, 48, 4, seed=1)
+    b = {}
+    for name, k in (("chain", 0), ("sweep3", 3), ("sweep4", 4), ("sweep5", 5)):
+        eng = simengine.SimEngine(f)
+        eng.set_option("sweep", k)
+        tot, res = 0.0, []
+        for i in range(48):
+            res.append(eng._one([to_var[q[i]]], to_var[ev[i]], ec[i]))
+            tot += eng.last_stats[0]
+        b[name] = (tot, res)
+    for name in ("sweep3", "sweep4", "sweep5"):
+        for x, y in zip(b["chain"][1], b[name][1]):
+            assert float(np.max(np.abs(x - y))) <= 1e-14
+    assert b["sweep5"][0] < 0.8 * b["chain"][0]
+    assert b["sweep5"][0] <= b["sweep4"][0] <= b["sweep3"][0] <= b["chain"][0]
+
+
 def test_chain_form_on_the_simulator():
     """CHAIN steps (three variables per pass, option chain=1): the planner's programs, executed by the simulator,
     reproduce the reference's answers on the 10x10 grid and move fewer bytes than the two-variable passes."""
@@ -240,6 +269,8 @@ def test_chain_form_on_the_simulator():
     q, ev, ec = netspec.c3_requests(100, 4, 24, 4, seed=1)
     plain, chain = simengine.SimEngine(f), simengine.SimEngine(f)
     plain.set_option("chain", 0)
+    plain.set_option("sweep", 0)
+    chain.set_option("sweep", 0)
     b0 = b1 = 0.0
     for i in range(24):
         a = plain._one([to_var[q[i]]], to_var[ev[i]], ec[i])
@@ -249,6 +280,7 @@ def test_chain_form_on_the_simulator():
         assert float(np.max(np.abs(a - b))) <= 1e-14
     assert b1 < 0.9 * b0
     tiled = simengine.SimEngine(f, tiling=(64, 3))  # several iterations per tile, CHAIN steps on small tables
+    tiled.set_option("sweep", 0)
     for i in range(8):
         assert float(np.max(np.abs(tiled._one([to_var[q[i]]], to_var[ev[i]], ec[i]) - plain._one([to_var[q[i]]], to_var[ev[i]], ec[i])))) <= 1e-14
 

@@ -37,11 +37,22 @@ def decode(w):
         w0 = int(w[p]); kind = w0 & 0xff; n_in = (w0 >> 8) & 0xff; na = (w0 >> 16) & 0xff; nlo = (w0 >> 24) & 0xff
         cx = int(w[p + 1]) & 0xffff; fin = (int(w[p + 1]) >> 16) & 1
         lo, hi, words = int(w[p + 2]), int(w[p + 3]), int(w[p + 6])
-        d = dict(w1=int(w[p + 1]), kind="FIBER" if kind else "GENERIC", n_in=n_in, na=na, nlo=nlo, fin=fin, cx=cx, lo=lo, hi=hi,
+        d = dict(w1=int(w[p + 1]), kind={0: "GENERIC", 1: "FIBER", 2: "SWEEP"}[kind], n_in=n_in, na=na, nlo=nlo, fin=fin, cx=cx, lo=lo, hi=hi,
                  bytes=32 * int(w[p + 9]), words=words)
         q = p + 10
         I = lambda k: int(np.int32(w[k]))
-        if kind == 0:
+        if kind == 2:  # SWEEP: k variables per pass, tile in LDS (planner.h)
+            k = na
+            d.update(k=k, rb=nlo, kout=int(w[p + 7]) & 0xffff, T=int(w[p + 7]) >> 16, stages=[])
+            sq = q + 2 + 5 * k
+            for j in range(k):
+                s0, s1 = int(w[q + 2 + 5 * j]), int(w[q + 3 + 5 * j])
+                ns, nc = (s0 >> 8) & 15, (s0 >> 12) & 15
+                d["stages"].append(dict(dig=s0 & 15, cout=(s0 >> 4) & 15, ns=ns, loop=(s0 >> 16) & 15,
+                                        fields=[(s0 >> 20) & 15, (s0 >> 24) & 15, (s0 >> 28) & 15],
+                                        ctrl=[int(w[q + 4 + 5 * j + c]) & 0xff for c in range(nc)], t_cells=s1 >> 16))
+                sq += 7 * ns
+        elif kind == 0:
             d["ins"] = [("C" if int(w[q + 3 * j + 1]) >> 31 else "A", I(q + 3 * j + 2)) for j in range(n_in)]
             q += 3 * n_in
             d["card"] = [int(x) for x in w[q:q + na]]; q += na
@@ -87,7 +98,9 @@ if __name__ == "__main__":
         if s["lo"] * s["hi"] < int(os.environ.get("MINCELLS", "1")):
             continue
         head = f"{k:3d} {s['kind']:7s} cx={s['cx']} lo={s['lo']} hi={s['hi']} nlo={s['nlo']} na={s['na']} MB={s['bytes']/1e6:8.3f}"
-        if s["kind"] == "GENERIC":
+        if s["kind"] == "SWEEP":
+            print(head, f"k={s['k']} kout={s['kout']} T={s['T']} stages=" + " ".join(f"[d{g['dig']} out{g['cout']} ns{g['ns']} ctrl{g['ctrl']} loop{g['loop']}]" for g in s["stages"]))
+        elif s["kind"] == "GENERIC":
             print(head, f"n_in={s['n_in']} card={s['card']} ins={s['ins']} strides={s['strides']}", "FINAL" if s["fin"] else "")
         else:
             if s.get("chain"):
