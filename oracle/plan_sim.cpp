@@ -110,10 +110,22 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
                     t_off + t_cells > t_total) { g_err = "SWEEP: malformed stage"; return -9; }
                 seen[dig] = true;
                 t_expect += t_cells;
+                {   // the lane / loop split of the fibers follows the rule the kernel compiles in
+                    const int loop = (s0 >> 16) & 15;
+                    int m = 0;
+                    bool okf = loop == sweep_loop_digit(k, dig);
+                    for (int d = 0; d < k; ++d)
+                        if (d != dig && d != loop) { okf = okf && (int)((s0 >> (20 + 4 * m)) & 15) == d; ++m; }
+                    for (; m < 3; ++m) okf = okf && ((s0 >> (20 + 4 * m)) & 15) == 7;
+                    if (!okf) { g_err = "SWEEP: thread fields / loop digit off the rule"; return -9; }
+                    if (((p[1] >> 16) & kFlagSweepCanon) && dig != k - 1 - j) { g_err = "SWEEP: canonical flag on a permuted step"; return -9; }
+                }
+                int n_rctrl = 0;
                 for (int c = 0; c < nctrl; ++c) {
                     const uint32_t cw = stage[j * kSweepStageWords + 2 + c];
                     const int src = cw & 0xff, ts = (int)(cw >> 8);
                     if (ts != (cout * 4 << (2 * c))) { g_err = "SWEEP: ctrl stride"; return -9; }
+                    if (src >= 8 && ++n_rctrl > 2) { g_err = "SWEEP: more than two ctrl values from r"; return -9; }
                     if (src < 8 && (src >= k || src == dig || !live[src])) { g_err = "SWEEP: ctrl on a dead or contracted digit"; return -9; }
                     if (src >= 8 && (int64_t(4) << (src - 8)) > Rcells) { g_err = "SWEEP: ctrl bits beyond the R cells"; return -9; }
                 }

@@ -21,6 +21,7 @@
 #include "count_kernel.hip.h"
 #include "planner.h"
 #include "tiny_kernel.hip.h"
+#include "sweep_kernel.hip.h"
 #include "ve_kernel.hip.h"
 
 using namespace mibn;
@@ -108,7 +109,7 @@ struct mibn_ctx {
         size_t items_cap = 0;
         hipEvent_t uploaded = nullptr;       // the copy stream has delivered this set's programs and schedule
         std::vector<hipEvent_t> ev;          // launch boundaries of the waves in flight
-        struct Timed { int kid; size_t e0, e1; double bytes, items; uint64_t call; };
+        struct Timed { int kid; size_t e0, e1; double bytes, items; uint64_t call; };  // kid < 0: the wall time of a wave (kernel_ms); else one launch
         std::vector<Timed> timed;
         size_t ev_used = 0;
         bool busy = false;
@@ -178,6 +179,8 @@ struct mibn_ctx {
     mibn_kernel_stat ktotal[kNumKernels + 2];
     // options
     double arena_gb = 96.0;
+    hipStream_t stream2 = nullptr;  // the sweep kernel's stream (n_streams = 2: the two kernels of a level overlap)
+    int n_streams = 2;
     int threads = 0;
     int trace = 0;        // debug: one stderr line per launch
     int split_kinds = 0;  // profiling: one launch per (level, class of work) instead of one per level
@@ -265,7 +268,10 @@ int mibn_create(int device, mibn_t **out) {
     }
     h->n_cu = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    // the sweep kernel keeps its 64 KiB tile, the T tables and the step descriptor in dynamic LDS (two workgroups per CU)
+    ok = ok && hipFuncSetAttribute((const void *)ve_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes) == hipSuccess;
     if (!ok) { delete h; return MIBN_E_HIP; }
     *out = h;
     return MIBN_OK;
@@ -312,6 +318,7 @@ void mibn_destroy(mibn_t *h) {
         for (auto &sg : h->res_stage)
             if (sg.p) (void)hipHostFree(sg.p);
         if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -340,6 +347,10 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "fuse") h->net.fuse = value != 0;
     else if (n == "plan_cache") h->net.plan_cache = value != 0;  // plan templates for repeated request shapes
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
+    else if (n == "streams") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_streams = value >= 2 ? 2 : 1; }  // 1: the sweep kernel on the main stream, after the level kernel
+    else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
+    else if (n == "sweep_iters") h->net.sweep_iters = std::max(1, std::min(kTileMax, (int)value));  // tiles per workgroup of the sweep kernel
+    else if (n == "sweep") h->net.sweep = std::max(0, std::min(5, (int)value));  // SWEEP form: up to this many variables per pass, tile in LDS (0 / < 3: off)
     else if (n == "outer") h->net.outer = value != 0;
     else if (n == "stagger") h->net.stagger = std::max(1, std::min(8, (int)value));  // groups of requests with staggered levels per chunk
     else if (n == "prune") h->net.prune = value != 0;  // 0: multiply every CPT (full_joint_dist / predict_proba semantics)  // OUTER (MFMA) form for products of two big tables  // joint elimination of two variables per pass
@@ -500,11 +511,14 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         float ms = 0;
         HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));
         const bool mine = t.call == h->call_id;  // (launches of an earlier asynchronous call only count in the totals)
-        if (mine) {
-            h->stats.kernel_ms += ms;
-            h->stats.n_launches += 1;
+        if (t.kid < 0) {
+            // GPU wall time of a wave, first launch to last (the level kernel and the sweep kernel of a level overlap on two
+            // streams: the sum of the launches' own durations below exceeds it)
+            if (mine) h->stats.kernel_ms += ms;
+            h->total.kernel_ms += ms;
+            continue;
         }
-        h->total.kernel_ms += ms;
+        if (mine) h->stats.n_launches += 1;
         h->total.n_launches += 1;
         for (mibn_kernel_stat *ks : {&h->kstats[t.kid], &h->ktotal[t.kid]}) {
             if (ks == &h->kstats[t.kid] && !mine) continue;
@@ -528,14 +542,14 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     return MIBN_OK;
 }
 
-int next_event(mibn_ctx *h, mibn_ctx::Set &st, size_t &idx) {
+int next_event(mibn_ctx *h, mibn_ctx::Set &st, size_t &idx, hipStream_t stream = nullptr) {
     if (st.ev_used == st.ev.size()) {
         hipEvent_t e;
         HIP_TRY(h, hipEventCreate(&e));
         st.ev.push_back(e);
     }
     idx = st.ev_used++;
-    HIP_TRY(h, hipEventRecord(st.ev[idx], h->stream));
+    HIP_TRY(h, hipEventRecord(st.ev[idx], stream ? stream : h->stream));
     return MIBN_OK;
 }
 
@@ -870,31 +884,56 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             A.pool = h->d_pool;
             A.arena = h->d_arena;
             A.results = d_results + (out_off[b0] - out_off[0]);
-            size_t e_prev = 0;
             double n_wg = 0;
             if (h->trace) st.gap_from = h->n_waves ? (int)((h->n_waves - 1) & 3) : -1;
-            if ((rc = next_event(h, st, e_prev))) return rc;
+            // Two streams: the level kernel on the main stream, the sweep kernel on a second one.  The kernels of level L wait
+            // for the kernels of both streams below L (the end event of a stream's latest launch below L), not for each other:
+            // the two kernels of a level overlap and fill each other's tails.  Every launch is bracketed by its own pair of
+            // events; the wave as a whole by the first and the last event on the main stream (kernel_ms).
+            const bool two = h->n_streams > 1 && h->stream2;
+            constexpr size_t kNone = ~size_t(0);
+            size_t e_first = 0, lastA = kNone, lastB = kNone, prevA = kNone, prevB = kNone, waitedA = kNone, waitedB = kNone;
+            int cur_level = -1;
+            if ((rc = next_event(h, st, e_first))) return rc;
+            if (two) HIP_TRY(h, hipStreamWaitEvent(h->stream2, st.ev[e_first], 0));  // after this wave's uploads and the previous wave
             A.items = st.d_items;
             for (size_t li = 0; li < sc.launches.size();) {
-                // one launch per level (all classes of work together) unless split_kinds
+                // one launch of the level kernel per level (all its classes of work together) unless split_kinds, and one
+                // of the sweep kernel for the level's SWEEP items (the last class of a level: its own LDS budget)
                 size_t lj = li + 1;
+                const bool sweep = sc.launches[li].kid == kKidSweep;
                 double bytes = sc.launches[li].alg_bytes;
                 size_t grid = sc.launches[li].grid;
-                if (!h->split_kinds)
-                    for (; lj < sc.launches.size() && sc.launches[lj].level == sc.launches[li].level; ++lj) {
+                if (!h->split_kinds && !sweep)
+                    for (; lj < sc.launches.size() && sc.launches[lj].level == sc.launches[li].level && sc.launches[lj].kid != kKidSweep; ++lj) {
                         bytes += sc.launches[lj].alg_bytes;
                         grid += sc.launches[lj].grid;
                     }
                 const Launch &L = sc.launches[li];
+                if (L.level != cur_level) { cur_level = L.level; prevA = lastA; prevB = lastB; }
+                const bool onB = sweep && two;
+                hipStream_t S = onB ? h->stream2 : h->stream;
+                if (two) {
+                    size_t &need = onB ? prevA : prevB, &waited = onB ? waitedB : waitedA;
+                    if (need != kNone && need != waited) { HIP_TRY(h, hipStreamWaitEvent(S, st.ev[need], 0)); waited = need; }
+                }
                 A.wg_item = st.d_wg_item + L.wg_level;
                 A.wg_base = (uint32_t)(L.wg_first - L.wg_level);
-                hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, h->stream, A);
-                size_t e_next = 0;
-                if ((rc = next_event(h, st, e_next))) return rc;
-                st.timed.push_back({h->split_kinds ? L.kid : kNumKernels, e_prev, e_next, bytes, (double)grid, h->call_id});
+                size_t e0 = 0, e1 = 0;
+                if ((rc = next_event(h, st, e0, S))) return rc;
+                if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
+                else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, S, A);
+                if ((rc = next_event(h, st, e1, S))) return rc;
+                (onB ? lastB : lastA) = e1;
+                st.timed.push_back({sweep ? kKidSweep : (h->split_kinds ? L.kid : kNumKernels), e0, e1, bytes, (double)grid, h->call_id});
                 n_wg += (double)grid;
-                e_prev = e_next;
                 li = lj;
+            }
+            if (two && lastB != kNone) HIP_TRY(h, hipStreamWaitEvent(h->stream, st.ev[lastB], 0));  // the main stream ends the wave
+            {
+                size_t e_last = 0;
+                if ((rc = next_event(h, st, e_last))) return rc;
+                st.timed.push_back({-1, e_first, e_last, 0.0, 0.0, h->call_id});
             }
             HIP_TRY(h, hipGetLastError());
             if (h->trace) {

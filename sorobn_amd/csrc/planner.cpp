@@ -1091,6 +1091,11 @@ struct Emitter {
                         }
                 }
                 if (src < 0 || g.nctrl >= 3) { ok = false; return; }
+                if (src >= 8) {  // at most two ctrl values come from r (the kernel keeps their shifts in scalar registers)
+                    int nr = 0;
+                    for (int c = 0; c < g.nctrl; ++c) nr += g.src[c] >= 8;
+                    if (nr >= 2) { ok = false; return; }
+                }
                 g.src[g.nctrl] = src;
                 g.cvar[g.nctrl] = v;
                 ++g.nctrl;
@@ -1100,21 +1105,11 @@ struct Emitter {
             g.t_off = t_total;
             t_total += g.t_cells;
             if (t_total > kSweepMaxT) return false;
-            // thread fields / loop digit: the free digits ascending, the loop digit = the highest one that is no ctrl
-            int free_[4], nf = 0;
-            for (int d = 0; d < k; ++d)
-                if (d != dig[j]) free_[nf++] = d;
-            int loop = -1;
-            for (int q = nf - 1; q >= 0 && loop < 0; --q) {
-                bool is_ctrl = false;
-                for (int c = 0; c < g.nctrl; ++c) is_ctrl = is_ctrl || g.src[c] == free_[q];
-                if (!is_ctrl) loop = free_[q];
-            }
-            if (loop < 0) loop = free_[nf - 1];
-            g.loop = loop;
+            // thread fields / loop digit (planner.h): a fixed rule, so that the kernel's stage geometry is known at compile time
+            g.loop = sweep_loop_digit(k, dig[j]);
             g.f[0] = g.f[1] = g.f[2] = 7;
-            for (int q = 0, m = 0; q < nf; ++q)
-                if (free_[q] != loop) g.f[m++] = free_[q];
+            for (int d = 0, m = 0; d < k; ++d)
+                if (d != dig[j] && d != g.loop) g.f[m++] = d;
             var_on[dig[j]] = g.newv;  // (-1: the digit is dead from here on)
         }
         for (int i = 0; i < n_in; ++i)
@@ -1154,6 +1149,11 @@ struct Emitter {
         w[7] = (uint32_t)kout | ((uint32_t)t_total << 16);
         w[8] = 0;
         for (int q = 0; q < kout; ++q) w[8] |= (uint32_t)surv[q] << (4 * q);
+        {
+            bool canon = net.sweep_canon != 0;
+            for (int j = 0; j < k; ++j) canon = canon && dig[j] == k - 1 - j;
+            if (canon) w[1] |= kFlagSweepCanon << 16;
+        }
         uint32_t *p = w + kHdrWords;
         put_off(p, F);
         for (int j = 0; j < k; ++j) {
@@ -1861,7 +1861,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }
@@ -2061,7 +2061,7 @@ const char *kernel_name(int kid) {
                         "fiber<" + std::to_string(nb) + "," + cxn[c] + "," + ncn[n] + ">";
         names[kKidChain] = "fiber<1,cx64,chain-mfma>";  // (the slot of the impossible class <2,cxN,outer-mfma>)
         for (int j = 0; j < kMaxIn; ++j) names[kKidGeneric0 + j] = "generic<" + std::to_string(j + 1) + ">";
-        names[kKidSweep] = "sweep<lds>";
+        names[kKidSweep] = "ve_sweep_kernel";
         init = true;
     }
     return kid >= 0 && kid < kNumKernels ? names[kid].c_str() : "?";
@@ -2107,7 +2107,7 @@ bool step_is_tiled(const Network &net, const uint32_t *w) {
 }
 
 int step_tile_h(const Network &net, const uint32_t *w) {
-    if ((w[0] & 0xff) == kKindSweep) return kSweepIters;  // (tiles of 64 KiB in, <= 64 KiB out)
+    if ((w[0] & 0xff) == kKindSweep) return std::max(1, std::min(net.sweep_iters, kTileMax));  // (tiles of 64 KiB in, <= 64 KiB out)
     if (net.tile_h > 0) return std::min(net.tile_h, kTileMax);
     // bytes one hi iteration moves = the step's section-8(d) traffic / hi (broadcast re-reads of a small "big" input
     // are cache hits, they do not count)

@@ -28,6 +28,7 @@ constexpr int kMaxAxes = 32;              // output axes per step after merging
 constexpr int kLoTarget = 256;            // lane-varying block: first axes whose product reaches this
 constexpr int kLoMax = 512;               // ... but never more than this many cells (2 per lane)
 constexpr uint64_t kConstFlag = 1ull << 63;  // in_off bit: table lives in the constants pool
+constexpr int kSweepItersDefault = 8;     // SWEEP: tiles per workgroup (Network::sweep_iters)
 
 struct Bits {
     std::array<uint64_t, kWords> w{};
@@ -78,6 +79,8 @@ struct Network {
     int chain = 1;           // CHAIN form: a third 4-state variable eliminated in the registers of the same pass
     int stagger = 1;         // build_schedule: groups of requests whose levels are staggered inside a chunk (1 = all in phase)
     int sweep = 5;           // SWEEP form: up to this many 4-state variables of one big table per pass, tile resident in LDS (0 = off)
+    int sweep_iters = kSweepItersDefault;  // tiles per workgroup of the sweep kernel
+    int sweep_canon = 1;     // 0 (test hook): never flag a SWEEP step canonical - the kernel's general path runs everything
 
     // returns "" or an error message
     std::string set(int32_t n, const int32_t *card_, const int64_t *scope_off, const int32_t *scope_vars,
@@ -163,7 +166,7 @@ struct PlanStats {
 //           L[.., n, ..] = sum_x L[.., x, ..] * T_j[n + cout_j * (x + 4 * (c0 + 4 * (c1 + 4 * c2)))]        n < cout_j
 //      cout_j = 4: the one new variable of the CPT slices that mention x_j takes over the digit; 1: the digit dies.  The
 //      ctrl values c0..c2 are four-state variables that are on a live digit right now (x_j' not yet eliminated, n_j'
-//      already introduced) or R axes of F with a power-of-two stride (bits of r).  T_j = product of the step's small
+//      already introduced) or R axes of F with a power-of-two stride (bits of r; at most two of the three).  T_j = product of the step's small
 //      inputs that mention x_j and none of x_1..x_{j-1}.  Output: the surviving digits (ascending) are the fastest axes,
 //      then F's R axes in F's order:  out index = sum_q val_q * 4^q + 4^kout * r.
 //      header: w0 = kind | n_in << 8 | k << 16 | log2(Rt) << 24;  w1 = 4^k | flags << 16;  w2 = 8192;  w3 = tiles = Rcells / Rt
@@ -174,15 +177,25 @@ struct PlanStats {
 //                                         s1 = T_j offset (cells) | T_j cells << 16
 //                                         ctrl c < 3:  src | tstride << 8     src 0..4 = digit, 8 + s = bits (r >> s) & 3
 //              per stage, per small input (7 words): off lo, off hi, stride of the new variable, of x_j, of ctrl 0..2
-//      A work item = kSweepIters consecutive tiles; one workgroup of kSweepWG lanes per item.
+//      flag SWEEP_CANON (w1): see kFlagSweepCanon.  The loop digit of a stage is sweep_loop_digit(k, dig), the thread fields are
+//      the other free digits in ascending order.
+//      A work item = Network::sweep_iters consecutive tiles; one workgroup of kSweepWG lanes per item.
 constexpr uint32_t kFlagFinal = 1, kFlagContig = 2, kFlagOuter = 4, kFlagChain = 8;
 constexpr uint32_t kKindSweep = 2;
 constexpr int kSweepTileCells = 8192;  // 64 KiB of LDS
 constexpr int kSweepMaxT = 1024;       // T cells of all stages together (8 KiB)
 constexpr int kSweepMaxSmall = 16;     // small inputs of all stages together
-constexpr int kSweepIters = 8;         // tiles per workgroup
 constexpr int kSweepWG = 512;
 constexpr int kSweepStageWords = 5, kSweepSmallWords = 7;
+constexpr uint32_t kFlagSweepCanon = 16;  // stage j contracts digit k-1-j (first eliminated = slowest axis, the layout rule): the
+                                          // kernel's compile-time stage geometry applies
+// the loop digit of a stage (the digit a lane's four fibers differ in): the highest one that is neither contracted nor -
+// the usual ctrl of a grid sweep - its lower neighbour
+constexpr int sweep_loop_digit(int k, int dig) {
+    for (int d = k - 1; d >= 0; --d)
+        if (d != dig && d != dig - 1) return d;
+    return -1;
+}
 constexpr int kRowStrideShift = 20;  // w1 bits 20..27
 constexpr int kHdrWords = 10;
 constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;  // (kKindSweep = 2 above)

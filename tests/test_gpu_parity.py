@@ -143,6 +143,7 @@ def test_c3_chain_form_vs_pair_form(amd):
     be = bn.backend
     q, ev, ec = netspec.c3_requests(100, 4, 4096, 4, seed=1)
     to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    be.engine.set_option("sweep", 0)  # (the SWEEP form would take these steps first: test_c3_sweep_form_vs_chain_form)
     be.engine.set_option("chain", 0)
     pair = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
     pair_bytes = be.engine.stats()["alg_bytes"]
@@ -168,11 +169,50 @@ def test_c3_chain_form_vs_pair_form(amd):
         for small_cells, tiling in [(3, (4, 1)), (20, (64, 2))]:
             b = netspec.build(sp, amd.BayesNet)
             b.backend.engine.set_option("chain", 1)
+            b.backend.engine.set_option("sweep", 0)
             b.backend.engine.set_option("tiny", 0)
             b.backend.engine.set_option("small_cells", small_cells)
             b.backend.engine.set_option("big_iters", tiling[0])
             b.backend.engine.set_option("tile_h", tiling[1])
             _check_requests(b, e["requests"], sp["name"] + " chain")
+
+
+def test_c3_sweep_form_vs_chain_form(amd):
+    """SWEEP steps (up to five variables per pass, the tile resident in LDS: ve_sweep_kernel, the default) against the
+    CHAIN / pair programs (option sweep=0) on the C3 stream: another kernel, another contraction order, a quarter fewer
+    bytes - and the golden 10x10 answers of the reference with three, four and five variables per pass."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 4096, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    be.engine.set_option("sweep", 0)
+    base = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    base_bytes = be.engine.stats()["alg_bytes"]
+    assert not any("sweep" in k["name"] for k in be.engine.kernel_stats())
+    entry = gu.load("grid10x10.json")
+    last = base_bytes
+    for k in (3, 4, 5):
+        be.engine.set_option("sweep", k)
+        got = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+        b = be.engine.stats()["alg_bytes"]
+        ks = {s["name"]: s for s in be.engine.kernel_stats()}
+        assert "ve_sweep_kernel" in ks and ks["ve_sweep_kernel"]["alg_bytes"] > 0.05 * b, list(ks)
+        assert b <= last
+        last = b
+        assert np.allclose(got.sum(1), 1.0, atol=1e-12)
+        assert float(np.max(np.abs(got - base))) <= 1e-13, k
+        _check_requests(bn, entry["requests"], f"grid10x10 sweep={k}")
+    assert last < 0.8 * base_bytes
+    be.engine.set_option("sweep_canon", 0)  # the kernel's general path (runtime strides) on the same programs
+    got = be.engine.query_fixed(to_var[q[:1024]][:, None], to_var[ev[:1024]], ec[:1024])
+    assert float(np.max(np.abs(got - base[:1024]))) <= 1e-13
+    be.engine.set_option("sweep_canon", 1)
+    # tables of 4^7 - 4^8 cells (one to eight tiles per step) on the 8x8 grid: every class of stage on small inputs
+    be.engine.set_option("big_iters", 512)
+    small = be.engine.query_fixed(to_var[q[:1024]][:, None], to_var[ev[:1024]], ec[:1024])
+    assert float(np.max(np.abs(small - base[:1024]))) <= 1e-13
+    be.engine.set_option("big_iters", 4096)
 
 
 def test_c3_bayes_rule_and_marginalisation_at_full_size(amd):
@@ -225,7 +265,7 @@ def test_fresh_random_dags_vs_oracle(amd, seed):
 
 @pytest.mark.parametrize("shape", [(8, 8), (9, 8), (8, 11)])
 def test_wide_grids_every_request_vs_oracle(amd, shape):
-    """Grids wide enough for the heavy step forms (CHAIN / pair MFMA / OUTER on 4^8..4^9-cell frontier tables) and
+    """Grids wide enough for the heavy step forms (SWEEP / CHAIN / pair MFMA / OUTER on 4^8..4^9-cell frontier tables) and
     still small enough for the CPU oracle to answer every request: 96 requests each, all compared."""
     from oracle.oracle import OracleNet
     R, C = shape
@@ -240,7 +280,11 @@ def test_wide_grids_every_request_vs_oracle(amd, shape):
     be.engine.set_option("split_kinds", 1)
     post = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
     names = {k["name"] for k in be.engine.kernel_stats()}
-    assert any("chain" in x for x in names) and any("nc16-mfma" in x for x in names), names
+    assert any("sweep" in x for x in names) and any("nc16-mfma" in x for x in names), names
+    be.engine.set_option("sweep", 0)  # ... and the same requests through the CHAIN / pair forms
+    post_chain = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert any("chain" in k["name"] for k in be.engine.kernel_stats())
+    assert float(np.max(np.abs(post - post_chain))) <= 1e-13
     worst = 0.0
     for i in range(96):
         codes, vals = on.query_codes([int(oid[q[i]])], oid[ev[i]].tolist(), ec[i].tolist())

@@ -216,6 +216,92 @@ __global__ __launch_bounds__(WG, 4) void sweep2(const double *__restrict__ in, d
     }
 }
 
+// ---- version 3: the loads of two adjacent tiles (r cells 0-7 and 8-15 of the same 128-byte lines) are issued together,
+// as back-to-back 64-byte requests for the two halves of every line
+template <int WG>
+__global__ __launch_bounds__(WG, 4) void sweep3(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ Tg,
+                                                int tiles_per_req, int iters) {
+    constexpr int PAD = 0;
+    constexpr int RT = 8, TILE = kXC * RT;
+    extern __shared__ double lds[];
+    double *L = lds;
+    double *T = lds + kPadTile;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < 5 * 64; t += WG) T[t] = Tg[t];
+    constexpr int PER = TILE / 2 / WG;   // double2 per thread and tile: 8
+    double va[2 * PER], vb[2 * PER];
+    const int first = blockIdx.x * iters;    // iters = number of tile PAIRS
+    const int rp = tid & 3;
+#define LOADPAIR(pair_id_)                                                                           \
+    {                                                                                                \
+        const int req_ = (2 * (pair_id_)) / tiles_per_req, tile_ = (2 * (pair_id_)) % tiles_per_req; \
+        const double *__restrict__ F_ = in + (long)req_ * kCells + tile_ * RT;                       \
+        _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                            \
+            const int xc = (i * WG + tid) >> 2;                                                      \
+            const double2 qa = *reinterpret_cast<const double2 *>(F_ + (long)xc * kR + 2 * rp);      \
+            const double2 qb = *reinterpret_cast<const double2 *>(F_ + (long)xc * kR + 8 + 2 * rp);  \
+            va[2 * i] = qa.x; va[2 * i + 1] = qa.y; vb[2 * i] = qb.x; vb[2 * i + 1] = qb.y;          \
+        }                                                                                            \
+    }
+#define STAGES_AND_STORE(O_, AFTER_STAGES)                                                           \
+    {                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                              \
+            const int dig = 4 - j, cdig = dig + 1;                                                   \
+            const int ldig = j == 0 ? 3 : (j == 1 ? 2 : (j == 4 ? 3 : 4));                           \
+            constexpr int PERF = TILE / 4 / WG;                                                      \
+            int rem = tid, base = rem & 7;                                                           \
+            rem >>= 3;                                                                               \
+            int ctrl = 0;                                                                            \
+            _Pragma("unroll") for (int d = 0; d < 5; ++d) {                                          \
+                if (d == dig || d == ldig) continue;                                                 \
+                const int val = rem & 3;                                                             \
+                rem >>= 2;                                                                           \
+                base += val * pst(d);                                                                \
+                if (d == cdig && j > 0) ctrl = val;                                                  \
+            }                                                                                        \
+            double t[16];                                                                            \
+            const double *Tp = T + j * 64 + ctrl * 16;                                               \
+            _Pragma("unroll") for (int q = 0; q < 16; ++q) t[q] = Tp[q];                             \
+            _Pragma("unroll") for (int l = 0; l < PERF; ++l) {                                       \
+                const int b = base + (rem * PERF + l) * pst(ldig);                                   \
+                double f[4];                                                                         \
+                _Pragma("unroll") for (int x = 0; x < 4; ++x) f[x] = L[b + x * pst(dig)];            \
+                _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                      \
+                    double sacc = 0;                                                                 \
+                    _Pragma("unroll") for (int x = 0; x < 4; ++x) sacc += f[x] * t[x * 4 + n];       \
+                    L[b + n * pst(dig)] = sacc;                                                      \
+                }                                                                                    \
+            }                                                                                        \
+            __syncthreads();                                                                         \
+        }                                                                                            \
+        AFTER_STAGES;                                                                                \
+        constexpr int PERS = TILE / WG;                                                              \
+        _Pragma("unroll") for (int i = 0; i < PERS; ++i) {                                           \
+            const int c = i * WG + tid;                                                              \
+            const int r = (c >> 10) & 7;                                                             \
+            (O_)[c] = L[r + 8 * (c & 1023)];                                                         \
+        }                                                                                            \
+    }
+    LOADPAIR(first);
+    for (int it = 0; it < iters; ++it) {
+        const int tile_id = 2 * (first + it);
+        const int req = tile_id / tiles_per_req, tile = tile_id % tiles_per_req;
+        double *__restrict__ O = out + (long)req * kCells + (long)tile * RT * kXC;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) *reinterpret_cast<double2 *>(L + 2 * (i * WG + tid)) = make_double2(va[2 * i], va[2 * i + 1]);
+        __syncthreads();
+        STAGES_AND_STORE(O, );
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; ++i) *reinterpret_cast<double2 *>(L + 2 * (i * WG + tid)) = make_double2(vb[2 * i], vb[2 * i + 1]);
+        __syncthreads();
+        STAGES_AND_STORE(O + RT * kXC, LOADPAIR(first + min(it + 1, iters - 1)));
+    }
+#undef LOADPAIR
+#undef STAGES_AND_STORE
+}
+
 template <class Fn>
 static double time_ms(Fn f, int reps) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -288,6 +374,25 @@ int main(int argc, char **argv) {
         for (int k = 0; k < 40; ++k) { const int r = (k * 131) % kR, nc = (k * 577) % 1024; const double e = ref(r, nc); err = fmax(err, fabs(o[(long)r * kXC + nc] - e) / e); } \
         printf("%-60s %8.3f ms  %8.1f GB/s  max rel err %.1e\n", label, ms, gb / ms * 1e3, err); fflush(stdout);            \
     }
+
+#define RUN3(WG, ITERS, label)                                                                                               \
+    {                                                                                                                        \
+        const int tiles = kR / 8;                                                                                            \
+        const size_t lds = (size_t)(kPadTile + 5 * 64) * 8;                                                                  \
+        CHECK(hipFuncSetAttribute((const void *)sweep3<WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        CHECK(hipMemset(out, 0, n * 8));                                                                                     \
+        { int nb = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)sweep3<WG>, WG, lds)); printf("[WGs/CU %d] ", nb); } \
+        const double ms = time_ms([&] { hipLaunchKernelGGL((sweep3<WG>), dim3(nreq * tiles / 2 / ITERS), dim3(WG), lds, 0, in, out, T, tiles, ITERS); }, 20); \
+        CHECK(hipGetLastError());                                                                                            \
+        std::vector<double> o(kCells);                                                                                       \
+        CHECK(hipMemcpy(o.data(), out + (long)(nreq - 1) * kCells, kCells * 8, hipMemcpyDeviceToHost));                       \
+        double err = 0;                                                                                                      \
+        for (int k = 0; k < 40; ++k) { const int r = (k * 131) % kR, nc = (k * 577) % 1024; const double e = ref(r, nc); err = fmax(err, fabs(o[(long)r * kXC + nc] - e) / e); } \
+        printf("%-60s %8.3f ms  %8.1f GB/s  max rel err %.1e\n", label, ms, gb / ms * 1e3, err); fflush(stdout);            \
+    }
+    RUN3(512, 4, "v3 128-byte runs for tile pairs, 512 thr, 4 pairs/WG");
+    RUN3(512, 8, "v3 128-byte runs for tile pairs, 512 thr, 8 pairs/WG");
+    RUN3(512, 2, "v3 128-byte runs for tile pairs, 512 thr, 2 pairs/WG");
     RUN2(512, 1, 1, 8, "v2 padded+prefetch, 512 thr, 8 tiles/WG");
     RUN2(512, 1, 0, 8, "v2 pow2 strides+prefetch, 512 thr, 8 tiles/WG");
     RUN2(512, 0, 0, 8, "v2 pow2 strides, no prefetch, 512 thr, 8 tiles/WG");
