@@ -180,7 +180,8 @@ struct mibn_ctx {
     // options
     double arena_gb = 96.0;
     hipStream_t stream2 = nullptr;  // the sweep kernel's stream (n_streams = 2: the two kernels of a level overlap)
-    int n_streams = 2;
+    int n_streams = 1;  // 2: the sweep kernel of a level on a stream of its own, overlapping the level kernel (+3 % on C3; per-kernel times then include the contention)
+    int first_chunk = 1;  // short first chunk of a call: 0 never, 1 when the GPU is idle, 2 always
     int threads = 0;
     int trace = 0;        // debug: one stderr line per launch
     int split_kinds = 0;  // profiling: one launch per (level, class of work) instead of one per level
@@ -347,7 +348,8 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "fuse") h->net.fuse = value != 0;
     else if (n == "plan_cache") h->net.plan_cache = value != 0;  // plan templates for repeated request shapes
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
-    else if (n == "streams") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_streams = value >= 2 ? 2 : 1; }  // 1: the sweep kernel on the main stream, after the level kernel
+    else if (n == "streams") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_streams = value >= 2 ? 2 : 1; }  // 1 (default): the sweep kernel on the main stream, after the level kernel; 2: on its own stream, overlapping it
+    else if (n == "first_chunk") h->first_chunk = std::max(0, std::min(2, (int)value));
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
     else if (n == "sweep_iters") h->net.sweep_iters = std::max(1, std::min(kTileMax, (int)value));  // tiles per workgroup of the sweep kernel
     else if (n == "sweep") h->net.sweep = std::max(0, std::min(5, (int)value));  // SWEEP form: up to this many variables per pass, tile in LDS (0 / < 3: off)
@@ -795,9 +797,13 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     const bool search_on = h->gpu_search && h->order_net_ok;
     int64_t search_b0 = -1;
     bool search_done = false;
-    // a short first chunk gets the GPU going while the host plans the first full-size one
+    // a short first chunk gets an idle GPU going while the host plans the first full-size one (first_chunk = 2: also when
+    // an earlier asynchronous call still keeps the GPU busy; 0: never)
+    bool gpu_busy = false;
+    for (auto &st : h->set) gpu_busy = gpu_busy || (st.busy && st.ev_used && hipEventQuery(st.ev[st.ev_used - 1]) == hipErrorNotReady);
+    const bool short_first = h->first_chunk == 2 || (h->first_chunk == 1 && !gpu_busy);
     for (int64_t b0 = 0, b1 = 0; b0 < B; b0 = b1, ++n_chunks) {
-        b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
+        b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk && short_first ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
         const int64_t n = b1 - b0;
         mibn_ctx::Set &st = h->set[h->set_cursor];
         h->set_cursor = (h->set_cursor + 1) % h->n_sets;

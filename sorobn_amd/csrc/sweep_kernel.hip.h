@@ -12,7 +12,8 @@
 //     digits of the fiber or bits of r) and writes the cout results over the fiber: the new variable takes the digit of the
 //     eliminated one (cout = 4) or the digit dies (cout = 1).  64 fp64 FMAs per 64 bytes of LDS traffic, five times;
 //   * the tile's output - surviving digits fastest, then r - is ONE contiguous block of Rt * 4^kout cells;
-//   * the next tile's loads are issued before the stores of the current one and land in registers.
+//   * the next tile's loads are issued before the stores of the current one and land in registers (PMC calibration on a
+//     known byte count, profiles/r02_u_pmc_calibration.log: WRITE_SIZE exact; FETCH_SIZE counts these 64-byte runs in full).
 // LDS: 64 KiB tile + 8 KiB T + 1.5 KiB descriptor = 73.5 KiB -> two workgroups per CU, 4 waves per SIMD (<= 128 VGPRs).
 // Measured form of the idea: tools/ubench/sweep_lds.hip (five variables, 4.0 - 4.3 TB/s of algorithmic traffic).
 #pragma once
@@ -159,11 +160,14 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
         MIBN_SWEEP_STAGE(3)
         MIBN_SWEEP_STAGE(4)
 #undef MIBN_SWEEP_STAGE
-        {   // the next tile's loads fly during the stores (the last trip re-reads its own tile: no branch around the loads)
-            const double *__restrict__ Ft = F + (long)min(tile + 1, t_end - 1) * Rt + g_tid;
+        {   // the next tile's loads fly during the stores.  No branch around them (the compiler then keeps v[] in scratch):
+            // after the last tile every lane re-reads one and the same cell pair instead - one 64-byte request per wave
+            const long more = tile + 1 < t_end ? 1 : 0;
+            const double *__restrict__ Ft = F + (long)(tile + more) * Rt + more * g_tid;
+            const long g_step_ = more * g_step;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const double2 q = *reinterpret_cast<const double2 *>(Ft + i * g_step);
+                const double2 q = *reinterpret_cast<const double2 *>(Ft + i * g_step_);
                 v[2 * i] = q.x;
                 v[2 * i + 1] = q.y;
             }

@@ -1,0 +1,41 @@
+"""profiles/<tag>_rocprofv3_summary.txt -> profiles/<tag>_pmc.json: HBM traffic per launch of every kernel of the exact path.
+
+    python tools/make_pmc_json.py profiles/r02_u_rocprofv3_summary.txt
+
+FETCH_SIZE / WRITE_SIZE come from separate rocprofv3 --pmc passes of the bench command (tools/gpu_profile.sh).  On gfx950
+FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM section): doubled for ve_level_kernel, whose
+waves read 512 contiguous bytes per instruction.  ve_sweep_kernel reads runs of 64 bytes, which the counter tallies in
+full: calibrated on a known byte count (tools/gpu_r02_calib.sh, profiles/r02_u_pmc_calibration.log: WRITE_SIZE exact,
+FETCH_SIZE = bytes read), so no correction there.  The algorithmic bytes per launch of the same command are taken from
+the bench line at the end of the summary.  bench.py's `roofline.traffic` reads
+the newest profiles/r*_pmc.json.
+"""
+import json
+import re
+import sys
+
+path = sys.argv[1]
+text = open(path).read()
+fetch, write = {}, {}
+for m in re.finditer(r"pmc (FETCH_SIZE|WRITE_SIZE): (\S+?)\(.*? launches (\d+) avg value ([0-9.]+) KB", text):
+    name = m.group(2).split("::")[-1]
+    (fetch if m.group(1) == "FETCH_SIZE" else write)[name] = (int(m.group(3)), float(m.group(4)))
+line = [l for l in text.splitlines() if l.startswith('{"metric"')]
+bench = json.loads(line[-1]) if line else {}
+per = {}
+for name in sorted(set(fetch) & set(write)):
+    f, w = fetch[name][1], write[name][1]
+    k = bench.get("kernels", {}).get(name)
+    corr = 1.0 if name == "ve_sweep_kernel" else 2.0
+    per[name] = {"launches_under_the_counters": fetch[name][0], "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
+                 "fetch_correction": corr, "traffic_bytes_per_launch": corr * f * 1024 + w * 1024,
+                 "alg_bytes_per_launch_same_run": (k["alg_GB"] * 1e9 / k["launches"]) if k else None}
+out = {"source": path + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of the bench command)",
+       "note": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled for ve_level_kernel; ve_sweep_kernel's 64-byte runs are "
+               "counted in full (calibration: profiles/r02_u_pmc_calibration.log); WRITE_SIZE as reported", "per_kernel": per}
+dst = path.replace("_rocprofv3_summary.txt", "_pmc.json")
+json.dump(out, open(dst, "w"), indent=1)
+print(dst)
+for n, d in per.items():
+    a = d["alg_bytes_per_launch_same_run"]
+    print("  %-20s traffic %.3f GB / launch, algorithmic %.3f GB -> %.3f" % (n, d["traffic_bytes_per_launch"] / 1e9, (a or 0) / 1e9, d["traffic_bytes_per_launch"] / a if a else float("nan")))
