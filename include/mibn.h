@@ -173,8 +173,11 @@ int mibn_device_synchronize(mibn_t *h);
  * host: identical orders and programs; 2: every chunk, synchronously - tests), "minfill_above" (bytes of the best sweep order above which the min-fill search runs), "stagger" (groups
  * of requests whose levels are staggered inside a chunk), "tiny" (0: never use the
  * small-network kernel - one lane per request, CPTs in LDS, no planning - that answers blocking calls on networks of at
- * most 32 variables / 4096 CPT cells / 65536 joint states).
- * Test and profiling hooks: "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the
+ * most 32 variables / 4096 CPT cells / 65536 joint states), "sweep" (0..5: the most four-state variables of one big table
+ * a single pass may eliminate with the tile resident in LDS - ve_sweep_kernel; below 3: off), "sweep_iters" (tiles per
+ * workgroup of that kernel), "streams" (2: the sweep kernel of a level on a stream of its own, overlapping the level
+ * kernel), "first_chunk" (short first chunk of a call: 0 never, 1 when the GPU is idle, 2 always).
+ * Test and profiling hooks: "sweep_canon" (0: the sweep kernel's general path for every step), "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the
  * kernels' step forms onto small networks), "split_kinds" (one launch per class of work and level, so that
  * mibn_last_kernel_stats reports per-class rates), "trace" (one stderr line per launch), "gibbs_lds" (0: the Gibbs
  * kernel reads the CPTs through L2 even when they would fit in LDS). */
