@@ -350,6 +350,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
     else if (n == "streams") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_streams = value >= 2 ? 2 : 1; }  // 1 (default): the sweep kernel on the main stream, after the level kernel; 2: on its own stream, overlapping it
     else if (n == "first_chunk") h->first_chunk = std::max(0, std::min(2, (int)value));
+    else if (n == "order_weights") h->net.order_weights = value != 0;  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
     else if (n == "sweep_iters") h->net.sweep_iters = std::max(1, std::min(kTileMax, (int)value));  // tiles per workgroup of the sweep kernel
     else if (n == "sweep") h->net.sweep = std::max(0, std::min(5, (int)value));  // SWEEP form: up to this many variables per pass, tile in LDS (0 / < 3: off)
@@ -602,6 +603,11 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
         A.net = h->order_net_dev;
         A.net.prune = h->net.prune;
         A.net.minfill_above = h->net.minfill_above;
+        {   // (options set after the network: the model weights follow them like on the host)
+            const OrderNet hv = h->net.order_view();
+            A.net.chain_weight = hv.chain_weight;
+            A.net.big_cells = hv.big_cells;
+        }
         A.q_off = reinterpret_cast<const int64_t *>(h->d_search_req) + s0;
         A.e_off = reinterpret_cast<const int64_t *>(h->d_search_req + off_bytes) + s0;
         A.q_vars = reinterpret_cast<const int32_t *>(h->d_search_req + 2 * off_bytes);

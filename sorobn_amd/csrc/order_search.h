@@ -49,6 +49,12 @@ struct OrderNet {
     const int32_t *hint_sorted = nullptr;  // [n_hints][n] every hint as a variable list in ascending (priority, id) order
     int32_t prune = 1;
     double minfill_above = 2e7;
+    // Weight of an elimination that consumes exactly ONE big table (> big_cells cells) in the byte model below.  Such steps
+    // chain into multi-variable passes (pair / CHAIN / SWEEP: up to five eliminations for one read and one write of the
+    // table), the joins of two big tables do not and are the slowest bytes of a plan: with the SWEEP form on, candidate
+    // orders are compared with the single-table steps at a quarter of their section-8(d) bytes.  (Powers of two only: the
+    // host and the device search must round alike.)
+    double chain_weight = 1.0, big_cells = 1024.0;
 };
 
 constexpr int kOrderSlotWords = 5, kOrderSlots = 64 * kOrderSlotWords;  // factor slots of the byte model: <= 128 CPTs + 128 created + 1
@@ -107,6 +113,7 @@ MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const
         const int x = order[o];
         B2 u;
         double in = 0;
+        int nbig = 0;
         for (int k = 0; k < kOrderSlotWords; ++k) {
             uint64_t m = S.mem[x][k] & alive[k];
             alive[k] &= ~m;
@@ -115,11 +122,12 @@ MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const
                 u.a |= S.f[i].a;
                 u.b |= S.f[i].b;
                 in += S.fc[i];
+                nbig += S.fc[i] > net.big_cells;
             }
         }
         u.clr(x);
         const double uc = order_cells(net, u);
-        bytes += 8.0 * (in + uc);
+        bytes += (nbig == 1 ? 8.0 * net.chain_weight : 8.0) * (in + uc);
         if (bytes > abort_above) return bytes;
         S.f[nf] = u;
         S.fc[nf] = uc;
@@ -198,7 +206,7 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
         S.cand[S.n_cand++] = (uint8_t)best;
         alive[best] = 0;
         created += order_exp2(ws[best]);  // cells of the factor this elimination creates (its scope = the neighbours)
-        if (16.0 * created > abort_above) return false;
+        if (16.0 * net.chain_weight * created > abort_above) return false;
         const B2 nb = adj[best];
         b2_each(nb, [&](int y) {
             B2 fresh;  // members of nb not yet adjacent to y
@@ -305,7 +313,7 @@ MIBN_HD inline double order_search(const OrderNet &net, OrderScratch &S, int nq,
     }
     // greedy min-fill: the best order on 60 % of the C3 requests (52.7 MB mean against 67.6 MB for the sweeps alone),
     // skipped where the sweeps already found a plan too cheap to be worth the time
-    if (best_cost > net.minfill_above && order_greedy(net, S, hidden, best_cost)) consider();
+    if (best_cost > net.minfill_above * net.chain_weight && order_greedy(net, S, hidden, best_cost)) consider();
     return best_cost;
 }
 

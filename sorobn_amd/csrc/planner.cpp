@@ -130,6 +130,8 @@ OrderNet Network::order_view() const {
     o.hint_sorted = hint_flat.data();
     o.prune = prune;
     o.minfill_above = minfill_above;
+    o.chain_weight = (fuse && sweep >= 4 && order_weights) ? 0.25 : 1.0;
+    o.big_cells = (double)small_cells;
     return o;
 }
 
@@ -1861,7 +1863,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.order_weights); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }

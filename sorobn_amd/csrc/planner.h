@@ -80,6 +80,7 @@ struct Network {
     int stagger = 1;         // build_schedule: groups of requests whose levels are staggered inside a chunk (1 = all in phase)
     int sweep = 5;           // SWEEP form: up to this many 4-state variables of one big table per pass, tile resident in LDS (0 = off)
     int sweep_iters = kSweepItersDefault;  // tiles per workgroup of the sweep kernel
+    int order_weights = 1;   // compare candidate orders with single-table eliminations at a quarter of their bytes (order_search.h)
     int sweep_canon = 1;     // 0 (test hook): never flag a SWEEP step canonical - the kernel's general path runs everything
 
     // returns "" or an error message
