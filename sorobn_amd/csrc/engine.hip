@@ -350,6 +350,15 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
     else if (n == "streams") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_streams = value >= 2 ? 2 : 1; }  // 1 (default): the sweep kernel on the main stream, after the level kernel; 2: on its own stream, overlapping it
     else if (n == "first_chunk") h->first_chunk = std::max(0, std::min(2, (int)value));
+    else if (n == "builtin_sweeps") {  // two depth-first topological orders as candidate elimination orders (rebuilds the hint lists)
+        h->net.builtin_sweeps = value != 0;
+        if (h->net.n_vars > 0) {
+            std::vector<int32_t> flat;
+            for (const auto &hh : h->net.hints) flat.insert(flat.end(), hh.begin(), hh.end());
+            h->net.set_hints((int32_t)h->net.hints.size(), flat.data());
+            if (!h->planner_only) return upload_order_net(h);
+        }
+    }
     else if (n == "order_weights") h->net.order_weights = value != 0;  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
     else if (n == "sweep_iters") h->net.sweep_iters = std::max(1, std::min(kTileMax, (int)value));  // tiles per workgroup of the sweep kernel

@@ -113,7 +113,38 @@ std::string Network::set(int32_t n, const int32_t *card_, const int64_t *scope_o
             for (int32_t u : scope[v]) scope2[v].set(u);
         }
     }
+    if (err.empty()) set_hints(0, nullptr);  // the built-in sweep lists
     return err;
+}
+
+// Two depth-first topological orders (Kahn's algorithm with a stack; the children of a finished node pushed in ascending /
+// descending id order): on a grid the column-major and the row-major sweep, on any DAG two sweeps that finish one branch
+// before they start the next.  Candidate elimination orders next to the host's hints.
+static void lifo_topological(const Network &net, bool ascending, std::vector<int32_t> &out) {
+    const int n = net.n_vars;
+    std::vector<int> indeg(n, 0);
+    std::vector<std::vector<int32_t>> children(n);
+    for (int v = 0; v < n; ++v)
+        for (size_t i = 0; i + 1 < net.scope[v].size(); ++i) {
+            children[net.scope[v][i]].push_back(v);
+            ++indeg[v];
+        }
+    std::vector<int32_t> stack;
+    for (int v = 0; v < n; ++v) {
+        const int r = ascending ? v : n - 1 - v;
+        if (indeg[r] == 0) stack.push_back(r);
+    }
+    out.clear();
+    while (!stack.empty()) {
+        const int v = stack.back();
+        stack.pop_back();
+        out.push_back(v);
+        std::vector<int32_t> &ch = children[v];
+        std::sort(ch.begin(), ch.end());
+        if (!ascending) std::reverse(ch.begin(), ch.end());
+        for (int32_t c : ch)
+            if (--indeg[c] == 0) stack.push_back(c);
+    }
 }
 
 OrderNet Network::order_view() const {
@@ -139,15 +170,27 @@ void Network::set_hints(int32_t n_hints, const int32_t *priorities) {
     hints.clear();
     hint_sorted.clear();
     hint_flat.clear();
+    auto add_list = [&](std::vector<int32_t> &&o) {
+        if ((int)o.size() != n_vars) return;
+        for (const auto &have : hint_sorted)
+            if (have == o) return;  // (the host's name order of a grid IS one of the built-in sweeps)
+        hint_flat.insert(hint_flat.end(), o.begin(), o.end());
+        hint_sorted.push_back(std::move(o));
+    };
     for (int i = 0; i < n_hints; ++i) {
         hints.emplace_back(priorities + (size_t)i * n_vars, priorities + (size_t)(i + 1) * n_vars);
         std::vector<int32_t> o(n_vars);
         std::iota(o.begin(), o.end(), 0);
         const std::vector<int32_t> &h = hints.back();
         std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return h[a] < h[b]; });
-        hint_flat.insert(hint_flat.end(), o.begin(), o.end());
-        hint_sorted.push_back(std::move(o));
+        add_list(std::move(o));
     }
+    if (builtin_sweeps)
+        for (int asc = 0; asc < 2; ++asc) {
+            std::vector<int32_t> o;
+            lifo_topological(*this, asc != 0, o);
+            add_list(std::move(o));
+        }
 }
 
 bool request_is_valid(const Network &net, const Request &rq) {
@@ -1863,7 +1906,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.order_weights); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }

@@ -58,7 +58,7 @@ struct Network {
     std::vector<Bits> anc;                       // ancestors (bayes_net.py:373-378), memoised
     std::vector<int32_t> depth;                  // longest path from a root
     std::vector<std::vector<int32_t>> hints;     // optional priority arrays (lower = earlier); install with set_hints()
-    std::vector<std::vector<int32_t>> hint_sorted;  // every hint as a variable list in ascending (priority, id) order
+    std::vector<std::vector<int32_t>> hint_sorted;  // every hint as a variable list in ascending (priority, id) order, then the built-in sweeps
     std::vector<int32_t> topo_asc, topo_desc;    // all variables by (depth ascending, id) / (depth descending, id)
     // networks of up to 128 variables: what the shared host / device order search reads (order_search.h)
     std::vector<B2> anc2, scope2;
@@ -80,6 +80,8 @@ struct Network {
     int stagger = 1;         // build_schedule: groups of requests whose levels are staggered inside a chunk (1 = all in phase)
     int sweep = 5;           // SWEEP form: up to this many 4-state variables of one big table per pass, tile resident in LDS (0 = off)
     int sweep_iters = kSweepItersDefault;  // tiles per workgroup of the sweep kernel
+    int builtin_sweeps = 0;  // 1: two depth-first topological orders (grid: row- and column-major) as candidate orders next to the host's
+                             // hints: -2 % bytes on C3, no measurable time (profiles/r02_w_builtin_sweeps.log): off by default
     int order_weights = 1;   // compare candidate orders with single-table eliminations at a quarter of their bytes (order_search.h)
     int sweep_canon = 1;     // 0 (test hook): never flag a SWEEP step canonical - the kernel's general path runs everything
 
