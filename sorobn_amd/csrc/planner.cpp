@@ -1839,7 +1839,8 @@ static uint32_t tag_request(const Network &net, const uint32_t *prog, std::vecto
         if (step_is_tiled(net, w)) {
             flush();
             const uint32_t th = (uint32_t)step_tile_h(net, w);
-            out.push_back({off, th, (w[3] + th - 1) / th, level, (uint16_t)kernel_id_of_step(w), (float)bytes});
+            // (SWEEP items carry their tile count: build_schedule sizes the workgroups of a level's sweep launch as a whole)
+            out.push_back({off, (w[0] & 0xff) == kKindSweep ? w[3] : th, (w[3] + th - 1) / th, level, (uint16_t)kernel_id_of_step(w), (float)bytes});
             ++level;
         } else {
             if (!seg_steps) seg_first = off;
@@ -1906,7 +1907,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_adapt); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }
@@ -2219,6 +2220,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
     const size_t nb = (size_t)n_levels * kNumKernels;
     std::vector<size_t> count(nb + 1, 0);
     std::vector<double> bytes(nb, 0.0);
+    std::vector<uint64_t> sweep_tiles((size_t)n_levels, 0);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t r = r0 + i;
         const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
@@ -2227,8 +2229,23 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
             const size_t bkt = (size_t)(tg[k].level + sh) * kNumKernels + kClassOrder.rank_of[tg[k].kid];
             ++count[bkt + 1];
             bytes[bkt] += tg[k].bytes;
-            n_wg += tg[k].wgs;
+            if (tg[k].kid == kKidSweep) sweep_tiles[(size_t)(tg[k].level + sh)] += tg[k].a;
+            else n_wg += tg[k].wgs;
         }
+    }
+    // Tiles per workgroup of a level's sweep launch: net.sweep_iters where the launch is big enough to keep every CU busy
+    // for several workgroup lifetimes (one lives ~ 20 us per tile, 512 are resident), fewer - down to 2: the next tile's
+    // loads fly under the current one's stores - where it is not, so that the tail of the launch stays short.
+    std::vector<uint32_t> sweep_iters((size_t)n_levels, (uint32_t)std::max(1, net.sweep_iters));
+    if (net.sweep_adapt)
+        for (int l = 0; l < n_levels; ++l)
+            while (sweep_iters[(size_t)l] > 2 && sweep_tiles[(size_t)l] / sweep_iters[(size_t)l] < (uint64_t)net.sweep_adapt) sweep_iters[(size_t)l] /= 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = r0 + i;
+        const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
+        const int sh = shift(i);
+        for (uint32_t k = 0; k < bp.tag_count[r]; ++k)
+            if (tg[k].kid == kKidSweep) { const uint32_t it = sweep_iters[(size_t)(tg[k].level + sh)]; n_wg += (tg[k].a + it - 1) / it; }
     }
     for (size_t k = 0; k < nb; ++k) count[k + 1] += count[k];
     // pass 2: scatter (Item::b = workgroups of the item for now)
@@ -2238,8 +2255,11 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         const int64_t r = r0 + i;
         const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
         const int sh = shift(i);
-        for (uint32_t k = 0; k < bp.tag_count[r]; ++k)
-            out.items[cur[(size_t)(tg[k].level + sh) * kNumKernels + kClassOrder.rank_of[tg[k].kid]]++] = Item{(uint32_t)i, tg[k].rel_off, tg[k].a, tg[k].wgs};
+        for (uint32_t k = 0; k < bp.tag_count[r]; ++k) {
+            uint32_t a = tg[k].a, wgs = tg[k].wgs;
+            if (tg[k].kid == kKidSweep) { const uint32_t it = sweep_iters[(size_t)(tg[k].level + sh)]; wgs = (a + it - 1) / it; a = it; }
+            out.items[cur[(size_t)(tg[k].level + sh) * kNumKernels + kClassOrder.rank_of[tg[k].kid]]++] = Item{(uint32_t)i, tg[k].rel_off, a, wgs};
+        }
     }
     // pass 3: workgroup -> item table, level by level
     out.wg_item.resize(n_wg);

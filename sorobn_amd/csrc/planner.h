@@ -80,6 +80,7 @@ struct Network {
     int stagger = 1;         // build_schedule: groups of requests whose levels are staggered inside a chunk (1 = all in phase)
     int sweep = 5;           // SWEEP form: up to this many 4-state variables of one big table per pass, tile resident in LDS (0 = off)
     int sweep_iters = kSweepItersDefault;  // tiles per workgroup of the sweep kernel
+    int sweep_adapt = 4096;  // build_schedule: fewer tiles per workgroup (down to 2) in sweep launches of fewer workgroups than this (0: off)
     int builtin_sweeps = 0;  // 1: two depth-first topological orders (grid: row- and column-major) as candidate orders next to the host's
                              // hints: -2 % bytes on C3, no measurable time (profiles/r02_w_builtin_sweeps.log): off by default
     int order_weights = 1;   // compare candidate orders with single-table eliminations at a quarter of their bytes (order_search.h)
@@ -244,7 +245,7 @@ private:
 // One work item of a request, tagged while the request's program is still in the planning worker's cache.
 struct Tag {
     uint32_t rel_off;  // word offset of the (first) step inside the request's program
-    uint32_t a;        // SEGMENT: number of steps | kItemSegment.  TILED step: hi iterations per tile
+    uint32_t a;        // SEGMENT: number of steps | kItemSegment.  TILED step: hi iterations per tile.  SWEEP step: its tiles
     uint32_t wgs;      // workgroups: 1, or the number of tiles
     uint16_t level, kid;
     float bytes;       // algorithmic bytes

@@ -63,6 +63,37 @@ __device__ __forceinline__ void sweep_fibers(double *__restrict__ L, const doubl
     }
 }
 
+// T_j[n + cout * (x + 4 * ctrl)] = product of the CPT slices of stage j, all stages of the step (once per work item)
+struct SweepTables {
+    double *T;
+    const uint32_t *stw, *smw;
+    const double *pool;
+    const double *slot;
+    int k, t_total;
+};
+__device__ __forceinline__ void sweep_build_tables(const SweepTables &b, const int tid) {
+    for (int t = tid; t < b.t_total; t += kSweepWG) {
+        int j = 0, rec0 = 0;
+        while (j + 1 < b.k && t >= (int)((b.stw[j * kSweepStageWords + 1] & 0xffff) + (b.stw[j * kSweepStageWords + 1] >> 16))) {
+            rec0 += (int)((b.stw[j * kSweepStageWords] >> 8) & 15);
+            ++j;
+        }
+        const uint32_t s0 = b.stw[j * kSweepStageWords], s1 = b.stw[j * kSweepStageWords + 1];
+        const int cout = (s0 >> 4) & 15, ns = (s0 >> 8) & 15;
+        const int e = t - (int)(s1 & 0xffff);
+        const int n = cout == 4 ? (e & 3) : 0;
+        const int r = cout == 4 ? (e >> 2) : e;
+        const int x = r & 3, c0 = (r >> 2) & 3, c1 = (r >> 4) & 3, c2 = (r >> 6) & 3;
+        double v = 1.0;
+        for (int i = 0; i < ns; ++i) {
+            const uint32_t *rec = b.smw + (rec0 + i) * kSweepSmallWords;
+            const int off = n * (int)rec[2] + x * (int)rec[3] + c0 * (int)rec[4] + c1 * (int)rec[5] + c2 * (int)rec[6];
+            v *= table_ptr(rec[0], rec[1], b.pool, b.slot)[off];
+        }
+        b.T[t] = v;
+    }
+}
+
 // What a lane keeps per stage across the tiles of a work item: the LDS index of its first fiber and the T offset its digits
 // select.  Everything else of a stage is uniform and re-derived from the descriptor words (scalar registers) per tile.
 __device__ __forceinline__ void sweep_stage_lane(const uint32_t s0, const uint32_t s1, const uint32_t (&cw)[3], const int rb, const int tid,
@@ -93,7 +124,7 @@ template <int K>
 __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const double *__restrict__ T, const uint32_t *stw, const int k_rt,
                                                  const int rb_rt, const double *__restrict__ F, double *__restrict__ outp,
                                                  const long Rcells, const int t_begin, const int t_end, const int kout,
-                                                 const uint32_t surv, const int tid) {
+                                                 const uint32_t surv, const int tid, const SweepTables &tb) {
     constexpr int KS = K ? K : 5;  // stage slots
     const int k = K ? K : k_rt, rb = K ? 13 - 2 * K : rb_rt;
     const int Rt = 1 << rb;
@@ -127,6 +158,7 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
             v[2 * i + 1] = q.y;
         }
     }
+    sweep_build_tables(tb, tid);  // (under the first tile's loads)
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();  // T is complete / the previous tile has been read out of L
 #pragma unroll
@@ -187,14 +219,15 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
 template <int K>
 __device__ __forceinline__ void sweep_tiles(double *__restrict__ L, const double *__restrict__ T, const uint32_t *stw, const double *__restrict__ F,
                                          double *__restrict__ outp, const long Rcells, const int t_begin, const int t_end, const int kout,
-                                         const uint32_t surv, const int tid) {
-    sweep_tiles_impl<K>(L, T, stw, K, 13 - 2 * K, F, outp, Rcells, t_begin, t_end, kout, surv, tid);
+                                         const uint32_t surv, const int tid, const SweepTables &tb) {
+    sweep_tiles_impl<K>(L, T, stw, K, 13 - 2 * K, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
 }
 
 // Any step (digits in any order): the stage records are re-read per tile and stage, all strides are runtime values.
 __device__ __forceinline__ void sweep_tiles_any(double *__restrict__ L, const double *__restrict__ T, const uint32_t *stw, const int k, const int rb,
                                                 const double *__restrict__ F, double *__restrict__ outp, const long Rcells, const int t_begin,
-                                                const int t_end, const int kout, const uint32_t surv, const int tid) {
+                                                const int t_end, const int kout, const uint32_t surv, const int tid, const SweepTables &tb) {
+    sweep_build_tables(tb, tid);
     const int Rt = 1 << rb;
     const int ocells = Rt << (2 * kout);
     const int p_tid = sweep_perm(tid, kout, rb, surv);
@@ -257,34 +290,14 @@ __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_kernel(const LevelArgs A
     const uint32_t *smw = stw + k * kSweepStageWords;       // the small inputs, stage by stage
     const double *__restrict__ F = slot + ((uint64_t)sh_step[kHdrWords] | ((uint64_t)sh_step[kHdrWords + 1] << 32));
     double *__restrict__ outp = slot + ((uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32));
-    // T_j[n + cout * (x + 4 * ctrl)] = product of the CPT slices of stage j
-    for (int t = tid; t < t_total; t += kSweepWG) {
-        int j = 0, rec0 = 0;
-        while (j + 1 < k && t >= (int)((stw[j * kSweepStageWords + 1] & 0xffff) + (stw[j * kSweepStageWords + 1] >> 16))) {
-            rec0 += (int)((stw[j * kSweepStageWords] >> 8) & 15);
-            ++j;
-        }
-        const uint32_t s0 = stw[j * kSweepStageWords], s1 = stw[j * kSweepStageWords + 1];
-        const int cout = (s0 >> 4) & 15, ns = (s0 >> 8) & 15;
-        const int e = t - (int)(s1 & 0xffff);
-        const int n = cout == 4 ? (e & 3) : 0;
-        const int r = cout == 4 ? (e >> 2) : e;
-        const int x = r & 3, c0 = (r >> 2) & 3, c1 = (r >> 4) & 3, c2 = (r >> 6) & 3;
-        double v = 1.0;
-        for (int i = 0; i < ns; ++i) {
-            const uint32_t *rec = smw + (rec0 + i) * kSweepSmallWords;
-            const int off = n * (int)rec[2] + x * (int)rec[3] + c0 * (int)rec[4] + c1 * (int)rec[5] + c2 * (int)rec[6];
-            v *= table_ptr(rec[0], rec[1], A.pool, slot)[off];
-        }
-        T[t] = v;
-    }
+    const SweepTables tb{T, stw, smw, A.pool, slot, k, t_total};
     const int t_begin = (int)((wg - it.b) * it.a);
     const int t_end = min(tiles, t_begin + (int)it.a);
     const bool canon = (sh_step[1] >> 16) & kFlagSweepCanon;
-    if (canon && k == 5) sweep_tiles<5>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid);
-    else if (canon && k == 4) sweep_tiles<4>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid);
-    else if (canon && k == 3) sweep_tiles<3>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid);
-    else sweep_tiles_any(L, T, stw, k, rb, F, outp, Rcells, t_begin, t_end, kout, surv, tid);
+    if (canon && k == 5) sweep_tiles<5>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 4) sweep_tiles<4>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 3) sweep_tiles<3>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else sweep_tiles_any(L, T, stw, k, rb, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
 }
 
 }  // namespace mibn
