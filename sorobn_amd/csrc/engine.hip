@@ -501,8 +501,10 @@ int default_threads() {
     if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) local_world = std::max(1, std::atoi(e));
     double cpus = hw;
     const double quota = cpu_quota();
-    if (quota > 0) cpus = std::min(cpus, 4.0 * quota);  // planning is bursty (~1/3 duty cycle): 4 threads per quota CPU finish a
-                                                        // chunk sooner inside the same CPU-time budget (measured: 64 beat 32 threads at quota 16)
+    if (quota > 0) cpus = std::min(cpus, 2.0 * quota);  // planning is bursty: 2 threads per quota CPU finish a chunk sooner inside the same
+                                                        // CPU-time budget; 4 per CPU (round 1's choice) run into the cgroup's throttling now that
+                                                        // a step is 135 ms instead of 170 (profiles/r02_y_threads.log: 16-32 threads 237-239 k
+                                                        // queries/s, 64 threads 235 k, 128 threads 221 k with 44 thread-seconds throttled)
     return std::max(1, std::min(64, (int)(cpus / local_world)));
 }
 
