@@ -753,13 +753,14 @@ def test_multi_request_schedule_stagger_and_threads_on_the_simulator():
     invariants checked (one item of a request per level, tiles covered exactly once, bytes add up): with the requests in
     phase, with 2 / 3 / 5 staggered groups (option `stagger`) and planned by 1 or 3 workers - always the posteriors of
     the one-request-at-a-time path, bit for bit (same programs, another launch order)."""
-    for R, C, small_cells, tiling in ((6, 6, 1024, (4096, 0)), (6, 6, 20, (64, 2)), (5, 7, 3, (4, 1))):
+    # (the 8x8 grid brings SWEEP items - 4^7 / 4^8-cell tables, 2-8 tiles each - whose workgroups build_schedule sizes per launch)
+    for R, C, small_cells, tiling, n_req in ((6, 6, 1024, (4096, 0), 96), (6, 6, 20, (64, 2), 96), (5, 7, 3, (4, 1), 96), (8, 8, 1024, (512, 0), 40)):
         spec = netspec.grid_spec(R, C, 4, seed=R * 10 + C)
         bn = netspec.build(spec, sorobn_amd.BayesNet)
         f = flatten(bn)
         n = R * C
         sim = simengine.SimEngine(f, small_cells=small_cells, tiling=tiling)
-        q, ev, ec = netspec.c3_requests(n, 4, 96, 3, seed=2)
+        q, ev, ec = netspec.c3_requests(n, 4, n_req, 3, seed=2)
         to_var = np.array([f.id[f"{i:03d}"] for i in range(n)], np.int32)
         Q, E = to_var[q][:, None], to_var[ev]
         one_by_one = sim.query_fixed(Q, E, ec)
