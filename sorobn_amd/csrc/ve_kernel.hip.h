@@ -685,21 +685,28 @@ __device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__re
     const int lrow = lane & 15, lk = lane >> 4;
     const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);
     uint32_t la[4], lb[4];
-    int tb[4];          // T offset of row block rb
-    int oc[4][4];       // output offset of accumulator element v of row block rb (-1: beyond the lane block)
+    const int t_lane = lrow + 16 * lk;  // (the T offset of row block rb is re-read from sh_cell in the loop: four registers fewer)
+    // output offset of accumulator element v of row block rb (-1: beyond the lane block): 16 values per lane, parked in LDS
+    // behind sh_cell (shX has exactly the room) - in registers they pushed the kernel over its budget (an 8-byte spill
+    // reloaded in this loop was the level kernel's only scratch)
+    int *sh_oc = sh_cell + 4 * kWG;  // [16][kWG]
+    int oc_val[4][4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);
         la[rb] = (uint32_t)(sh_cell[c] + lk * axs1);
         lb[rb] = (uint32_t)(sh_cell[kWG + wave * 64 + rs * rb] + (int)d.nB[lrow] + lk * bxs1);
-        tb[rb] = sh_cell[3 * kWG + wave * 64 + rs * rb] + lrow + 16 * lk;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = lk + 4 * v;
             const int oc_cell = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
-            oc[rb][v] = oc_cell < d.lo_cells ? sh_cell[2 * kWG + oc_cell] + (int)d.nout[lrow] : -1;
+            oc_val[rb][v] = oc_cell < d.lo_cells ? sh_cell[2 * kWG + oc_cell] + (int)d.nout[lrow] : -1;
         }
     }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sh_oc[(rb * 4 + v) * kWG + tid] = oc_val[rb][v];  // (a lane reads back only what it wrote: no barrier)
     // An operand whose wave-uniform offset did not change since the previous iteration (the iteration moved along an
     // axis only the other table depends on) stays in registers: these steps multiply two tables over the union of
     // their axes, every element of A feeds all the cells of B that share its batch axes and vice versa.
@@ -728,14 +735,17 @@ __device__ __forceinline__ void outer_mfma_call(const uint32_t *sw, double *__re
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const int tb = has_t ? sh_cell[3 * kWG + wave * 64 + rs * rb] + t_lane : 0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const double bo = has_t ? braw[rb][ks] * shT[ht + tb[rb] + 64 * ks] : braw[rb][ks];
+                const double bo = has_t ? braw[rb][ks] * shT[ht + tb + 64 * ks] : braw[rb][ks];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][ks], bo, acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (oc[rb][v] >= 0) outp[ho + oc[rb][v]] = acc[v];
+            for (int v = 0; v < 4; ++v) {
+                const int o = sh_oc[(rb * 4 + v) * kWG + tid];
+                if (o >= 0) outp[ho + o] = acc[v];
+            }
         }
     }
 }
@@ -884,9 +894,17 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
     __shared__ double sh_red[kWG / 64];
     const int tid = threadIdx.x;
     const uint32_t wg = blockIdx.x + A.wg_base;
-    const Item it = A.items[A.wg_item[wg]];
-    double *slot = A.arena + A.arena_off[it.req];
-    const uint32_t *p = A.prog + A.prog_off[it.req] + it.rel_off;
+    // (everything about the work item is wave-uniform: kept in scalar registers explicitly - as lane values the arena and
+    //  program pointers were spilled around the switch over the step forms)
+    const uint32_t item_idx = (uint32_t)uni((int)A.wg_item[wg]);
+    Item it;
+    it.req = (uint32_t)uni((int)A.items[item_idx].req);
+    it.rel_off = (uint32_t)uni((int)A.items[item_idx].rel_off);
+    it.a = (uint32_t)uni((int)A.items[item_idx].a);
+    it.b = (uint32_t)uni((int)A.items[item_idx].b);
+    const uint64_t ao = A.arena_off[it.req], po = A.prog_off[it.req];
+    double *slot = A.arena + (((uint64_t)(uint32_t)uni((int)(ao >> 32)) << 32) | (uint32_t)uni((int)(ao & 0xffffffffu)));
+    const uint32_t *p = A.prog + (((uint64_t)(uint32_t)uni((int)(po >> 32)) << 32) | (uint32_t)uni((int)(po & 0xffffffffu))) + it.rel_off;
     if (it.a & kItemSegment) {
         // SEGMENT: small GENERIC steps of one request, back to back
         const int n_steps = (int)(it.a & ~kItemSegment);
