@@ -296,7 +296,7 @@ def test_wide_grids_every_request_vs_oracle(amd, shape):
 
 def test_schedule_and_effort_options_do_not_change_answers(amd):
     """`stagger` (groups of requests whose levels are staggered inside a chunk: the same programs in another launch
-    order) must reproduce the posteriors bit for bit; `minfill_above` (the knob the adaptive planning effort turns:
+    order) and the other schedule options must reproduce the posteriors bit for bit; `minfill_above` (the knob the adaptive planning effort turns:
     which requests get the min-fill order search) changes elimination orders, i.e. rounding only."""
     spec = netspec.grid_spec(10, 10, 4, seed=0)
     bn = netspec.build(spec, amd.BayesNet)
@@ -309,6 +309,20 @@ def test_schedule_and_effort_options_do_not_change_answers(amd):
         be.engine.set_option("stagger", g)
         assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base), g
     be.engine.set_option("stagger", 1)
+    # round 2: the sweep kernel on its own stream, other workgroup sizes of its launches, the chunking of a call - the same
+    # programs in another schedule: bit for bit
+    for name, value, back in (("streams", 2, 1), ("sweep_iters", 4, 8), ("sweep_iters", 2, 8), ("sweep_adapt", 0, 4096),
+                              ("first_chunk", 0, 1), ("first_chunk", 2, 1), ("chunk_sets", 3, 2), ("chunk", 4096, 16384)):
+        be.engine.set_option(name, value)
+        assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base), (name, value)
+        be.engine.set_option(name, back)
+    # other elimination orders: rounding only
+    for name, value, back in (("order_weights", 0, 1), ("builtin_sweeps", 1, 0)):
+        be.engine.set_option(name, value)
+        other = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+        assert float(np.max(np.abs(other - base))) <= 1e-12, name
+        be.engine.set_option(name, back)
+    assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base)
     be.engine.set_option("minfill_above", 1e18)  # sweeps only
     sweeps = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
     assert be.engine.stats()["alg_bytes"] > 1.1 * base_bytes
