@@ -819,6 +819,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     // an earlier asynchronous call still keeps the GPU busy; 0: never)
     bool gpu_busy = false;
     for (auto &st : h->set) gpu_busy = gpu_busy || (st.busy && st.ev_used && hipEventQuery(st.ev[st.ev_used - 1]) == hipErrorNotReady);
+    (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error: do not leave it for the check after the launches)
     const bool short_first = h->first_chunk == 2 || (h->first_chunk == 1 && !gpu_busy);
     for (int64_t b0 = 0, b1 = 0; b0 < B; b0 = b1, ++n_chunks) {
         b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk && short_first ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
