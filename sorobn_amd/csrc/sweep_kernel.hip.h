@@ -143,7 +143,8 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
         }
     }
     const int ocells = Rt << (2 * kout);
-    const int p_tid = sweep_perm(tid, kout, rb, surv);
+    const int p_tid2 = sweep_perm(2 * tid, kout, rb, surv);
+    const int st0 = kout > 0 ? 1 << (rb + 2 * (int)(surv & 15)) : 1;  // LDS stride between output cells c and c + 1 (c even)
     // the tile's loads: pair c2 = i * 512 + tid -> cells (2 c2, 2 c2 + 1) of L = R cells (2 rp, 2 rp + 1) of combination xc
     const int rp = tid & ((Rt >> 1) - 1);
     const long g_tid = (long)(tid >> (rb - 1)) * Rcells + 2 * rp;
@@ -204,13 +205,18 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
                 v[2 * i + 1] = q.y;
             }
         }
+        // the tile's output block, two cells (16 bytes) per lane and trip: cells c and c + 1 differ in the first surviving
+        // digit (or, without one, in r)
         double *__restrict__ ot = outp + (long)tile * ocells;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c0 = i * kSweepWG;  // (uniform)
+        for (int i = 0; i < 8; ++i) {
+            const int c0 = i * 2 * kSweepWG;  // (uniform)
             if (c0 < ocells) {
-                const int c = c0 + tid;
-                if (c < ocells) ot[c] = L[sweep_perm(c0, kout, rb, surv) + p_tid];
+                const int c = c0 + 2 * tid;
+                if (c < ocells) {
+                    const int a = sweep_perm(c0, kout, rb, surv) + p_tid2;
+                    *reinterpret_cast<double2 *>(ot + c) = make_double2(L[a], L[a + st0]);
+                }
             }
         }
     }
