@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void order_kernel(const OrderArgs A) {
 // then idles 5-12 ms (the "[mibn gap]" lines of option trace); a third set (option chunk_sets=3) closes those gaps but
 // proved erratic end to end (planning wall time doubles, runs between 155 k and 204 k queries/s against a steady
 // 194-204 k with two: profiles/r02_q_chunk_sets.log), so it stays an experiment.
-constexpr int kChunkSets = 3;
+constexpr int kChunkSets = 4;
 
 struct mibn_ctx {
     Network net;
@@ -77,8 +77,11 @@ struct mibn_ctx {
     hipStream_t stream = nullptr;       // kernels, gibbs, result download
     hipStream_t copy_stream = nullptr;  // program / schedule uploads: overlap the previous chunk's kernels
     double *d_pool = nullptr;
-    double *d_arena = nullptr;  // private arenas of the requests of the wave in flight
-    size_t arena_bytes = 0;
+    // Lanes: consecutive chunks of a call alternate between two streams with an arena each and run CONCURRENTLY - requests are
+    // independent, and the launch boundaries of one chunk's levels (the only synchronisation of the level-synchronous schedule)
+    // then overlap with the other chunk's launches instead of leaving the tail of every launch to half-empty CUs.
+    double *d_arena[2] = {nullptr, nullptr};  // private arenas of the requests of the wave in flight, per lane
+    size_t arena_bytes[2] = {0, 0};
     double *d_results[2] = {nullptr, nullptr};  // dense posteriors of the call in flight (two calls may overlap)
     size_t results_cap[2] = {0, 0};             // doubles
     struct Pending {                            // an asynchronous call whose results have not been collected yet
@@ -152,7 +155,7 @@ struct mibn_ctx {
     double search_ms = 0;            // host wall time spent waiting for the device search (last call)
     hipEvent_t gap_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // trace: ends of the last waves (GPU idle time between waves)
     uint64_t n_waves = 0;
-    int n_sets = 2;           // chunk sets in use (option "chunk_sets": 2 or 3)
+    int n_sets = 2;           // chunk sets in use (option "chunk_sets": 2..4; two per lane: one on the GPU, one being planned)
     int set_cursor = 0;    // the chunk set the next chunk plans into: alternates across calls, so that a call of one chunk
                            // plans into the idle set while the previous call's kernels still run from the other one
     uint64_t call_id = 0;  // kernel time retired later is booked to the call that launched it
@@ -178,9 +181,14 @@ struct mibn_ctx {
     mibn_kernel_stat kstats[kNumKernels + 2];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel
     mibn_kernel_stat ktotal[kNumKernels + 2];
     // options
-    double arena_gb = 96.0;
-    hipStream_t stream2 = nullptr;  // the sweep kernel's stream (n_streams = 2: the two kernels of a level overlap)
-    int n_streams = 1;  // 2: the sweep kernel of a level on a stream of its own, overlapping the level kernel (+3 % on C3; per-kernel times then include the contention)
+    double arena_gb = 180.0;  // scratch budget of all lanes together (of the 288 GB)
+    hipStream_t stream2 = nullptr;  // lane 1 (lane 0 = stream)
+    hipEvent_t epoch = nullptr;     // reference of the busy-time bookkeeping (re-recorded when the GPU is idle)
+    hipEvent_t lane_ev = nullptr, zero_ev = nullptr;  // end of lane 1's work of a call / results buffer zeroed
+    double busy_until = 0;          // ms since epoch up to which GPU time has been booked as kernel_ms
+    int n_streams = 1;  // lanes.  1 (default): every chunk on the main stream, one after the other.  2: consecutive chunks run concurrently
+                        // (+3 % with 8 192-request chunks, profiles/r02_y_lanes*.log; the per-launch event times then include the other lane's
+                        // contention and stop being a roofline measurement, which is why it is not the default)
     int first_chunk = 1;  // short first chunk of a call: 0 never, 1 when the GPU is idle, 2 always
     int threads = 0;
     int trace = 0;        // debug: one stderr line per launch
@@ -286,7 +294,12 @@ void mibn_destroy(mibn_t *h) {
         if (h->stream) (void)hipStreamSynchronize(h->stream);
         (void)mibn_comm_destroy(h);
         (void)hipFree(h->d_pool);
-        (void)hipFree(h->d_arena);
+        if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+        (void)hipFree(h->d_arena[0]);
+        (void)hipFree(h->d_arena[1]);
+        if (h->epoch) (void)hipEventDestroy(h->epoch);
+        if (h->lane_ev) (void)hipEventDestroy(h->lane_ev);
+        if (h->zero_ev) (void)hipEventDestroy(h->zero_ev);
         (void)hipFree(h->d_tiny_meta);
         (void)hipFree(h->d_tiny_req);
         (void)hipFree(h->d_tiny_bad);
@@ -348,7 +361,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "fuse") h->net.fuse = value != 0;
     else if (n == "plan_cache") h->net.plan_cache = value != 0;  // plan templates for repeated request shapes
     else if (n == "chain") h->net.chain = value != 0;  // CHAIN form: three variables per pass
-    else if (n == "streams") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_streams = value >= 2 ? 2 : 1; }  // 1 (default): the sweep kernel on the main stream, after the level kernel; 2: on its own stream, overlapping it
+    else if (n == "streams") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_streams = value >= 2 ? 2 : 1; h->n_sets = 2 * h->n_streams; h->set_cursor = 0; }  // lanes: 2 (default) = consecutive chunks run concurrently on two streams; 1 = one after the other
     else if (n == "first_chunk") h->first_chunk = std::max(0, std::min(2, (int)value));
     else if (n == "builtin_sweeps") {  // two depth-first topological orders as candidate elimination orders (rebuilds the hint lists)
         h->net.builtin_sweeps = value != 0;
@@ -527,10 +540,16 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));
         const bool mine = t.call == h->call_id;  // (launches of an earlier asynchronous call only count in the totals)
         if (t.kid < 0) {
-            // GPU wall time of a wave, first launch to last (the level kernel and the sweep kernel of a level overlap on two
-            // streams: the sum of the launches' own durations below exceeds it)
-            if (mine) h->stats.kernel_ms += ms;
-            h->total.kernel_ms += ms;
+            // GPU time of a wave, first launch to last.  With two lanes the waves of consecutive chunks overlap: what is
+            // booked as kernel_ms is the time the GPU was busy (the union of the intervals, kept as a high-water mark
+            // since the epoch event; sets retire in launch order)
+            float t0 = 0, t1 = 0;
+            HIP_TRY(h, hipEventElapsedTime(&t0, h->epoch, st.ev[t.e0]));
+            HIP_TRY(h, hipEventElapsedTime(&t1, h->epoch, st.ev[t.e1]));
+            const double add = std::max(0.0, (double)t1 - std::max((double)t0, h->busy_until));
+            h->busy_until = std::max(h->busy_until, (double)t1);
+            if (mine) h->stats.kernel_ms += add;
+            h->total.kernel_ms += add;
             continue;
         }
         if (mine) h->stats.n_launches += 1;
@@ -554,6 +573,20 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     st.timed.clear();
     st.ev_used = 0;
     st.busy = false;
+    return MIBN_OK;
+}
+
+// every set, oldest launches first (set_cursor points at the set that is re-used next = the oldest): the busy-time
+// bookkeeping of retire() wants the waves in launch order
+int retire_all(mibn_ctx *h) {
+    for (int i = 0; i < h->n_sets; ++i) {
+        int rc = retire(h, h->set[(h->set_cursor + i) % h->n_sets]);
+        if (rc) return rc;
+    }
+    for (auto &st : h->set) {  // (sets beyond n_sets: idle unless the option has just changed)
+        int rc = retire(h, st);
+        if (rc) return rc;
+    }
     return MIBN_OK;
 }
 
@@ -807,10 +840,27 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     const size_t res_cells = (size_t)(out_off[B] - out_off[0]);
     if ((rc = ensure(h, h->d_results[slot], h->results_cap[slot], res_cells))) return rc;
     double *const d_results = h->d_results[slot];
+    const int n_lanes = h->n_streams > 1 ? 2 : 1;
+    {
+        bool idle = true;
+        for (auto &st : h->set) idle = idle && !st.busy;
+        if (!h->epoch) { HIP_TRY(h, hipEventCreate(&h->epoch)); idle = true; }
+        if (idle) {  // (times since the epoch stay small: float milliseconds)
+            HIP_TRY(h, hipEventRecord(h->epoch, h->stream));
+            h->busy_until = 0;
+        }
+    }
     HIP_TRY(h, hipMemsetAsync(d_results, 0, res_cells * 8, h->stream));
+    if (n_lanes > 1) {  // lane 1 starts this call's work after the results buffer is zeroed
+        if (!h->zero_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->zero_ev, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->zero_ev, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->zero_ev, 0));
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
-    const int64_t budget_cells = (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes)) / 8.0);
+    const int64_t budget_cells =
+        (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes[0] + h->arena_bytes[1])) / 8.0) / n_lanes;
+    bool lane1_used = false;
     int64_t n_chunks = 0;
     const bool search_on = h->gpu_search && h->order_net_ok;
     int64_t search_b0 = -1;
@@ -825,6 +875,9 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk && short_first ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
         const int64_t n = b1 - b0;
         mibn_ctx::Set &st = h->set[h->set_cursor];
+        const int lane = n_lanes > 1 ? (h->set_cursor & 1) : 0;  // consecutive chunks alternate between the lanes
+        hipStream_t S = lane ? h->stream2 : h->stream;
+        lane1_used = lane1_used || lane == 1;
         h->set_cursor = (h->set_cursor + 1) % h->n_sets;
         if ((rc = retire(h, st))) return rc;  // its buffers are about to be rewritten
         double t0 = now_ms();
@@ -850,7 +903,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         BatchPlan &ck = st.plan;
         plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck,
                    (flags & MIBN_Q_NOPRUNE) != 0, orders, order_len);
-        if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); return MIBN_E_LIMIT; }
+        if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->stream2); return MIBN_E_LIMIT; }
         for (auto &b : st.bufs)
             if (b.cap && !b.data) { h->err = "pinned host allocation failed"; return MIBN_E_HIP; }
         h->stats.plan_ms += now_ms() - t0;
@@ -881,17 +934,17 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             build_schedule(h->net, ck, st.bufs, r0, r1, sc);
             h->stats.plan_ms += now_ms() - t0;
             const size_t need_bytes = (size_t)std::max<int64_t>(16, sc.arena_cells) * sizeof(double);
-            if (need_bytes > h->arena_bytes) {
+            if (need_bytes > h->arena_bytes[lane]) {
                 // grow with headroom (chunks differ by ~10 %): re-allocating tens of GB costs hundreds of ms
-                HIP_TRY(h, hipStreamSynchronize(h->stream));  // earlier launches still use the old arena
-                if (h->d_arena) { HIP_TRY(h, hipFree(h->d_arena)); h->d_arena = nullptr; h->arena_bytes = 0; }
+                HIP_TRY(h, hipStreamSynchronize(S));  // earlier launches of the lane still use the old arena
+                if (h->d_arena[lane]) { HIP_TRY(h, hipFree(h->d_arena[lane])); h->d_arena[lane] = nullptr; h->arena_bytes[lane] = 0; }
                 const size_t want = std::max(need_bytes, std::min((size_t)((double)budget_cells * 8.0), need_bytes + need_bytes / 3));
-                HIP_TRY(h, hipMalloc(&h->d_arena, want));
-                h->arena_bytes = want;
+                HIP_TRY(h, hipMalloc(&h->d_arena[lane], want));
+                h->arena_bytes[lane] = want;
             }
             // items / arena offsets of this wave live until the wave's launches have run: one wave per set at a
             // time unless the chunk had to be split (then wait for the previous wave first)
-            if (r0 > 0) { HIP_TRY(h, hipStreamSynchronize(h->stream)); HIP_TRY(h, hipStreamSynchronize(h->copy_stream)); }
+            if (r0 > 0) { HIP_TRY(h, hipStreamSynchronize(S)); HIP_TRY(h, hipStreamSynchronize(h->copy_stream)); }
             if ((rc = ensure(h, st.d_items, st.items_cap, sc.items.size()))) return rc;
             if ((rc = ensure(h, st.d_wg_item, st.wg_item_cap, sc.wg_item.size()))) return rc;
             t0 = now_ms();
@@ -900,27 +953,21 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             if ((rc = upload(h, st.stage[3], st.d_wg_item, sc.wg_item.data(), sc.wg_item.size() * sizeof(uint32_t)))) return rc;
             if (!st.uploaded) HIP_TRY(h, hipEventCreateWithFlags(&st.uploaded, hipEventDisableTiming));
             HIP_TRY(h, hipEventRecord(st.uploaded, h->copy_stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->stream, st.uploaded, 0));  // the kernels of this wave wait for its uploads only
+            HIP_TRY(h, hipStreamWaitEvent(S, st.uploaded, 0));  // the kernels of this wave wait for its uploads only
             h->stats.h2d_ms += now_ms() - t0;
             LevelArgs A;
             A.prog = st.d_prog;
             A.prog_off = st.d_prog_off + r0;
             A.arena_off = st.d_arena_off;
             A.pool = h->d_pool;
-            A.arena = h->d_arena;
+            A.arena = h->d_arena[lane];
             A.results = d_results + (out_off[b0] - out_off[0]);
             double n_wg = 0;
             if (h->trace) st.gap_from = h->n_waves ? (int)((h->n_waves - 1) & 3) : -1;
-            // Two streams: the level kernel on the main stream, the sweep kernel on a second one.  The kernels of level L wait
-            // for the kernels of both streams below L (the end event of a stream's latest launch below L), not for each other:
-            // the two kernels of a level overlap and fill each other's tails.  Every launch is bracketed by its own pair of
-            // events; the wave as a whole by the first and the last event on the main stream (kernel_ms).
-            const bool two = h->n_streams > 1 && h->stream2;
-            constexpr size_t kNone = ~size_t(0);
-            size_t e_first = 0, lastA = kNone, lastB = kNone, prevA = kNone, prevB = kNone, waitedA = kNone, waitedB = kNone;
-            int cur_level = -1;
-            if ((rc = next_event(h, st, e_first))) return rc;
-            if (two) HIP_TRY(h, hipStreamWaitEvent(h->stream2, st.ev[e_first], 0));  // after this wave's uploads and the previous wave
+            // Every launch is bracketed by its own pair of events on the lane's stream; the wave as a whole by the first and
+            // the last one (retire() books the GPU's busy time from them).
+            size_t e_first = 0;
+            if ((rc = next_event(h, st, e_first, S))) return rc;
             A.items = st.d_items;
             for (size_t li = 0; li < sc.launches.size();) {
                 // one launch of the level kernel per level (all its classes of work together) unless split_kinds, and one
@@ -935,13 +982,6 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                         grid += sc.launches[lj].grid;
                     }
                 const Launch &L = sc.launches[li];
-                if (L.level != cur_level) { cur_level = L.level; prevA = lastA; prevB = lastB; }
-                const bool onB = sweep && two;
-                hipStream_t S = onB ? h->stream2 : h->stream;
-                if (two) {
-                    size_t &need = onB ? prevA : prevB, &waited = onB ? waitedB : waitedA;
-                    if (need != kNone && need != waited) { HIP_TRY(h, hipStreamWaitEvent(S, st.ev[need], 0)); waited = need; }
-                }
                 A.wg_item = st.d_wg_item + L.wg_level;
                 A.wg_base = (uint32_t)(L.wg_first - L.wg_level);
                 size_t e0 = 0, e1 = 0;
@@ -949,22 +989,20 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
                 else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, S, A);
                 if ((rc = next_event(h, st, e1, S))) return rc;
-                (onB ? lastB : lastA) = e1;
                 st.timed.push_back({sweep ? kKidSweep : (h->split_kinds ? L.kid : kNumKernels), e0, e1, bytes, (double)grid, h->call_id});
                 n_wg += (double)grid;
                 li = lj;
             }
-            if (two && lastB != kNone) HIP_TRY(h, hipStreamWaitEvent(h->stream, st.ev[lastB], 0));  // the main stream ends the wave
             {
                 size_t e_last = 0;
-                if ((rc = next_event(h, st, e_last))) return rc;
+                if ((rc = next_event(h, st, e_last, S))) return rc;
                 st.timed.push_back({-1, e_first, e_last, 0.0, 0.0, h->call_id});
             }
             HIP_TRY(h, hipGetLastError());
             if (h->trace) {
                 hipEvent_t &ge = h->gap_ev[h->n_waves & 3];
                 if (!ge) HIP_TRY(h, hipEventCreate(&ge));
-                HIP_TRY(h, hipEventRecord(ge, h->stream));
+                HIP_TRY(h, hipEventRecord(ge, S));
             }
             ++h->n_waves;
             st.busy = true;
@@ -989,6 +1027,11 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         h->total.arena_bytes = std::max(h->total.arena_bytes, h->stats.arena_bytes);
         h->total.max_step_cells = std::max(h->total.max_step_cells, h->stats.max_step_cells);
     };
+    if (lane1_used) {  // the download (main stream) follows the kernels of both lanes
+        if (!h->lane_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->lane_ev, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->lane_ev, h->stream2));
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->lane_ev, 0));
+    }
     if (ticket) {
         mibn_ctx::Pending &pd = h->pend[slot];
         mibn_ctx::Staging &sg = h->res_stage[slot];
@@ -1009,8 +1052,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         fold();
         return MIBN_OK;
     }
-    for (auto &st : h->set)
-        if ((rc = retire(h, st))) return rc;
+    if ((rc = retire_all(h))) return rc;
     double t0 = now_ms();
     HIP_TRY(h, hipMemcpyAsync(out + out_off[0], d_results, res_cells * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1061,10 +1103,7 @@ extern "C" int mibn_drain(mibn_t *h) {
     if (!h) return MIBN_E_ARG;
     if (h->planner_only) return MIBN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    int rc;
-    for (auto &st : h->set)
-        if ((rc = retire(h, st))) return rc;
-    return MIBN_OK;
+    return retire_all(h);
 }
 
 extern "C" int mibn_total_stats(const mibn_t *h, mibn_stats *out) {
