@@ -111,6 +111,32 @@ def grid_spec(R, C, K, seed=0, name=None):
             "nodes": order, "edges": edges, "cpts": cpts}
 
 
+def mixed_grid_spec(R, C, cards, seed):
+    """Grid like netspec.grid_spec with a cardinality per COLUMN (cards[c])."""
+    import graphlib
+    nm = lambda r, c: f"{r * C + c:03d}"
+    parents, edges, card_of = {}, [], {}
+    for r in range(R):
+        for c in range(C):
+            ps = ([nm(r - 1, c)] if r else []) + ([nm(r, c - 1)] if c else [])
+            parents[nm(r, c)] = sorted(ps)
+            card_of[nm(r, c)] = cards[c]
+            edges += [[p, nm(r, c)] for p in sorted(ps)]
+    ts = graphlib.TopologicalSorter()
+    for n in sorted(parents):
+        ts.add(n, *parents[n])
+    order = list(ts.static_order())
+    rng = np.random.default_rng(seed)
+    cpts = {}
+    for node in order:
+        cols = [*parents[node], node]
+        doms = [range(card_of[n]) for n in cols]
+        n_cfg = int(np.prod([card_of[n] for n in parents[node]])) if parents[node] else 1
+        p = rng.dirichlet(np.ones(card_of[node]), size=n_cfg).reshape(-1)
+        cpts[node] = {"names": cols, "rows": [list(cfg) + [float(v)] for cfg, v in zip(itertools.product(*doms), p)]}
+    return {"name": f"mixed{R}x{C}s{seed}", "hashed_names": True, "nodes": order, "edges": edges, "cpts": cpts}
+
+
 def random_dag_spec(seed, n_nodes=None, max_parents=3, cards=(2, 3, 4, 5), p_zero=0.08,
                     p_missing=0.05, labels="int"):
     """Random DAG with mixed cardinalities, Dirichlet CPTs, some exact zeros and missing rows."""

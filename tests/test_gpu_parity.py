@@ -215,6 +215,40 @@ def test_c3_sweep_form_vs_chain_form(amd):
     be.engine.set_option("big_iters", 4096)
 
 
+def test_sweep_form_with_other_cardinalities_around_it_gpu(amd):
+    """GPU twin of tests/test_host_logic.py::test_sweep_form_with_other_cardinalities_around_it: an 8 x 9 grid whose outer
+    columns have 3, 2 and 5 states (the tiles of a SWEEP step then run along axes of other cardinalities) against the C
+    oracle and against the CHAIN / pair programs."""
+    from oracle.oracle import OracleNet
+    R, C = 8, 9
+    spec = netspec.mixed_grid_spec(R, C, [3, 4, 4, 4, 4, 4, 4, 2, 5], seed=5)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    n = R * C
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(n)], np.int32)
+    on = OracleNet(spec)
+    oid = np.array([on.id[f"{i:03d}"] for i in range(n)], np.int32)
+    rng = np.random.default_rng(3)
+    be.engine.set_option("big_iters", 512)
+    B = 48
+    qv = rng.integers(n - 2 * C, n, B).astype(np.int32)
+    evs = np.stack([rng.choice([v for v in range(n) if v != q], 3, replace=False) for q in qv]).astype(np.int32)
+    codes = np.array([[int(rng.integers(0, be.flat.card[to_var[e]])) for e in row] for row in evs], np.int32)
+    cells = be.flat.card[to_var[qv]].astype(np.int64)
+    q_off = np.arange(B + 1, dtype=np.int64)
+    e_off = np.arange(B + 1, dtype=np.int64) * 3
+    out_off = np.concatenate([[0], np.cumsum(cells)]).astype(np.int64)
+    got, _ = be.engine.query_batch(q_off, to_var[qv], e_off, to_var[evs].reshape(-1), codes.reshape(-1), out_off)
+    names = {k["name"] for k in be.engine.kernel_stats()}
+    assert "ve_sweep_kernel" in names, names
+    be.engine.set_option("sweep", 0)
+    ref, _ = be.engine.query_batch(q_off, to_var[qv], e_off, to_var[evs].reshape(-1), codes.reshape(-1), out_off)
+    assert float(np.max(np.abs(got - ref))) <= 1e-13
+    for i in range(0, B, 4):
+        oc, ov = on.query_codes([int(oid[qv[i]])], oid[evs[i]].tolist(), codes[i].tolist())
+        assert float(np.max(np.abs(got[out_off[i]:out_off[i + 1]][oc[:, 0]] - ov))) <= gu.TOL
+
+
 def test_c3_bayes_rule_and_marginalisation_at_full_size(amd):
     """Size-independent properties on the BASELINE C3 stream, whole-grid requests included (no CPU oracle finishes
     those): (i) P(q | e1..e4) equals the slice e4 = v of the two-variable posterior P(q, e4 | e1..e3), renormalised

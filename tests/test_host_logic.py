@@ -773,3 +773,35 @@ def test_multi_request_schedule_stagger_and_threads_on_the_simulator():
     ec2[5, 0] = 7
     got = sim.batch(Q, E, ec2, stagger=2, threads=2)
     assert not got[5].any() and np.array_equal(np.delete(got, 5, 0), np.delete(one_by_one, 5, 0))
+
+
+def test_sweep_form_with_other_cardinalities_around_it():
+    """SWEEP steps need four-state eliminated / new / ctrl variables; the other axes of the table may have any cardinality
+    (the tile takes `Rt` consecutive cells of them, ctrl values on them need a power-of-two stride).  An 8 x 9 grid whose
+    outer columns have 3, 2 and 5 states: sweeps do form, and the programs - simulated the way the kernel runs them -
+    agree with the CHAIN / pair programs and with the C oracle."""
+    from oracle.oracle import OracleNet
+    R, C = 8, 9
+    spec = netspec.mixed_grid_spec(R, C, [3, 4, 4, 4, 4, 4, 4, 2, 5], seed=5)
+    bn = netspec.build(spec, sorobn_amd.BayesNet)
+    f = flatten(bn)
+    n = R * C
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(n)], np.int32)
+    rng = np.random.default_rng(3)
+    on = OracleNet(spec)
+    oid = np.array([on.id[f"{i:03d}"] for i in range(n)], np.int32)
+    with_sweep, plain = simengine.SimEngine(f, tiling=(512, 0)), simengine.SimEngine(f, tiling=(512, 0))
+    plain.set_option("sweep", 0)
+    n_sweeps = 0
+    for _ in range(16):
+        qv = int(rng.integers(n - 2 * C, n))  # (a query in the last two rows: the whole grid is relevant, long sweeps)
+        evs = rng.choice([v for v in range(n) if v != qv], 3, replace=False)
+        codes = np.array([int(rng.integers(0, f.card[to_var[e]])) for e in evs], np.int32)
+        a = with_sweep._one([to_var[qv]], to_var[evs], codes)
+        bytes_sweep = with_sweep.last_stats[0]
+        b = plain._one([to_var[qv]], to_var[evs], codes)
+        n_sweeps += bytes_sweep < 0.97 * plain.last_stats[0]  # (a multi-variable pass replaced CHAIN / pair steps)
+        assert float(np.max(np.abs(a - b))) <= 1e-14
+        oc, ov = on.query_codes([int(oid[qv])], oid[evs].tolist(), codes.tolist())
+        assert float(np.max(np.abs(a[oc[:, 0]] - ov))) <= gu.TOL
+    assert n_sweeps >= 3, n_sweeps
