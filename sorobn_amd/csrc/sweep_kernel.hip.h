@@ -118,24 +118,9 @@ __device__ __forceinline__ void sweep_stage_lane(const uint32_t s0, const uint32
         }
 }
 
-// A canonical five-variable step whose first stage can run on the registers the tile arrives in and whose last stage can run
-// on the way out (sweep_tiles_impl): both create a variable, the first reads no ctrl value from bit 0 of r, the ctrl values the
-// last one reads from r are uniform over a tile.
-__device__ __forceinline__ bool sweep_fusable(const uint32_t *stw, const int rb) {
-    const uint32_t a0 = (uint32_t)uni((int)stw[0]), a4 = (uint32_t)uni((int)stw[4 * kSweepStageWords]);
-    bool ok = ((a0 >> 4) & 15) == 4 && ((a4 >> 4) & 15) == 4;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int s0 = (int)((uint32_t)uni((int)stw[2 + c]) & 0xff), s4 = (int)((uint32_t)uni((int)stw[4 * kSweepStageWords + 2 + c]) & 0xff);
-        if (c < (int)((a0 >> 12) & 15) && s0 == 8) ok = false;
-        if (c < (int)((a4 >> 12) & 15) && s4 >= 8 && s4 - 8 < rb) ok = false;
-    }
-    return ok;
-}
-
 // The tiles [t_begin, t_end) of one work item.  K > 0: canonical step of K variables (stage j contracts digit K - 1 - j, the
 // loop digit follows sweep_loop_digit): all LDS strides are immediates and the stages are unrolled.
-template <int K, bool FUSE>
+template <int K>
 __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const double *__restrict__ T, const uint32_t *stw, const int k_rt,
                                                  const int rb_rt, const double *__restrict__ F, double *__restrict__ outp,
                                                  const long Rcells, const int t_begin, const int t_end, const int kout,
@@ -158,35 +143,6 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
         }
     }
     const int ocells = Rt << (2 * kout);
-    // Five-variable passes: the first stage runs on the registers the tile arrives in (a lane's eight 16-byte loads hold the
-    // four values of four fibers along the slowest digit) and the last one on the way out (a lane reads a fiber along digit 0,
-    // whose four results are 32 contiguous bytes of the output): two LDS round trips and two barriers fewer per tile.
-    // fuse_first: stage 0 creates a variable and reads no ctrl value from bit 0 of r; fuse_last: the last stage creates a
-    // variable and its ctrl values from r are uniform over the tile.
-    constexpr bool fuse_first = FUSE, fuse_last = FUSE;  // (sweep_fusable: checked by the caller)
-    int ff_toff[2] = {0, 0}, fl_base = 0, fl_toff = 0;
-    if constexpr (K == 5 && FUSE) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {  // T offset of stage 0 for the lane's fibers with xc bit 7 = hh (ctrl values on digits 0..3)
-            const int xc = hh * 128 + (tid >> 2);
-            ff_toff[hh] = (int)(sw1[0] & 0xffff);
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (c < (int)((sw0[0] >> 12) & 15)) {
-                    const int src = swc[0][c] & 0xff, ts = (int)(swc[0][c] >> 8);
-                    if (src < 8) ff_toff[hh] += ((xc >> (2 * src)) & 3) * ts;
-                }
-        }
-        // the lane's output fibers g = i * 512 + tid (cells 4 g .. 4 g + 3): LDS index of cell 4 tid, T offset from its digits
-        fl_base = sweep_perm(4 * tid, kout, rb, surv);
-        fl_toff = (int)(sw1[K - 1] & 0xffff);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            if (c < (int)((sw0[K - 1] >> 12) & 15)) {
-                const int src = swc[K - 1][c] & 0xff, ts = (int)(swc[K - 1][c] >> 8);
-                if (src < 8) fl_toff += ((fl_base >> (rb + 2 * src)) & 3) * ts;
-            }
-    }
     const int p_tid2 = sweep_perm(2 * tid, kout, rb, surv);
     const int st0 = kout > 0 ? 1 << (rb + 2 * (int)(surv & 15)) : 1;  // LDS stride between output cells c and c + 1 (c even)
     // the tile's loads: pair c2 = i * 512 + tid -> cells (2 c2, 2 c2 + 1) of L = R cells (2 rp, 2 rp + 1) of combination xc
@@ -206,40 +162,12 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
     sweep_build_tables(tb, tid);  // (under the first tile's loads)
     for (int tile = t_begin; tile < t_end; ++tile) {
         __syncthreads();  // T is complete / the previous tile has been read out of L
-        if (K == 5 && fuse_first) {
-            // v[2 (2 x + hh) + rr] = F[x4 = x, xc bit 7 = hh, r = 2 rp + rr]: stage 0 along x4, results to the cells the values would go
-            const int rg0 = tile * Rt + 2 * (tid & 3);
-            int radd = 0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (c < (int)((sw0[0] >> 12) & 15) && (swc[0][c] & 0xff) >= 8) radd += ((rg0 >> ((swc[0][c] & 0xff) - 8)) & 3) * (int)(swc[0][c] >> 8);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const double *__restrict__ Tp = T + (ff_toff[hh] + radd);
-                double t[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) t[q] = Tp[q];
-                double o[4][2];
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        double acc = v[2 * hh + rr] * t[n];
-#pragma unroll
-                        for (int x = 1; x < 4; ++x) acc += v[2 * (2 * x + hh) + rr] * t[n + 4 * x];
-                        o[n][rr] = acc;
-                    }
-#pragma unroll
-                for (int n = 0; n < 4; ++n) *reinterpret_cast<double2 *>(L + 2 * ((2 * n + hh) * kSweepWG + tid)) = make_double2(o[n][0], o[n][1]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<double2 *>(L + 2 * (i * kSweepWG + tid)) = make_double2(v[2 * i], v[2 * i + 1]);
-        }
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<double2 *>(L + 2 * (i * kSweepWG + tid)) = make_double2(v[2 * i], v[2 * i + 1]);
         __syncthreads();
         const int rg = tile * Rt + (tid & (Rt - 1));  // this lane's R cell in every stage (the lowest lane bits are r)
 #define MIBN_SWEEP_STAGE(J)                                                                                                   \
-        if (J < KS && J < k && !(K == 5 && J == 0 && fuse_first) && !(K == 5 && J == K - 1 && fuse_last)) {                   \
+        if (J < KS && J < k) {                                                                                                \
             constexpr int JJ = J < KS ? J : 0;                                                                                \
             const uint32_t s0 = sw0[JJ];                                                                                      \
             const int cout = (s0 >> 4) & 15, nctrl = (s0 >> 12) & 15, loop = (s0 >> 16) & 15;                                 \
@@ -280,37 +208,6 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
         // the tile's output block, two cells (16 bytes) per lane and trip: cells c and c + 1 differ in the first surviving
         // digit (or, without one, in r)
         double *__restrict__ ot = outp + (long)tile * ocells;
-        if (K == 5 && fuse_last) {
-            // the last stage on the way out: output fiber g = i * 512 + tid = cells 4 g .. 4 g + 3 (digit 0 is the fastest axis)
-            int radd = 0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (c < (int)((sw0[K - 1] >> 12) & 15) && (swc[K - 1][c] & 0xff) >= 8)
-                    radd += (((tile * Rt) >> ((swc[K - 1][c] & 0xff) - 8)) & 3) * (int)(swc[K - 1][c] >> 8);
-            const double *__restrict__ Tp = T + (fl_toff + radd);
-            double t[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t[q] = Tp[q];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int g0 = i * kSweepWG;  // (uniform)
-                if (4 * g0 < ocells && 4 * (g0 + tid) < ocells) {
-                    const int b = sweep_perm(4 * g0, kout, rb, surv) + fl_base;
-                    double f[4], o[4];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) f[x] = L[b + x * Rt];
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        o[n] = f[0] * t[n];
-#pragma unroll
-                        for (int x = 1; x < 4; ++x) o[n] += f[x] * t[n + 4 * x];
-                    }
-                    double *__restrict__ op = ot + 4 * (g0 + tid);
-                    *reinterpret_cast<double2 *>(op) = make_double2(o[0], o[1]);
-                    *reinterpret_cast<double2 *>(op + 2) = make_double2(o[2], o[3]);
-                }
-            }
-        } else
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c0 = i * 2 * kSweepWG;  // (uniform)
@@ -325,11 +222,11 @@ __device__ __forceinline__ void sweep_tiles_impl(double *__restrict__ L, const d
     }
 }
 
-template <int K, bool FUSE>
+template <int K>
 __device__ __forceinline__ void sweep_tiles(double *__restrict__ L, const double *__restrict__ T, const uint32_t *stw, const double *__restrict__ F,
                                          double *__restrict__ outp, const long Rcells, const int t_begin, const int t_end, const int kout,
                                          const uint32_t surv, const int tid, const SweepTables &tb) {
-    sweep_tiles_impl<K, FUSE>(L, T, stw, K, 13 - 2 * K, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    sweep_tiles_impl<K>(L, T, stw, K, 13 - 2 * K, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
 }
 
 // Any step (digits in any order): the stage records are re-read per tile and stage, all strides are runtime values.
@@ -403,10 +300,9 @@ __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_kernel(const LevelArgs A
     const int t_begin = (int)((wg - it.b) * it.a);
     const int t_end = min(tiles, t_begin + (int)it.a);
     const bool canon = (sh_step[1] >> 16) & kFlagSweepCanon;
-    if (canon && k == 5 && sweep_fusable(stw, rb)) sweep_tiles<5, true>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
-    else if (canon && k == 5) sweep_tiles<5, false>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
-    else if (canon && k == 4) sweep_tiles<4, false>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
-    else if (canon && k == 3) sweep_tiles<3, false>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    if (canon && k == 5) sweep_tiles<5>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 4) sweep_tiles<4>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 3) sweep_tiles<3>(L, T, stw, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else sweep_tiles_any(L, T, stw, k, rb, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
 }
 
