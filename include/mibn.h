@@ -246,7 +246,7 @@ int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *
  * Multi-GPU: one process per GPU, requests / chains sharded with no data-path collective; the
  * only communication is the final gather of the posteriors (exact path) or the sum of the histograms (Gibbs).  These
  * entry points sit directly on RCCL (librccl.so is dlopen'ed by mibn_comm_init - a single-GPU process never loads it) and
- * run on the context's own stream, over xGMI between the GPUs of a node.  No PyTorch involved.
+ * run on a stream of their own (the gather of batch s must not queue behind the kernels of batch s + 1), over xGMI between the GPUs of a node.  No PyTorch involved.
  *   mibn_comm_unique_id   rank 0 creates the 128-byte RCCL id; the caller hands it to the other ranks out of band
  *                         (sorobn_amd/sharding.py: a file next to the rendezvous port, single node)
  *   mibn_comm_init        collective: every rank calls it with the same id

@@ -16,7 +16,7 @@
 #include <cmath>
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MIBN_HD __host__ __device__
 #else
 #define MIBN_HD

@@ -8,8 +8,9 @@
 //     ancestors, exactly the pruning of BayesNet._variable_elimination (sorobn/bayes_net.py:763-765; MIBN_Q_NOPRUNE:
 //     every variable, the semantics of full_joint_dist, bayes_net.py:460),
 //   * for every joint state of the query variables enumerates the states of the hidden variables (766) in
-//     topological (= id) order with running prefix products - a state change at variable k re-evaluates only the CPTs
-//     of the relevant variables >= k, about two table reads per state - and sums the product of the relevant CPTs: the
+//     TOPOLOGICAL order (Network::topo_asc: by depth, then id - the ids themselves may be any acyclic numbering) with running
+//     prefix products - a state change at position k re-evaluates only the CPTs at positions >= k, which is every CPT
+//     that mentions the variable because a CPT's parents come before it; about two table reads per state - and sums the product of the relevant CPTs: the
 //     same sum-product the reference evaluates by pointwise_mul / sum_out (233-256, 100-103), in a different order of
 //     additions (agreement ~1e-16),
 //   * normalises (790) and writes the dense posterior; zero-probability or out-of-domain evidence gives all zeros
@@ -45,7 +46,7 @@ inline bool tiny_eligible(const Network &net) {
 
 struct TinyArgs {
     const double *pool;
-    const int32_t *meta;  // card[n], pool_off[n], scope_begin[n + 1], anc_mask[n], then (scope_var, scope_stride) pairs
+    const int32_t *meta;  // card[n], pool_off[n], scope_begin[n + 1], anc_mask[n], topo[n], then (scope_var, scope_stride) pairs
     const int64_t *q_off, *e_off, *out_off;
     const int32_t *q_vars, *e_vars, *e_codes;
     double *out;          // results, out_off[0]-relative
@@ -65,12 +66,13 @@ __global__ __launch_bounds__(64) void tiny_kernel(const TinyArgs A) {
     double *P = lpool + A.pool_cells;                                       // [n + 1][64] prefix products
     int32_t *meta = reinterpret_cast<int32_t *>(P + (kTinyMaxVars + 1) * 64);
     uint8_t *st = reinterpret_cast<uint8_t *>(meta + A.meta_words);        // [n][64] current code of every variable
-    uint8_t *seq = st + kTinyMaxVars * 64;                                  // [n][64] relevant variables, ascending
+    uint8_t *seq = st + kTinyMaxVars * 64;                                  // [n][64] relevant variables in topological order
     for (int i = lane; i < A.pool_cells; i += 64) lpool[i] = A.pool[i];
     for (int i = lane; i < A.meta_words; i += 64) meta[i] = A.meta[i];
     __syncthreads();
     const int32_t *card = meta, *pool_off = meta + n, *scope_begin = meta + 2 * n, *anc = meta + 3 * n + 1;
-    const int32_t *scope = meta + 4 * n + 1;
+    const int32_t *topo = meta + 4 * n + 1;  // all variables, parents before children
+    const int32_t *scope = meta + 5 * n + 1;
     const int64_t out0 = A.out_off[0];
     for (int64_t b = (int64_t)blockIdx.x * 64 + lane; b < A.B; b += (int64_t)gridDim.x * 64) {
         const int64_t q0 = A.q_off[b], q1 = A.q_off[b + 1], e0 = A.e_off[b], e1 = A.e_off[b + 1];
@@ -106,7 +108,10 @@ __global__ __launch_bounds__(64) void tiny_kernel(const TinyArgs A) {
         }
         const uint32_t hidden = rel & ~qmask & ~emask;
         int ns = 0;
-        for (uint32_t m = rel; m; m &= m - 1) seq[(ns++) * 64 + lane] = (uint8_t)__builtin_ctz(m);
+        for (int t = 0; t < n; ++t) {  // (ids need not be topological: a parent may carry a larger id than its child)
+            const int v = topo[t];
+            if ((rel >> v) & 1u) seq[(ns++) * 64 + lane] = (uint8_t)v;
+        }
         double total = 0.0;
         for (int qc = 0; qc < qcells; ++qc) {
             {   // joint state qc of the query variables (C-order over the caller's argument order, last fastest)
@@ -158,6 +163,7 @@ inline std::vector<int32_t> tiny_meta(const Network &net) {
     for (int v = 0; v < n; ++v) { m.push_back(run); run += (int32_t)net.scope[v].size(); }
     m.push_back(run);
     for (int v = 0; v < n; ++v) m.push_back((int32_t)(uint32_t)net.anc[v].w[0]);
+    for (int v = 0; v < n; ++v) m.push_back(net.topo_asc[v]);
     for (int v = 0; v < n; ++v)
         for (size_t k = 0; k < net.scope[v].size(); ++k) { m.push_back(net.scope[v][k]); m.push_back((int32_t)net.cstride[v][k]); }
     return m;

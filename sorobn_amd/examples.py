@@ -3,7 +3,8 @@ as `sorobn_amd.BayesNet` objects, so that code written against `sorobn.examples.
 
 The structures and CPT numbers are data: they are read from `data/example_networks.json`, the network specs
 `tests/golden/make_golden.py` dumped from the reference's own objects (the same specs the golden tests use), not from
-the reference's source.  Label types (bool / str) and CPT row order are preserved.
+the reference's source.  Label types (bool / str) are preserved; `prepare()` stores every CPT with its rows sorted (the reference's `alarm()` leaves
+multi-parent CPTs in the order they were typed - the posteriors do not depend on it).
 """
 import json
 import os

@@ -7,6 +7,12 @@
 #include <vector>
 #include <cmath>
 
+#ifdef SWEEP_PROF  // phase timing of the LDS-DMA kernel: 100 MHz ticks accumulated by lane 0 of every workgroup
+__device__ unsigned long long g_prof[16];
+#define MIBN_PROF_INIT unsigned long long prof_t_ = wall_clock64(), prof_a_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define MIBN_PROF_TICK(k) { const unsigned long long t_ = wall_clock64(); prof_a_[k] += t_ - prof_t_; prof_t_ = t_; }
+#define MIBN_PROF_END if (tid == 0) { for (int k_ = 0; k_ < 9; ++k_) atomicAdd(&g_prof[k_], prof_a_[k_]); }
+#endif
 #include "../../sorobn_amd/csrc/sweep_kernel.hip.h"
 
 using namespace mibn;
@@ -81,39 +87,58 @@ int main(int argc, char **argv) {
     for (int r = 0; r < nreq; ++r) CHECK(hipMemcpy(d_arena + (size_t)r * 2 * kCells, h.data(), kCells * 8, hipMemcpyHostToDevice));
     A.prog = d_prog; A.prog_off = d_prog_off; A.arena_off = d_arena_off; A.pool = d_pool; A.arena = d_arena; A.results = nullptr;
     A.items = d_items; A.wg_item = d_wg; A.wg_base = 0;
-    CHECK(hipFuncSetAttribute((const void *)ve_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes));
     for (int wu = 0; wu < 30; ++wu) CHECK(hipMemcpy(d_arena + kCells, d_arena, kCells * 8 * 64, hipMemcpyDeviceToDevice));  // warm the clocks up
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const unsigned grid = (unsigned)wg_item.size();
-    hipLaunchKernelGGL(ve_sweep_kernel, dim3(grid), dim3(kSweepWG), kSweepLdsBytes, 0, A);
-    CHECK(hipDeviceSynchronize());
-    const int reps = 10;
-    CHECK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(ve_sweep_kernel, dim3(grid), dim3(kSweepWG), kSweepLdsBytes, 0, A);
-    CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
-    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    ms /= reps;
-    // check a few cells of the last request against a direct evaluation
-    std::vector<double> o(kCells);
-    CHECK(hipMemcpy(o.data(), d_arena + (size_t)(nreq - 1) * 2 * kCells + kCells, kCells * 8, hipMemcpyDeviceToHost));
-    double err = 0;
-    for (int q = 0; q < 24; ++q) {
-        const int r = (q * 131) % 1024, nc = (q * 577) % 1024;
-        int nn[5]; for (int d = 0; d < 5; ++d) nn[d] = (nc >> (2 * d)) & 3;  // value on digit d after the pass
-        double s = 0;
-        for (int xc = 0; xc < 1024; ++xc) {
-            int xx[5]; for (int d = 0; d < 5; ++d) xx[d] = (xc >> (2 * d)) & 3;
-            double pr = h[(long)xc * 1024 + r];
-            for (int j = 0; j < 5; ++j) {
-                const int dig = 4 - j;
-                const int ctrl = dig > 0 ? xx[dig - 1] : (r >> 4) & 3;  // lower digits are still x when stage j runs
-                pr *= pool[j * 64 + nn[dig] + 4 * xx[dig] + 16 * ctrl];
+    auto run = [&](const char *name, auto kern, int wg, int lds) {
+        CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int r = 0; r < nreq; ++r) CHECK(hipMemsetAsync(d_arena + (size_t)r * 2 * kCells + kCells, 0, kCells * 8, 0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(wg), lds, 0, A);
+        CHECK(hipDeviceSynchronize());
+        const int reps = 10;
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(wg), lds, 0, A);
+        CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        // check cells of the first, a middle and the last request against a direct evaluation
+        double err = 0;
+        std::vector<double> o(kCells);
+        for (int rq : {0, nreq / 2, nreq - 1}) {
+            CHECK(hipMemcpy(o.data(), d_arena + (size_t)rq * 2 * kCells + kCells, kCells * 8, hipMemcpyDeviceToHost));
+            for (int q = 0; q < 48; ++q) {
+                const int r = (q * 131 + rq) % 1024, nc = (q * 577 + 3 * rq) % 1024;
+                int nn[5]; for (int d = 0; d < 5; ++d) nn[d] = (nc >> (2 * d)) & 3;  // value on digit d after the pass
+                double s = 0;
+                for (int xc = 0; xc < 1024; ++xc) {
+                    int xx[5]; for (int d = 0; d < 5; ++d) xx[d] = (xc >> (2 * d)) & 3;
+                    double pr = h[(long)xc * 1024 + r];
+                    for (int j = 0; j < 5; ++j) {
+                        const int dig = 4 - j;
+                        const int ctrl = dig > 0 ? xx[dig - 1] : (r >> 4) & 3;  // lower digits are still x when stage j runs
+                        pr *= pool[j * 64 + nn[dig] + 4 * xx[dig] + 16 * ctrl];
+                    }
+                    s += pr;
+                }
+                err = fmax(err, fabs(o[(long)r * 1024 + nc] - s) / s);
             }
-            s += pr;
         }
-        err = fmax(err, fabs(o[(long)r * 1024 + nc] - s) / s);
-    }
-    printf("ve_sweep_kernel: %d requests x %d tiles, %d tiles per workgroup (%u workgroups): %.3f ms  %.1f GB/s  max rel err %.1e\n", nreq, tiles,
-           iters, grid, ms, 2.0 * nreq * kCells * 8 / ms / 1e6, err);
+#ifdef SWEEP_PROF
+        {
+            unsigned long long hp[16], z[16] = {0};
+            CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_prof), sizeof(hp)));
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)));
+            const double nt = (double)nreq * tiles * (reps + 1) * 100.0;  // -> us per tile
+            printf("      per tile, us: loop top %.2f  dma wait %.2f  barrier+stages %.2f %.2f %.2f %.2f %.2f  readout+stores %.2f  barrier+dma issue %.2f\n",
+                   hp[0] / nt, hp[1] / nt, hp[2] / nt, hp[3] / nt, hp[4] / nt, hp[5] / nt, hp[6] / nt, hp[7] / nt, hp[8] / nt);
+        }
+#endif
+        printf("%-26s %d requests x %d tiles, %d tiles per workgroup (%u workgroups): %.3f ms  %.1f GB/s  max rel err %.1e\n", name, nreq, tiles,
+               iters, grid, ms, 2.0 * nreq * kCells * 8 / ms / 1e6, err);
+        fflush(stdout);
+    };
+    run("ve_sweep_kernel (r2)", ve_sweep_kernel, kSweepWG, kSweepLdsBytes);
+    run("ve_sweep_dma_kernel", ve_sweep_dma_kernel, 512, kSweepLdsBytes);
+    run("ve_sweep_dma2_kernel", ve_sweep_dma2_kernel, 512, kSweepDmaLdsBytes);
     return 0;
 }
