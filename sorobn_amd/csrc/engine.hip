@@ -193,8 +193,8 @@ struct mibn_ctx {
     int threads = 0;
     int trace = 0;        // debug: one stderr line per launch
     int split_kinds = 0;  // profiling: one launch per (level, class of work) instead of one per level
-    int sweep_dma = 1;    // the sweep kernel: 1 = tile filled by LDS-DMA, 16-byte LDS accesses, two workgroups per CU (round 3); 2 = the same with
-                          // two tile buffers and one workgroup per CU; 0 = round 2's register-staged kernel
+    int sweep_dma = 1;    // the sweep kernel: 1 = ve_sweep_dma_kernel (round 3: LDS-DMA fill, 16-byte LDS accesses, wave-local stage pairs,
+                          // wave-owned tail); 0 = round 2's register-staged ve_sweep_kernel (reference for A/B runs and the bit-for-bit test)
     int gibbs_lds = 1;    // Gibbs: keep the CPTs in LDS when they fit (0: always read them through L2)
     int64_t chunk = 16384;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
 };
@@ -283,9 +283,7 @@ int mibn_create(int device, mibn_t **out) {
               hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
     // the sweep kernel keeps its 64 KiB tile, the T tables and the step descriptor in dynamic LDS (two workgroups per CU)
     ok = ok && hipFuncSetAttribute((const void *)ve_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes) == hipSuccess;
-    // round 3: the double-buffered LDS-DMA form, 137.5 KiB per workgroup (one per CU)
     ok = ok && hipFuncSetAttribute((const void *)ve_sweep_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void *)ve_sweep_dma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSweepDmaLdsBytes) == hipSuccess;
     if (!ok) { delete h; return MIBN_E_HIP; }
     *out = h;
     return MIBN_OK;
@@ -357,7 +355,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "chunk_sets") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_sets = std::max(2, std::min(kChunkSets, (int)value)); h->set_cursor = 0; }
     else if (n == "trace") h->trace = (int)value;
     else if (n == "split_kinds") h->split_kinds = value != 0;
-    else if (n == "sweep_dma") h->sweep_dma = std::max(0, std::min(2, (int)value));
+    else if (n == "sweep_dma") h->sweep_dma = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
     else if (n == "tiny") h->tiny = value != 0;
     else if (n == "gpu_search") h->gpu_search = std::max(0, std::min(2, (int)value));  // elimination-order search on the device
@@ -992,8 +990,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 A.wg_base = (uint32_t)(L.wg_first - L.wg_level);
                 size_t e0 = 0, e1 = 0;
                 if ((rc = next_event(h, st, e0, S))) return rc;
-                if (sweep && h->sweep_dma == 2) hipLaunchKernelGGL(ve_sweep_dma2_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepDmaLdsBytes, S, A);
-                else if (sweep && h->sweep_dma) hipLaunchKernelGGL(ve_sweep_dma_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
+                if (sweep && h->sweep_dma) hipLaunchKernelGGL(ve_sweep_dma_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
                 else if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
                 else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, S, A);
                 if ((rc = next_event(h, st, e1, S))) return rc;

@@ -276,34 +276,38 @@ __device__ __forceinline__ void sweep_tiles_any(double *__restrict__ L, const do
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Round 3: the same pass with the tile DOUBLE-BUFFERED in LDS and filled by LDS-DMA (global_load_lds_dwordx4).
+// Round 3: ve_sweep_dma_kernel - the same pass, rebuilt around what the phase timers of tools/ubench/sweep_real.hip showed.
 //
-// What bounded the kernel above was not bytes (PMC traffic / algorithmic = 0.92) but memory-level parallelism: a workgroup
-// had its 64 KiB of loads in flight only between the end of a tile's stages and the start of the next tile's - the next
-// tile waited in 32 VGPRs per lane - and two workgroups per CU overlapped one another's phases only statistically
-// (9.3 us per tile and CU at 3.6 TB/s against 5 x 0.8 us of stages).  Here ONE workgroup per CU owns two tile buffers:
-// while tile i is contracted and written out of buffer i & 1, the 64 KiB of tile i + 1 stream from HBM straight into the
-// other buffer - no VGPRs, no ds_write pass - and the DMA of tile i + 2 is issued the moment tile i has been read out.
-// Every CU keeps 64 KiB of loads in flight all the time, the stores of tile i drain under the stages of tile i + 1, and the
-// per-tile critical path is the stages alone.
-//   * LDS: 2 x 64 KiB tiles + 8 KiB T + 1.5 KiB descriptor = 137.5 KiB (of 160 KiB): one workgroup per CU.
-//   * LDS-DMA writes base + 16 * lane: the staged layout L[r + Rt * xc] is exactly the order in which 16-byte piece
-//     c2 = i * WG + tid is laid down, only the per-lane SOURCE address is strided (runs of Rt * 8 bytes).
-//   * hipcc does not count the DMA (inline asm): completion is tracked by hand with s_waitcnt vmcnt(N).  VMEM operations
-//     of a wave retire in order, so "at most N outstanding" with N = the operations issued after the DMA of the tile
-//     (the stores of the previous tile, the DMA of the next one) means the tile has landed; __syncthreads() then publishes
-//     every wave's share.  __syncthreads() itself lowers to s_waitcnt lgkmcnt(0) + s_barrier on gfx950: it does not drain
-//     the vector-memory queue, the DMA stays in flight across the stage barriers.
-// The step encoding, the stage geometry and the arithmetic (order of the FMAs) are those of the kernel above: bit-identical
-// results (tests/test_gpu_parity.py::test_sweep_dma_kernel_reproduces_the_register_staged_kernel).
+// The kernel above is NOT bound by HBM (a copy with its access pattern - 64-byte runs in, 64 KiB blocks out - streams at
+// 5.05 TB/s through LDS-DMA, tools/ubench/pattern_copy.hip) but by LDS instruction issue: 1.0 - 1.3 us per stage with 8-byte
+// accesses (hipcc pairs them into ds_read2_b64 / ds_write2st64_b64: 8 and 13 LDS cycles each) against 0.2 us of fp64 FMAs, a
+// readout whose 32-lane groups hit ONE bank pair (1.6 us), a ds_write pass to fill the tile, and seven workgroup barriers
+// per tile that keep all waves in the same phase (all read, all multiply, all write).  Two workgroups per CU serialised
+// on the one LDS pipe: 8.1 us per tile and CU = 4.1 TB/s in isolation, 3.6 in the C3 mix.  What changed:
+//   * the tile is filled by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.  LDS-DMA writes
+//     base + 16 * lane: the staged layout L[r + Rt * xc] is kept, only the per-lane SOURCE address is strided.  hipcc does
+//     not count the DMA (inline asm): the wave waits with s_waitcnt vmcnt(0) - VMEM operations of a wave retire in order,
+//     the stores of the previous tile were issued before it - and __syncthreads() publishes every wave's share
+//     (__syncthreads() lowers to s_waitcnt lgkmcnt(0) + s_barrier on gfx950: it does not drain the vector-memory queue);
+//   * 16-byte LDS accesses: a lane owns the fibers of two adjacent R cells (one double2 per fiber position);
+//   * wave-local stage pairs (0, 1) and (2, 3): both stages of a pair give a wave the same cells, so there is no workgroup
+//     barrier between them and the waves drift out of phase - one wave's LDS writes overlap another one's FMAs;
+//   * a wave-owned tail: the last stage writes the output block from its registers (no LDS write, no readout pass) and
+//     refills the wave's own cells with the next tile's DMA before its FMAs: 3 workgroup barriers per tile instead of 7,
+//     the DMA latency runs under the last stage and the stores.
+// Two workgroups per CU as before (73.5 KiB of LDS, <= 128 VGPRs): while one waits for its tile the other one is in its
+// stages.  Measured: 4.5 - 4.7 TB/s in isolation (sweep_real.hip), 4.2 - 4.3 TB/s in the C3 mix (profiles/r03_*).  Also measured
+// and not kept: two tile buffers with one workgroup per CU (the next tile streams in under the stages: 4.0 - 4.1 TB/s, the
+// lock-step of one workgroup's eight waves costs more than the exposed latency), 1 024-lane workgroups (3.1), a straight-
+// line stage with all sixteen reads of a lane in flight (spills at 128 VGPRs), s_setprio around the memory phases (none).
+// The step encoding and the arithmetic (order of the FMAs per output cell) are those of the kernel above: the two kernels
+// agree bit for bit (tests/test_gpu_parity.py::test_sweep_kernels_agree_bit_for_bit).
 
 #ifndef MIBN_PROF_INIT  // (tools/ubench/sweep_real.hip defines these to time the phases of a tile with wall_clock64)
 #define MIBN_PROF_INIT
 #define MIBN_PROF_TICK(k)
 #define MIBN_PROF_END
 #endif
-
-constexpr int kSweepDmaLdsBytes = 2 * kSweepTileCells * 8 + kSweepMaxT * 8 + kMaxStepWords * 4;
 
 // byte address of an LDS location (what M0 takes)
 __device__ __forceinline__ uint32_t lds_byte_addr(const void *p) {
@@ -319,20 +323,7 @@ __device__ __forceinline__ void dma16(const double *gsrc, const uint32_t lds_bas
                  : "memory");
 }
 
-// s_waitcnt vmcnt(n), n wave-uniform in [0, 16]
-__device__ __forceinline__ void wait_vmcnt_le(const int n) {
-#define MIBN_VMCNT(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
-    switch (n) {
-        MIBN_VMCNT(1) MIBN_VMCNT(2) MIBN_VMCNT(3) MIBN_VMCNT(4) MIBN_VMCNT(5) MIBN_VMCNT(6) MIBN_VMCNT(7) MIBN_VMCNT(8)
-        MIBN_VMCNT(9) MIBN_VMCNT(10) MIBN_VMCNT(11) MIBN_VMCNT(12) MIBN_VMCNT(13) MIBN_VMCNT(14) MIBN_VMCNT(15) MIBN_VMCNT(16)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef MIBN_VMCNT
-}
-
-// ---- the stages.  What bounds a stage is LDS instruction issue (measured with the phase timers of tools/ubench/sweep_real.hip:
-// 1.0 - 1.3 us per stage with 8-byte accesses - hipcc pairs them into ds_read2_b64 / ds_write2st64_b64, 8 and 13 LDS cycles each -
-// against 0.2 us of fp64 FMAs), so the canonical steps move 16 bytes per LDS instruction: a lane owns the fibers of TWO
+// ---- the stages.  The canonical steps move 16 bytes per LDS instruction: a lane owns the fibers of TWO
 // adjacent R cells (r = 2 rp, 2 rp + 1: one double2 per fiber position) for two values of the loop digit.  Lane bits, low
 // to high: rp (rb - 1 bits), the free digits other than the contracted and the loop digit in ascending order (2 bits each),
 // and one bit that selects the half of the loop digit's values.  For k = 5 (rp = 2 bits) the 16-lane groups of a
@@ -450,11 +441,90 @@ __device__ __forceinline__ void sweep_fiber_pairs(double *__restrict__ L, const 
     else sweep_fiber_pairs_impl<COUT, SX, SL, false>(L, T, base, toff, loop_ts, 0);
 }
 
-// any step: the lane mapping and the 8-byte accesses of the register-staged kernel (sweep_fibers)
-template <int COUT>
-__device__ __forceinline__ void sweep_fibers_rt(double *__restrict__ L, const double *__restrict__ T, const int base, const int sx,
-                                                const int sl, const int toff, const int loop_ts) {
-    sweep_fibers<COUT, 0, 0>(L, T, base, sx, sl, toff, loop_ts);
+// The last stage of a wave-owned tail (sweep_tiles_dma, OWN): the results go from the registers straight to the output
+// block - no LDS write, no readout pass - and the moment the wave's reads of the stage have returned its cells are free:
+// the DMA of the NEXT tile is issued before the FMAs and lands under them and the stores.  Lane bits, low to high: the first
+// field d1 (four lanes = the 4 x 4 outputs of a 128-byte line: n = digit 0, then d1), rp, the other fields, the half of the
+// loop digit.  The 4-way bank conflict of the reads (only rp spreads the lanes of a group) is the one this stage had anyway.
+template <int K, bool PAR, class DmaNext>
+__device__ __forceinline__ void sweep_last_stage_out(const double *__restrict__ L, const double *__restrict__ T, double *__restrict__ ot,
+                                                     const int tid, const int rg_tile, const uint32_t s1, const uint32_t (&cw)[3],
+                                                     const int nctrl, DmaNext dma_next) {
+    constexpr int RB = 13 - 2 * K, RT = 1 << RB;
+    constexpr SweepGeom G = sweep_geom(K, K - 1);  // dig 0, fields (1, ..), loop
+    static_assert(G.dig == 0 && G.f[0] == 1, "last stage: digit 0 contracted, first field digit 1");
+    const int d1 = tid & 3, rp = (tid >> 2) & ((RT >> 1) - 1);
+    int bits = tid >> (RB + 1);
+    int base = 2 * rp + (d1 << (RB + 2));
+    int c_hi = 4 * d1;  // output cell without digit 0 and r
+#pragma unroll
+    for (int q = 1; q < K - 2; ++q) {
+        base += (bits & 3) << (RB + 2 * G.f[q]);
+        c_hi += (bits & 3) << (2 * G.f[q]);
+        bits >>= 2;
+    }
+    const int h = bits & 1;
+    base += (2 * h) << (RB + 2 * G.loop);
+    c_hi += (2 * h) << (2 * G.loop);
+    int toff = (int)(s1 & 0xffff), loop_ts = 0, par_ts = 0;
+    const int rg = rg_tile + 2 * rp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c < nctrl) {
+            const int src = cw[c] & 0xff, ts = (int)(cw[c] >> 8);
+            if (src >= 8) { toff += ((rg >> (src - 8)) & 3) * ts; if (src == 8) par_ts = ts; }
+            else {
+                toff += ((base >> (RB + 2 * src)) & 3) * ts;
+                if (src == G.loop) loop_ts = ts;
+            }
+        }
+    constexpr int SX = RT, SL = RT << (2 * G.loop);  // digit 0: stride Rt
+    const double2 *__restrict__ Lp = reinterpret_cast<const double2 *>(L + base);
+    double2 f[2][4];
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) f[l][x] = Lp[(l * SL + x * SX) / 2];
+    // the wave's cells have been read (the fence waits for the LDS): refill them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the data is in the registers before the DMA may overwrite the cells)
+    dma_next();
+    double t0[16];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        double s0[4], s1v[4];
+        if (PAR || l == 0 || loop_ts) {
+            const double2 *__restrict__ Tp = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double2 v = Tp[q]; t0[2 * q] = v.x; t0[2 * q + 1] = v.y; }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s0[n] = f[l][0].x * t0[n];
+#pragma unroll
+            for (int x = 1; x < 4; ++x) s0[n] += f[l][x].x * t0[n + 4 * x];
+        }
+        if constexpr (PAR) {
+            const double2 *__restrict__ Tq = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts + par_ts));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double2 v = Tq[q]; t0[2 * q] = v.x; t0[2 * q + 1] = v.y; }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s1v[n] = f[l][0].y * t0[n];
+#pragma unroll
+            for (int x = 1; x < 4; ++x) s1v[n] += f[l][x].y * t0[n + 4 * x];
+        }
+        // output cell: digits as in LDS (identity), r slowest: c = n + c_hi + (l << 2 loop) + 4^K r
+        double *__restrict__ o0 = ot + (c_hi + (l << (2 * G.loop)) + ((2 * rp) << (2 * K)));
+        double *__restrict__ o1 = o0 + (1 << (2 * K));
+        *reinterpret_cast<double2 *>(o0) = make_double2(s0[0], s0[1]);
+        *reinterpret_cast<double2 *>(o0 + 2) = make_double2(s0[2], s0[3]);
+        *reinterpret_cast<double2 *>(o1) = make_double2(s1v[0], s1v[1]);
+        *reinterpret_cast<double2 *>(o1 + 2) = make_double2(s1v[2], s1v[3]);
+    }
 }
 
 // Readout order.  Piece e (16 bytes = output cells c, c + 1) of a tile's output block: lanes e = trip * 512 + tid.  With the
@@ -470,10 +540,14 @@ __device__ __forceinline__ int sweep_readout_cell(const int e, const int kout) {
     return 2 * (lo | (mid << 2) | (r3 << mr) | (top << (mr + 3)));
 }
 
-// The tiles [t_begin, t_end) of one work item, double-buffered.  K > 0: canonical step of K variables (compile-time stage
-// geometry, 16-byte LDS accesses); K = 0: any step (runtime strides, 8-byte accesses).
-template <int K, int NBUF>
-__device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ Lbuf, double *__restrict__ T, const uint32_t *stw, const int k_rt,
+// The tiles [t_begin, t_end) of one work item.  K > 0: canonical step of K variables (compile-time stage geometry, 16-byte
+// LDS accesses); K = 0: any step (runtime strides, 8-byte accesses).  OWN (K = 5 / 4, every digit survives in place): the
+// wave-owned tail.  The last stage gives a wave the cells {one value fa of a digit, the pair 2 h, 2 h + 1 of another one} =
+// two runs of 512 consecutive LDS cells (K = 5: run rho = d3 + 4 d4, fa = d3, pair = d4; K = 4: rho = d2 + 4 d3, fa = d3,
+// pair = d2); the DMA fills the same cells per wave, so nothing between the barrier after stage K - 2 and the landing of
+// the next tile needs the other waves.
+template <int K, bool OWN>
+__device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *__restrict__ T, const uint32_t *stw, const int k_rt,
                                                 const int rb_rt, const double *__restrict__ F, double *__restrict__ outp,
                                                 const long Rcells, const int t_begin, const int t_end, const int kout,
                                                 const uint32_t surv, const int tid, const SweepTables &tb) {
@@ -483,50 +557,52 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ Lbuf, doubl
     const int k = K ? K : k_rt, rb = K ? 13 - 2 * K : rb_rt;
     const int Rt = 1 << rb;
     // (the stage records are re-read from the descriptor per tile and stage and a lane's cell index re-derived from its id:
-    //  kept across the tile loop they cost 25 scalar and 10 vector registers - spills at the 128-VGPR budget of two
-    //  workgroups per CU)
+    //  kept across the tile loop they cost 25 scalar and 10 vector registers - spills at the 128-VGPR budget)
     const int ocells = Rt << (2 * kout);
-    // readout: piece e = q * WG + tid of the output block = cells c, c + 1 (sweep_readout_cell); the bit deposit is linear
-    // in e, so a lane keeps its own part and adds a uniform part per trip
+    // readout (not OWN): piece e = q * WG + tid of the output block = cells c, c + 1 (sweep_readout_cell); the bit deposit is
+    // linear in e, so a lane keeps its own part and adds a uniform part per trip
     const int c_lane = sweep_readout_cell(tid, kout);
     const int p_lane = sweep_perm(c_lane, kout, rb, surv);
     const int st0 = kout > 0 ? 1 << (rb + 2 * (int)(surv & 15)) : 1;
-    // store instructions THIS WAVE issues per tile: a trip in which no lane of the wave has a cell is skipped by a scalar
-    // branch, so that the count below is exactly what the wave's vmcnt sees
-    const int c_wave = uni(sweep_readout_cell(tid & ~63, kout));  // (the lowest cell of the wave: the deposit is monotonic in e)
-    int n_st = 0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) n_st += (sweep_readout_cell(q * WG, kout) + c_wave < ocells) ? 1 : 0;
-    // DMA: piece c2 = i * WG + tid = cells (2 rp, 2 rp + 1) of combination xc
+    const int c_wave = uni(sweep_readout_cell(tid & ~63, kout));  // the lowest cell of the wave (the deposit is monotonic in e)
+    // DMA: a wave instruction fills 1 KiB = 128 consecutive LDS cells (lane l the cells lambda + 2 l, + 1); LDS cell lambda is
+    // cell (lambda & (Rt - 1)) of combination lambda >> rb.  Default: instruction i of wave w fills the cells from 1024 i + 128 w.
+    const int lane = tid & 63, wv = tid >> 6;
+    const int own_rho0 = K == 5 ? (wv & 3) + 8 * (wv >> 2) : 2 * (wv >> 2) + 4 * (wv & 3);  // run of the pair's first value; the second one:
+    constexpr int kOwnRhoStep = K == 5 ? 4 : 1;                                             // + this
     const int rp = tid & ((Rt >> 1) - 1);
-    const long g_tid = (long)(tid >> (rb - 1)) * Rcells + 2 * rp;
+    const long g_tid = OWN ? (long)((512 * own_rho0 + 2 * lane) >> rb) * Rcells + ((2 * lane) & (Rt - 1))
+                           : (long)(tid >> (rb - 1)) * Rcells + 2 * rp;
     const long g_step = (long)(WG >> (rb - 1)) * Rcells;
-    const uint32_t lds0 = lds_byte_addr(Lbuf) + 16u * (uint32_t)(tid & ~63);
-    auto dma_tile = [&](const int tile, const int buf) {
+    const uint32_t lds_l = lds_byte_addr(L);
+    auto dma_tile = [&](const int tile) {
         const double *__restrict__ Ft = F + (long)tile * Rt + g_tid;
-        const uint32_t lb = (uint32_t)uni((int)(lds0 + (uint32_t)buf * (kSweepTileCells * 8)));
+        if constexpr (OWN) {
+            const uint32_t lb = (uint32_t)uni((int)(lds_l + 8u * 512u * (uint32_t)own_rho0));
 #pragma unroll
-        for (int i = 0; i < PER; ++i) dma16(Ft + i * g_step, lb + (uint32_t)(i * WG * 16));
+            for (int i = 0; i < PER; ++i) {
+                const int lam = 512 * kOwnRhoStep * (i >> 2) + 128 * (i & 3);  // (compile-time)
+                dma16(Ft + (long)(lam >> rb) * Rcells, lb + (uint32_t)(8 * lam));
+            }
+        } else {
+            const uint32_t lb = (uint32_t)uni((int)(lds_l + 16u * (uint32_t)(tid & ~63)));
+#pragma unroll
+            for (int i = 0; i < PER; ++i) dma16(Ft + i * g_step, lb + (uint32_t)(i * WG * 16));
+        }
     };
     const int n_tiles = t_end - t_begin;
     MIBN_PROF_INIT
-    dma_tile(t_begin, 0);
+    dma_tile(t_begin);
     sweep_build_tables(tb, tid);  // (its loads retire behind the first tile's: the tile has landed when T is built)
-    if (NBUF > 1 && n_tiles > 1) dma_tile(t_begin + 1, 1);
     for (int i = 0; i < n_tiles; ++i) {
         const int tile = t_begin + i;
-        double *__restrict__ L = Lbuf + (NBUF > 1 ? (i & 1) * kSweepTileCells : 0);
         MIBN_PROF_TICK(0)
-        // two buffers: behind this tile's DMA the wave has issued the stores of the previous tile and the DMA of the next one;
-        // one buffer: nothing (the stores of the previous tile came before it)
-        if (NBUF > 1) wait_vmcnt_le((i > 0 ? n_st : 0) + (i + 1 < n_tiles ? PER : 0));
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed
         MIBN_PROF_TICK(1)
-        __syncthreads();  // every wave's share of the tile has landed (first tile: T is complete)
-        if (NBUF == 1) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();  // ... and everybody else's (first tile: T is complete)
         const int rg = tile * Rt + (K ? 2 * rp : (tid & (Rt - 1)));  // this lane's (even) R cell
 #define MIBN_SWEEP_STAGE(J)                                                                                                   \
-        if (J < KS && J < k) {                                                                                                \
+        if (J < KS && J < k && !(OWN && J == K - 1)) {                                                                        \
             const uint32_t s0 = (uint32_t)uni((int)stw[J * kSweepStageWords]), s1 = (uint32_t)uni((int)stw[J * kSweepStageWords + 1]); \
             uint32_t cw[3];                                                                                                   \
             _Pragma("unroll") for (int c = 0; c < 3; ++c) cw[c] = (uint32_t)uni((int)stw[J * kSweepStageWords + 2 + c]);      \
@@ -563,8 +639,8 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ Lbuf, doubl
                 }                                                                                                             \
             } else {                                                                                                          \
                 const int sx = 1 << (rb + 2 * (int)(s0 & 15)), sl = 1 << (rb + 2 * loop);                                     \
-                if (cout == 4) sweep_fibers_rt<4>(L, T, bs, sx, sl, toff, loop_ts);                                           \
-                else sweep_fibers_rt<1>(L, T, bs, sx, sl, toff, loop_ts);                                                     \
+                if (cout == 4) sweep_fibers<4, 0, 0>(L, T, bs, sx, sl, toff, loop_ts);                                        \
+                else sweep_fibers<1, 0, 0>(L, T, bs, sx, sl, toff, loop_ts);                                                  \
                 __syncthreads();                                                                                              \
             }                                                                                                                 \
             MIBN_PROF_TICK(2 + J)                                                                                             \
@@ -575,37 +651,51 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ Lbuf, doubl
         MIBN_SWEEP_STAGE(3)
         MIBN_SWEEP_STAGE(4)
 #undef MIBN_SWEEP_STAGE
-        // the tile's output block, two cells (16 bytes) per lane and trip.  One buffer, two workgroups per CU: from here to the
-        // landing of the next tile this workgroup has few instructions to issue - LDS reads, stores, the DMA - and all of them
-        // sit on its critical path while the other workgroup is in its stages: they go first (instruction arbitration is by
-        // priority, then age)
-        if (NBUF == 1) __builtin_amdgcn_s_setprio(3);
         double *__restrict__ ot = outp + (long)tile * ocells;
+        if constexpr (OWN) {
+            // the last stage writes the output block itself and refills the wave's cells (sweep_last_stage_out)
+            constexpr int JL = K > 0 ? K - 1 : 0;
+            const uint32_t s1 = (uint32_t)uni((int)stw[JL * kSweepStageWords + 1]);
+            const int nctrl = (int)(((uint32_t)uni((int)stw[JL * kSweepStageWords]) >> 12) & 15);
+            uint32_t cw[3];
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int c_trip = sweep_readout_cell(q * WG, kout);  // (uniform)
-            if (c_trip + c_wave < ocells) {                       // (wave-uniform: see n_st)
-                const int c = c_trip + c_lane;
-                const int a = sweep_perm(c_trip, kout, rb, surv) + p_lane;
-                if (c < ocells) *reinterpret_cast<double2 *>(ot + c) = make_double2(L[a], L[a + st0]);
+            for (int c = 0; c < 3; ++c) cw[c] = (uint32_t)uni((int)stw[JL * kSweepStageWords + 2 + c]);
+            bool par = false;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) par = par || (c < nctrl && (cw[c] & 0xff) == 8);
+            auto dma_next = [&]() { if (i + 1 < n_tiles) dma_tile(tile + 1); };
+            if (par) sweep_last_stage_out<(K > 0 ? K : 5), true>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dma_next);  // (uniform)
+            else sweep_last_stage_out<(K > 0 ? K : 5), false>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dma_next);
+            MIBN_PROF_TICK(7)
+        } else {
+            // the tile's output block, two cells (16 bytes) per lane and trip; a trip in which no lane of the wave has a cell is
+            // skipped by a scalar branch
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int c_trip = sweep_readout_cell(q * WG, kout);  // (uniform)
+                if (c_trip + c_wave < ocells) {
+                    const int c = c_trip + c_lane;
+                    const int a = sweep_perm(c_trip, kout, rb, surv) + p_lane;
+                    if (c < ocells) *reinterpret_cast<double2 *>(ot + c) = make_double2(L[a], L[a + st0]);
+                }
             }
-        }
-        MIBN_PROF_TICK(7)
-        if (i + NBUF < n_tiles) {
-            __syncthreads();  // every wave has read the tile out: its buffer takes the next tile (two buffers: the one after next)
-            dma_tile(tile + NBUF, NBUF > 1 ? (i & 1) : 0);
+            MIBN_PROF_TICK(7)
+            if (i + 1 < n_tiles) {
+                __syncthreads();  // every wave has read the tile out
+                dma_tile(tile + 1);
+            }
         }
         MIBN_PROF_TICK(8)
     }
     MIBN_PROF_END
 }
 
-template <int NBUF>
-__device__ __forceinline__ void sweep_dma_body(const LevelArgs &A) {
+// 73.5 KiB of dynamic LDS like the register-staged kernel: two workgroups per CU, <= 128 VGPRs
+__global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_dma_kernel(const LevelArgs A) {
     extern __shared__ __attribute__((aligned(16))) double sweep_lds[];
-    double *__restrict__ Lbuf = sweep_lds;
-    double *__restrict__ T = sweep_lds + NBUF * kSweepTileCells;
-    uint32_t *sh_step = reinterpret_cast<uint32_t *>(sweep_lds + NBUF * kSweepTileCells + kSweepMaxT);
+    double *__restrict__ L = sweep_lds;
+    double *__restrict__ T = sweep_lds + kSweepTileCells;
+    uint32_t *sh_step = reinterpret_cast<uint32_t *>(sweep_lds + kSweepTileCells + kSweepMaxT);
     const int tid = threadIdx.x;
     const uint32_t wg = blockIdx.x + A.wg_base;
     const Item it = A.items[A.wg_item[wg]];
@@ -627,17 +717,13 @@ __device__ __forceinline__ void sweep_dma_body(const LevelArgs &A) {
     const int t_begin = (int)((wg - it.b) * it.a);
     const int t_end = min(tiles, t_begin + (int)it.a);
     const bool canon = (sh_step[1] >> 16) & kFlagSweepCanon;
-    if (canon && k == 5) sweep_tiles_dma<5, NBUF>(Lbuf, T, stw, 5, 3, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
-    else if (canon && k == 4) sweep_tiles_dma<4, NBUF>(Lbuf, T, stw, 4, 5, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
-    else if (canon && k == 3) sweep_tiles_dma<3, NBUF>(Lbuf, T, stw, 3, 7, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
-    else sweep_tiles_dma<0, NBUF>(Lbuf, T, stw, k, rb, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    if (canon && k == 5 && kout == 5 && surv == 0x43210u) sweep_tiles_dma<5, true>(L, T, stw, 5, 3, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 5) sweep_tiles_dma<5, false>(L, T, stw, 5, 3, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 4 && kout == 4 && surv == 0x3210u) sweep_tiles_dma<4, true>(L, T, stw, 4, 5, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 4) sweep_tiles_dma<4, false>(L, T, stw, 4, 5, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 3) sweep_tiles_dma<3, false>(L, T, stw, 3, 7, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else sweep_tiles_dma<0, false>(L, T, stw, k, rb, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
 }
-
-// one tile buffer, two workgroups per CU (73.5 KiB each, <= 128 VGPRs): a workgroup's DMA latency and its store / DMA issue
-// hide under the other workgroup's stages
-__global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_dma_kernel(const LevelArgs A) { sweep_dma_body<1>(A); }
-// two tile buffers, one workgroup per CU (137.5 KiB): the next tile streams in under this tile's stages
-__global__ __launch_bounds__(kSweepWG, 2) void ve_sweep_dma2_kernel(const LevelArgs A) { sweep_dma_body<2>(A); }
 
 __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_kernel(const LevelArgs A) {
     extern __shared__ __attribute__((aligned(16))) double sweep_lds[];

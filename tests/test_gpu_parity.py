@@ -177,6 +177,32 @@ def test_c3_chain_form_vs_pair_form(amd):
             _check_requests(b, e["requests"], sp["name"] + " chain")
 
 
+def test_sweep_kernels_agree_bit_for_bit(amd):
+    """Round 3's sweep kernel (ve_sweep_dma_kernel: tile filled by LDS-DMA, 16-byte LDS accesses on R-cell pairs, wave-local
+    stage pairs, the last stage writing the output block from its registers) against round 2's register-staged
+    ve_sweep_kernel on the same programs: another lane <-> fiber mapping, another barrier structure, another readout - and the
+    SAME sequence of FMAs per output cell, so the posteriors must agree bit for bit.  Covers the canonical 5-, 4- and
+    3-variable steps, stages without a new variable (kout < k: the plain readout), the general path (sweep_canon = 0) and
+    two tiles per step (4^7-cell tables on the 8x8 grid)."""
+    for spec, n_req in ((netspec.grid_spec(10, 10, 4, seed=0), 3072), (netspec.grid_spec(8, 8, 4, seed=3), 512)):
+        bn = netspec.build(spec, amd.BayesNet)
+        be = bn.backend
+        n = len(spec["nodes"])
+        q, ev, ec = netspec.c3_requests(n, 4, n_req, 4, seed=5)
+        to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(n)], np.int32)
+        for opts in ({"sweep": 5}, {"sweep": 4}, {"sweep": 3}, {"sweep": 5, "sweep_canon": 0}, {"sweep": 5, "sweep_iters": 3}):
+            for k, v in {"sweep": 5, "sweep_canon": 1, "sweep_iters": 8, **opts}.items():
+                be.engine.set_option(k, v)
+            be.engine.set_option("sweep_dma", 0)
+            old = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+            swept = sum(s["alg_bytes"] for s in be.engine.kernel_stats() if s["name"] == "ve_sweep_kernel")
+            assert swept > 0.05 * be.engine.stats()["alg_bytes"], (spec["name"], opts)
+            be.engine.set_option("sweep_dma", 1)
+            new = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+            assert np.array_equal(old, new), (spec["name"], opts, float(np.max(np.abs(old - new))))
+            assert np.allclose(new.sum(1), 1.0, atol=1e-12)
+
+
 def test_c3_sweep_form_vs_chain_form(amd):
     """SWEEP steps (up to five variables per pass, the tile resident in LDS: ve_sweep_kernel, the default) against the
     CHAIN / pair programs (option sweep=0) on the C3 stream: another kernel, another contraction order, a quarter fewer

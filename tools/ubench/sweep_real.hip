@@ -139,6 +139,5 @@ int main(int argc, char **argv) {
     };
     run("ve_sweep_kernel (r2)", ve_sweep_kernel, kSweepWG, kSweepLdsBytes);
     run("ve_sweep_dma_kernel", ve_sweep_dma_kernel, 512, kSweepLdsBytes);
-    run("ve_sweep_dma2_kernel", ve_sweep_dma2_kernel, 512, kSweepDmaLdsBytes);
     return 0;
 }
