@@ -55,9 +55,9 @@ __device__ __forceinline__ void sweep_fibers(double *__restrict__ L, const doubl
         for (int x = 0; x < 4; ++x) f[x] = L[b + x * sx];
 #pragma unroll
         for (int n = 0; n < COUT; ++n) {
-            double s = f[0] * t[n];
-#pragma unroll
-            for (int x = 1; x < 4; ++x) s += f[x] * t[n + COUT * x];
+            double s = f[0] * t[n];  // (explicit FMAs: with contraction left to the compiler, which product of a sum stays a
+#pragma unroll                   //  plain multiply differs from one code shape to the next - the two sweep kernels then differ in the last bit)
+            for (int x = 1; x < 4; ++x) s = __builtin_fma(f[x], t[n + COUT * x], s);
             L[b + n * sx] = s;
         }
     }
@@ -405,7 +405,7 @@ __device__ __forceinline__ void sweep_fiber_pairs_impl(double *__restrict__ L, c
             for (int n = 0; n < COUT; ++n) {
                 s0[n] = f[0].x * t0[n];
 #pragma unroll
-                for (int x = 1; x < 4; ++x) s0[n] += f[x].x * t0[n + COUT * x];
+                for (int x = 1; x < 4; ++x) s0[n] = __builtin_fma(f[x].x, t0[n + COUT * x], s0[n]);
             }
             const double2 *__restrict__ Tq = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts + par_ts));
 #pragma unroll
@@ -414,7 +414,7 @@ __device__ __forceinline__ void sweep_fiber_pairs_impl(double *__restrict__ L, c
             for (int n = 0; n < COUT; ++n) {
                 s1[n] = f[0].y * t0[n];
 #pragma unroll
-                for (int x = 1; x < 4; ++x) s1[n] += f[x].y * t0[n + COUT * x];
+                for (int x = 1; x < 4; ++x) s1[n] = __builtin_fma(f[x].y, t0[n + COUT * x], s1[n]);
             }
 #pragma unroll
             for (int n = 0; n < COUT; ++n) Lp[n * (SX / 2)] = make_double2(s0[n], s1[n]);
@@ -424,8 +424,8 @@ __device__ __forceinline__ void sweep_fiber_pairs_impl(double *__restrict__ L, c
                 double s0 = f[0].x * t0[n], s1 = f[0].y * t0[n];
 #pragma unroll
                 for (int x = 1; x < 4; ++x) {
-                    s0 += f[x].x * t0[n + COUT * x];
-                    s1 += f[x].y * t0[n + COUT * x];
+                    s0 = __builtin_fma(f[x].x, t0[n + COUT * x], s0);
+                    s1 = __builtin_fma(f[x].y, t0[n + COUT * x], s1);
                 }
                 Lp[n * (SX / 2)] = make_double2(s0, s1);
             }
@@ -504,7 +504,7 @@ __device__ __forceinline__ void sweep_last_stage_out(const double *__restrict__ 
         for (int n = 0; n < 4; ++n) {
             s0[n] = f[l][0].x * t0[n];
 #pragma unroll
-            for (int x = 1; x < 4; ++x) s0[n] += f[l][x].x * t0[n + 4 * x];
+            for (int x = 1; x < 4; ++x) s0[n] = __builtin_fma(f[l][x].x, t0[n + 4 * x], s0[n]);
         }
         if constexpr (PAR) {
             const double2 *__restrict__ Tq = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts + par_ts));
@@ -515,7 +515,7 @@ __device__ __forceinline__ void sweep_last_stage_out(const double *__restrict__ 
         for (int n = 0; n < 4; ++n) {
             s1v[n] = f[l][0].y * t0[n];
 #pragma unroll
-            for (int x = 1; x < 4; ++x) s1v[n] += f[l][x].y * t0[n + 4 * x];
+            for (int x = 1; x < 4; ++x) s1v[n] = __builtin_fma(f[l][x].y, t0[n + 4 * x], s1v[n]);
         }
         // output cell: digits as in LDS (identity), r slowest: c = n + c_hi + (l << 2 loop) + 4^K r
         double *__restrict__ o0 = ot + (c_hi + (l << (2 * G.loop)) + ((2 * rp) << (2 * K)));
