@@ -208,6 +208,16 @@ int mibn_gibbs_shard(mibn_t *h, int32_t n_q, const int32_t *q_vars, int32_t n_e,
                      const int32_t *e_codes, const int32_t *cycle, int64_t chain_first, int64_t n_chains,
                      int64_t n_iterations, uint64_t seed, int64_t *counts);
 
+/* Parity hook for the deterministic half of the Gibbs path (tests): the Markov-blanket conditionals the chain samples from,
+ * bayes_net.py:699-710 - pointwise_mul of the CPTs of a node and its children, normalised per boundary configuration.  For each
+ * of n_rows full joint states (states[row * n_vars + v] = label code; evidence entries are overwritten by e_codes) out[row *
+ * card(var) + x] = P(var = x | the rest of the row), computed by gibbs_kernel ITSELF: the same update programs, the same
+ * LDS-resident tables and the same one of its three update forms a mibn_gibbs call with this network / evidence / cycle and
+ * n_rows chains takes - the weights are written out, normalised, where the chain would draw from them.  Only the random
+ * stream of the Gibbs path stays unpinned (the reference's depends on the absent third-party `vose` sampler). */
+int mibn_gibbs_conditional(mibn_t *h, int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle,
+                           int32_t var, int64_t n_rows, const uint8_t *states, double *out);
+
 /*
  * Forward (ancestral) sampling and the two approximate algorithms built on it.
  *   mibn_sample          BayesNet.sample(n, init) / _forward_sample (bayes_net.py:518-575): n_samples joint samples,

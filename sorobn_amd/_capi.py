@@ -20,7 +20,7 @@ SYMBOLS = [
     "mibn_total_kernel_stats", "mibn_sample", "mibn_sampling_query", "mibn_count_tables",
     "mibn_query_batch_ex", "mibn_plan_order", "mibn_estimate_costs", "mibn_device_synchronize", "mibn_gibbs_shard",
     "mibn_comm_unique_id", "mibn_comm_init", "mibn_comm_destroy", "mibn_comm_allgather_f64",
-    "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier",
+    "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier", "mibn_gibbs_conditional",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -79,6 +79,7 @@ def lib():
         L.mibn_device_synchronize.argtypes = [vp]
         L.mibn_gibbs_shard.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, i32p, i32p, C.c_int64, C.c_int64,
                                        C.c_int64, C.c_uint64, i64p]
+        L.mibn_gibbs_conditional.argtypes = [vp, C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int64, C.POINTER(C.c_uint8), f64p]
         L.mibn_comm_unique_id.argtypes = [vp, C.c_char_p]
         L.mibn_comm_init.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p]
         L.mibn_comm_destroy.argtypes = [vp]
@@ -301,6 +302,21 @@ class Engine:
                                              int(n_iterations), int(seed) & (2**64 - 1),
                                              _p(counts, C.c_int64)))
         return counts
+
+    def gibbs_conditional(self, var, states, evars=(), ecodes=(), cycle=None):
+        """P(var = x | the rest of each row of `states` [n_rows, n_vars]) as the Gibbs kernel computes it (mibn_gibbs_conditional)."""
+        e, c = _i32(evars), _i32(ecodes)
+        e_ = e if len(e) else np.zeros(1, np.int32)
+        c_ = c if len(c) else np.zeros(1, np.int32)
+        st = np.ascontiguousarray(states, np.uint8).reshape(-1, len(self.card))
+        out = np.zeros((len(st), int(self.card[var])), np.float64)
+        cyc = None
+        if cycle is not None:
+            cyc_arr = _i32(cycle)
+            cyc = _p(cyc_arr, C.c_int32)
+        self._check(self._L.mibn_gibbs_conditional(self._h, len(e), _p(e_, C.c_int32), _p(c_, C.c_int32), cyc, int(var), len(st),
+                                                   st.ctypes.data_as(C.POINTER(C.c_uint8)), _p(out, C.c_double)))
+        return out
 
     # ---- shard balancing / multi-GPU (SURVEY.md section 8e) ------------------------------------------------------
     def estimate_costs(self, qvars, evars):

@@ -1162,6 +1162,23 @@ extern "C" int mibn_gibbs_shard(mibn_t *h, int32_t n_q, const int32_t *q_vars, i
                      n_iterations, seed, counts, h->err, h->stats.kernel_ms);
 }
 
+extern "C" int mibn_gibbs_conditional(mibn_t *h, int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle,
+                                      int32_t var, int64_t n_rows, const uint8_t *states, double *out) {
+    if (!h || n_rows < 0 || (n_rows && (!states || !out)) || (n_e && (!e_vars || !e_codes))) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    if (var < 0 || var >= h->net.n_vars) { h->err = "gibbs conditional: unknown variable"; return MIBN_E_ARG; }
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int v = 0; v < h->net.n_vars; ++v)
+            if (states[r * h->net.n_vars + v] >= h->net.card[v]) { h->err = "gibbs conditional: a state code is outside its variable's domain"; return MIBN_E_ARG; }
+    if (n_rows == 0) return MIBN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int32_t q0 = var;  // (the histogram of the ordinary launch: one variable, unused)
+    double ms = 0;
+    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds != 0, 1, &q0, n_e, e_vars, e_codes, cycle, 0, n_rows, 1, 0, nullptr, h->err, ms,
+                     var, states, out);
+}
+
 extern "C" int mibn_sample(mibn_t *h, int64_t n_samples, int32_t n_init, const int32_t *init_vars, const int32_t *init_codes,
                            uint64_t seed, uint8_t *states) {
     if (!h || n_samples < 0 || !states || (n_init && (!init_vars || !init_codes))) return MIBN_E_ARG;

@@ -69,6 +69,11 @@ struct GibbsArgs {
     int64_t n_chains, n_iterations;
     int64_t chain_first;          // global index of this launch's first chain (shards of one stream: mibn_gibbs_shard)
     uint64_t seed;
+    // COND (mibn_gibbs_conditional, a parity hook): the rows' states come from the caller, ONE update of cycle position cond_pos is
+    // evaluated and its normalised weights are written instead of a draw
+    const uint8_t *cond_states;   // [n_chains][n_vars] codes
+    double *cond_out;             // [n_chains][card of the variable]
+    int32_t cond_pos;
 };
 
 constexpr int kGibbsWaves = 1;  // waves per workgroup (each wave = 64 independent chains)
@@ -106,7 +111,9 @@ __device__ __forceinline__ double gibbs_weight(const GibbsArgs &A, PoolPtr pool,
 // FAST (with POOL_LDS and PROG_LDS; every variable of the cycle has at most 8 states, 4 factors and factors with at most
 // two other variables - grids): fixed-size update records, so that the state reads of all factors, then all their table
 // reads, are issued together instead of factor after factor - the update is a handful of dependent LDS round trips.
-template <bool POOL_LDS, bool PROG_LDS, bool FAST = false>
+// COND: the parity hook of mibn_gibbs_conditional - the same set-up, the same weight computation of whichever of the three
+// update forms this launch takes, the weights written out (normalised) where the chain would draw from them.
+template <bool POOL_LDS, bool PROG_LDS, bool FAST = false, bool COND = false>
 __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -140,7 +147,9 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
     for (int v = 0; v < A.n_vars; ++v) {
         const GibbsVar V = A.vars[v];
         int val = V.ev_code;
-        if (!V.is_evidence) {
+        if (COND) {
+            if (!V.is_evidence) val = active ? (int)A.cond_states[local * A.n_vars + v] : 0;
+        } else if (!V.is_evidence) {
             int off = V.table_off;
             for (int k = 0; k + 1 < V.scope_len; ++k)
                 off += (int)st[A.scope_var[V.scope_begin + k] * 64 + lane] * A.scope_stride[V.scope_begin + k];
@@ -160,15 +169,15 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
 
     int qv4[4] = {0, 0, 0, 0}, qs4[4] = {0, 0, 0, 0};  // (unused slots: variable 0 with stride 0)
     for (int q = 0; q < 4 && q < A.n_q; ++q) { qv4[q] = A.qvars[q]; qs4[q] = A.qstride[q]; }
-    int cyc = 0;
+    int cyc = COND ? A.cond_pos : 0;
     constexpr int kRegCard = 16;
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
     i32x4 cur[kFastWords / 4];  // FAST: the update record of this iteration, loaded one iteration ahead
     if (FAST) {
 #pragma unroll
-        for (int q = 0; q < kFastWords / 4; ++q) cur[q] = reinterpret_cast<const i32x4 *>(lds_prog)[q];
+        for (int q = 0; q < kFastWords / 4; ++q) cur[q] = reinterpret_cast<const i32x4 *>(lds_prog + cyc * kFastWords)[q];
     }
-    for (int64_t it = 0; it < A.n_iterations; ++it) {
+    for (int64_t it = 0; it < (COND ? 1 : A.n_iterations); ++it) {
         int v, card, nf = 0;
         const int32_t *up = nullptr;
         i32x4 rec[kFastWords / 4];
@@ -217,7 +226,13 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
 #pragma unroll
             for (int x = 0; x < 8; ++x)
                 if (x < card) total += w[x];
-            if (total > 0) {
+            if constexpr (COND) {
+                if (active) {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        if (x < card) A.cond_out[local * card + x] = total > 0 ? w[x] / total : 0.0;
+                }
+            } else if (total > 0) {
                 const double u = u01 * total;
                 double acc = 0;
                 int val = -1, last = 0;
@@ -252,7 +267,13 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
 #pragma unroll
             for (int x = 0; x < kRegCard; ++x)
                 if (x < card) total += w[x];
-            if (total > 0) {
+            if constexpr (COND) {
+                if (active) {
+#pragma unroll
+                    for (int x = 0; x < kRegCard; ++x)
+                        if (x < card) A.cond_out[local * card + x] = total > 0 ? w[x] / total : 0.0;
+                }
+            } else if (total > 0) {
                 const double u = philox_uniform((uint64_t)it, 0u, k0, k1) * total;
                 double acc = 0;
                 int val = -1, last = 0;
@@ -269,7 +290,13 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
             const GibbsVar V = A.vars[v];
             double total = 0;
             for (int x = 0; x < V.card; ++x) total += POOL_LDS ? gibbs_weight(A, lds_pool, V, v, x, st, lane) : gibbs_weight(A, A.pool, V, v, x, st, lane);
-            if (total > 0) {
+            if constexpr (COND) {
+                if (active)
+                    for (int x = 0; x < V.card; ++x) {
+                        const double w = POOL_LDS ? gibbs_weight(A, lds_pool, V, v, x, st, lane) : gibbs_weight(A, A.pool, V, v, x, st, lane);
+                        A.cond_out[local * V.card + x] = total > 0 ? w / total : 0.0;
+                    }
+            } else if (total > 0) {
                 const double u = philox_uniform((uint64_t)it, 0u, k0, k1) * total;
                 double acc = 0;
                 int val = -1, last = 0;
@@ -283,7 +310,7 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
             }
         }
         // record the joint query state (bayes_net.py:732-733: every iteration, no burn-in)
-        if (active) {
+        if (!COND && active) {
             int cell = 0;
             if (A.n_q <= 4) {  // the usual case: query variables and strides preloaded (no global loads in the loop)
 #pragma unroll
@@ -308,9 +335,11 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
 }
 
 // host driver; returns MIBN_* code
+// cond_var >= 0 (mibn_gibbs_conditional): n_chains rows of cond_states, the conditional of cond_var into cond_out
 inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t stream, bool allow_lds, int32_t n_q, const int32_t *q_vars,
                      int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle_in, int64_t chain_first,
-                     int64_t n_chains, int64_t n_iterations, uint64_t seed, int64_t *counts, std::string &err, double &kernel_ms) {
+                     int64_t n_chains, int64_t n_iterations, uint64_t seed, int64_t *counts, std::string &err, double &kernel_ms,
+                     int32_t cond_var = -1, const uint8_t *cond_states = nullptr, double *cond_out = nullptr) {
     const int n = net.n_vars;
     std::vector<GibbsVar> vars(n);
     std::vector<int32_t> scope_var, scope_stride, children, cycle;
@@ -353,6 +382,12 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
             if (!vars[v].is_evidence) cycle.push_back(v);
     }
     if (cycle.empty()) { err = "gibbs: every variable is evidence"; return MIBN_E_ARG; }
+    int cond_pos = -1;
+    if (cond_var >= 0) {
+        for (size_t i = 0; i < cycle.size(); ++i)
+            if (cycle[i] == cond_var) cond_pos = (int)i;
+        if (cond_pos < 0) { err = "gibbs conditional: the variable is evidence or unknown"; return MIBN_E_ARG; }
+    }
     // update programs, one per cycle position
     std::vector<int32_t> uprog, uprog_off;
     for (int v : cycle) {
@@ -425,12 +460,14 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     GibbsVar *d_vars = nullptr;
     int32_t *d_i32 = nullptr;
     unsigned long long *d_counts = nullptr;
+    uint8_t *d_cond_states = nullptr;
+    double *d_cond_out = nullptr;
     std::vector<int32_t> pack;
     auto put = [&](const std::vector<int32_t> &a) { size_t o = pack.size(); pack.insert(pack.end(), a.begin(), a.end()); return o; };
     const size_t o_sv = put(scope_var), o_ss = put(scope_stride), o_ch = put(children), o_cy = put(cycle);
     const size_t o_q = put(std::vector<int32_t>(q_vars, q_vars + n_q)), o_qs = put(qstride);
     const size_t o_up = put(uprog), o_uo = put(uprog_off);
-    auto fail = [&](hipError_t e) { err = std::string("gibbs: ") + hipGetErrorString(e); hipFree(d_vars); hipFree(d_i32); hipFree(d_counts); return MIBN_E_HIP; };
+    auto fail = [&](hipError_t e) { err = std::string("gibbs: ") + hipGetErrorString(e); hipFree(d_vars); hipFree(d_i32); hipFree(d_counts); hipFree(d_cond_states); hipFree(d_cond_out); return MIBN_E_HIP; };
     hipError_t e;
     if ((e = hipMalloc(&d_vars, sizeof(GibbsVar) * n)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&d_i32, 4 * std::max<size_t>(1, pack.size()))) != hipSuccess) return fail(e);
@@ -461,6 +498,18 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     A.chain_first = chain_first;
     A.n_iterations = n_iterations;
     A.seed = seed;
+    A.cond_states = nullptr;
+    A.cond_out = nullptr;
+    A.cond_pos = 0;
+    const size_t cond_cells = cond_var >= 0 ? (size_t)n_chains * (size_t)net.card[cond_var] : 0;
+    if (cond_var >= 0) {
+        if ((e = hipMalloc(&d_cond_states, std::max<size_t>(1, (size_t)n_chains * n))) != hipSuccess) return fail(e);
+        if ((e = hipMalloc(&d_cond_out, 8 * std::max<size_t>(1, cond_cells))) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(d_cond_states, cond_states, (size_t)n_chains * n, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+        A.cond_states = d_cond_states;
+        A.cond_out = d_cond_out;
+        A.cond_pos = cond_pos;
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -468,6 +517,10 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     auto kernel = fast ? gibbs_kernel<true, true, true>
                        : pool_lds ? (prog_lds ? gibbs_kernel<true, true> : gibbs_kernel<true, false>)
                                   : (prog_lds ? gibbs_kernel<false, true> : gibbs_kernel<false, false>);
+    if (cond_var >= 0)  // the same form, writing the weights instead of drawing from them
+        kernel = fast ? gibbs_kernel<true, true, true, true>
+                      : pool_lds ? (prog_lds ? gibbs_kernel<true, true, false, true> : gibbs_kernel<true, false, false, true>)
+                                 : (prog_lds ? gibbs_kernel<false, true, false, true> : gibbs_kernel<false, false, false, true>);
     if (lds > 64 * 1024) {
         if ((e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return fail(e);
     }
@@ -483,7 +536,13 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     kernel_ms = ms;
     hipEventDestroy(e0);
     hipEventDestroy(e1);
-    for (int64_t i = 0; i < cells; ++i) counts[i] = (int64_t)hc[(size_t)i];
+    if (counts)
+        for (int64_t i = 0; i < cells; ++i) counts[i] = (int64_t)hc[(size_t)i];
+    if (cond_var >= 0) {
+        if ((e = hipMemcpy(cond_out, d_cond_out, 8 * cond_cells, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e);
+        hipFree(d_cond_states);
+        hipFree(d_cond_out);
+    }
     hipFree(d_vars);
     hipFree(d_i32);
     hipFree(d_counts);

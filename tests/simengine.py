@@ -117,6 +117,15 @@ class SimEngine:
         self.last_stats = stats
         return out.reshape(B, -1)
 
+    def gibbs(self, qvars, evars, ecodes, n_chains, n_iterations, seed=0, cycle=None, chain_first=0):
+        """STAND-IN (no chain on the CPU): the exact posterior scaled to counts, so that the host side of the Gibbs path -
+        `accelerate`'s rebind, Backend.gibbs_sampling, the Series construction - runs in the GPU-less container."""
+        exact = self._one(np.asarray(qvars, np.int32), np.asarray(evars, np.int32), np.asarray(ecodes, np.int32))
+        total = int(n_chains) * int(n_iterations)
+        counts = np.floor(exact * total).astype(np.int64)
+        counts[int(np.argmax(exact))] += total - int(counts.sum())
+        return counts
+
     def set_option(self, name, value):
         if name == "prune":
             self.prune = int(value)

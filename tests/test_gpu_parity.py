@@ -38,6 +38,69 @@ def _check_requests(bn, requests, ctx):
     return worst
 
 
+def test_tiny_kernel_with_non_topological_ids(amd):
+    """mibn_set_network accepts ANY acyclic numbering of the variables (include/mibn.h); the small-network kernel enumerates the
+    hidden states with running prefix products and must therefore walk the variables parents-first whatever their ids
+    (round 2 walked them in id order: wrong posteriors when a parent carried a larger id than its child - ADVICE r2).
+    Asia and three sparse random DAGs through the raw C-ABI with randomly permuted ids: the tiny kernel against the
+    planner path and against the answers with the original numbering."""
+    from sorobn_amd import _capi
+    from sorobn_amd.flatten import flatten
+    nets = [n for n in gu.load("examples.json") if n["spec"]["name"] == "asia"] + gu.load("random_dags.json")
+    rng = np.random.default_rng(8)
+    n_done = 0
+    for net in nets:
+        f = flatten(netspec.build(net["spec"], amd.BayesNet))
+        n = len(f.card)
+        if n > 32 or len(f.values) > 4096 or float(np.prod(f.card.astype(np.float64))) > 65536 or n_done >= 5:
+            continue  # (not a network of the small-network kernel: csrc/tiny_kernel.hip.h tiny_eligible)
+        n_done += 1
+        perm = rng.permutation(n).astype(np.int32)  # new id of variable v
+        assert any(perm[u] > perm[v] for v in range(n) for u in f.scope_vars[f.scope_off[v]:f.scope_off[v + 1] - 1]) or n < 3
+        inv = np.argsort(perm)
+        card = f.card[inv]
+        scopes = [perm[f.scope_vars[f.scope_off[v]:f.scope_off[v + 1]]] for v in inv]
+        vals = [f.values[f.value_off[v]:f.value_off[v + 1]] for v in inv]
+        scope_off = np.concatenate([[0], np.cumsum([len(x) for x in scopes])]).astype(np.int64)
+        value_off = np.concatenate([[0], np.cumsum([len(x) for x in vals])]).astype(np.int64)
+        engines = []
+        for ids in ("original", "permuted"):
+            e = _capi.Engine(0)
+            if ids == "original":
+                e.set_network(f.card, f.scope_off, f.scope_vars, f.value_off, f.values)
+            else:
+                e.set_network(card, scope_off, np.concatenate(scopes).astype(np.int32), value_off, np.concatenate(vals))
+            engines.append(e)
+        B = 400
+        qv = rng.integers(0, n, size=B)
+        ne = rng.integers(0, 3, size=B)
+        evs = [rng.choice([v for v in range(n) if v != qv[b]], size=ne[b], replace=False) for b in range(B)]
+        ecs = [[int(rng.integers(0, f.card[v])) for v in evs[b]] for b in range(B)]
+        q_off = np.arange(B + 1, dtype=np.int64)
+        e_off = np.concatenate([[0], np.cumsum(ne)]).astype(np.int64)
+        flat_e = np.array([v for ev in evs for v in ev], np.int32)
+        flat_c = np.array([c for ec in ecs for c in ec], np.int32)
+        base, off = engines[0].query_batch(q_off, qv.astype(np.int32), e_off, flat_e, flat_c)
+        assert [k["name"] for k in engines[0].kernel_stats()] == ["tiny_kernel"]
+        tiny, off2 = engines[1].query_batch(q_off, perm[qv], e_off, perm[flat_e] if len(flat_e) else flat_e, flat_c)
+        assert [k["name"] for k in engines[1].kernel_stats()] == ["tiny_kernel"]
+        engines[1].set_option("tiny", 0)
+        planned, _ = engines[1].query_batch(q_off, perm[qv], e_off, perm[flat_e] if len(flat_e) else flat_e, flat_c)
+        assert not any(k["name"] == "tiny_kernel" for k in engines[1].kernel_stats())
+        assert np.array_equal(off, off2)
+        assert float(np.max(np.abs(tiny - base))) <= 1e-12, net["spec"]["name"]
+        assert float(np.max(np.abs(tiny - planned))) <= 1e-12, net["spec"]["name"]
+        # the engine-wide option prune = 0 reaches the small-network kernel too (ADVICE r2): every CPT takes part
+        engines[0].set_option("prune", 0)
+        a, _ = engines[0].query_batch(q_off, qv.astype(np.int32), e_off, flat_e, flat_c)
+        engines[0].set_option("tiny", 0)
+        b, _ = engines[0].query_batch(q_off, qv.astype(np.int32), e_off, flat_e, flat_c)
+        assert float(np.max(np.abs(a - b))) <= 1e-12
+        for e in engines:
+            e.close()
+    assert n_done >= 3
+
+
 # small_cells < 1024 forces the FIBER (streaming) step form, normally reserved for > 8 KiB tables, onto the
 # small golden networks: mixed cardinalities, sparse CPTs, every (n_big, cx, NC) kernel specialisation
 # (big_iters, tile_h) below the defaults (4096, auto) turn small steps into tiled levels, so the tile kernels
@@ -175,6 +238,32 @@ def test_c3_chain_form_vs_pair_form(amd):
             b.backend.engine.set_option("big_iters", tiling[0])
             b.backend.engine.set_option("tile_h", tiling[1])
             _check_requests(b, e["requests"], sp["name"] + " chain")
+
+
+def test_arena_budget_exceeded_path(amd):
+    """Option arena_gb below what a chunk needs: the chunk is cut into waves of consecutive requests whose private arenas fit
+    the budget together (same posteriors bit for bit, more launches); a budget below ONE request's arena is a clean
+    MIBN_E_NOMEM with the reference-style message, not a device OOM."""
+    from sorobn_amd import _capi
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 256, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    base = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    launches = be.engine.stats()["n_launches"]
+    need = be.engine.stats()["arena_bytes"]
+    be.engine.set_option("arena_gb", need / 8 / 1e9)  # an eighth of what the chunk took
+    got = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert np.array_equal(got, base)
+    assert be.engine.stats()["n_launches"] > 2 * launches
+    assert be.engine.stats()["arena_bytes"] <= need / 8 * 1.34 + 4096  # (the allocation grows with a third of headroom)
+    be.engine.set_option("arena_gb", 1e-4)  # 100 KB: below a single request's arena
+    with pytest.raises(_capi.MibnError) as err:
+        be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert err.value.code == _capi.E_NOMEM and "above the arena budget" in str(err.value)
+    be.engine.set_option("arena_gb", 180.0)
+    assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base)  # the context is still usable
 
 
 def test_sweep_kernels_agree_bit_for_bit(amd):
@@ -560,6 +649,118 @@ def test_accelerate_live_reference_object_on_the_gpu(amd):
     if not refload.available():
         pytest.skip("oracle/_ref was not built (make -C oracle _ref where /root/reference is mounted)")
     check_accelerated_reference_object(refload.load(), None)
+
+
+def test_accelerate_gibbs_rebind_on_the_gpu(amd):
+    """`accelerate(ref_bn)` also rebinds `_gibbs_sampling` (the seam bayes_net.py:851-853): the reference's own
+    query(..., algorithm="gibbs") on a live reference object runs the HIP chain and post-processes it (869-875)."""
+    from oracle import refload
+    from test_host_logic import check_accelerated_gibbs
+    if not refload.available():
+        pytest.skip("oracle/_ref was not built (make -C oracle _ref where /root/reference is mounted)")
+    check_accelerated_gibbs(refload.load(), None, n_iterations=400_000, tol=0.02)
+
+
+def test_c2_stream_vs_reference(amd):
+    """BASELINE config 2: the first 2 000 requests of the Asia stream `bench.py` times (netspec.asia_requests, seed 0) through
+    the batched C-ABI - the small-network kernel - against the unmodified reference's BayesNet.query (oracle/_ref): values
+    within 1e-9 and the zero-probability requests - where the reference returns an EMPTY Series (bayes_net.py:254-255, 790) -
+    exactly the requests whose dense posterior is all zero."""
+    from oracle import refload
+    if not refload.available():
+        pytest.skip("oracle/_ref was not built (make -C oracle _ref where /root/reference is mounted)")
+    ref_mod = refload.load()
+    ref = ref_mod.examples.asia()
+    bn = netspec.build(netspec.dump(ref, "asia"), amd.BayesNet)
+    be = bn.backend
+    reqs = netspec.asia_requests(list(bn.nodes), 2000, seed=0)
+    q_off = np.arange(len(reqs) + 1, dtype=np.int64)
+    q_vars = np.array([be.flat.id[q] for q, _ in reqs], np.int32)
+    e_off = np.concatenate([[0], np.cumsum([len(e) for _, e in reqs])]).astype(np.int64)
+    e_vars = np.array([be.flat.id[k] for _, e in reqs for k in e], np.int32)
+    e_codes = np.array([be.flat.code_of(be.flat.id[k], v) for _, e in reqs for k, v in e.items()], np.int32)
+    post, off = be.engine.query_batch(q_off, q_vars, e_off, e_vars, e_codes)
+    assert [k["name"] for k in be.engine.kernel_stats()] == ["tiny_kernel"]
+    n_empty, worst = 0, 0.0
+    for i, (q, ev) in enumerate(reqs):
+        want = ref.query(q, event=ev)
+        dense = post[off[i]:off[i + 1]]
+        if len(want) == 0:
+            n_empty += 1
+            assert not dense.any(), (i, q, ev, dense)  # zero-probability evidence: all zeros <-> the reference's empty Series
+            continue
+        assert dense.sum() > 0, (i, q, ev)
+        labels = be.flat.dom_index[be.flat.id[q]]
+        got = {lab: dense[c] for c, lab in enumerate(labels) if dense[c] > 0}
+        assert set(got) == set(want.index), (i, q, ev)  # rows of probability 0 are absent from the reference's answer
+        worst = max(worst, max(abs(got[lab] - want[lab]) for lab in want.index))
+        # ... and the pandas object the product API returns is the reference's
+        if i < 200:
+            pd.testing.assert_series_equal(bn.query(q, event=ev), want, rtol=0, atol=1e-9, check_exact=False)
+    assert worst <= 1e-9, worst
+    assert n_empty > 0  # (the stream contains TB-or-cancer contradictions: 2.4 % of it)
+
+
+def _reference_conditionals(ref_mod, bn, node, fast_normalise=False):
+    """P(node | Markov boundary) the way bayes_net.py:699-710 builds it: the reference's own pointwise_mul over the CPTs of
+    the node and its children, normalised per boundary configuration, levels [*boundary, node].  `fast_normalise`: the same
+    g / g.sum() through groupby().transform (the reference's apply-per-group takes minutes on 8^6 groups)."""
+    from sorobn.bayes_net import pointwise_mul
+    post = pointwise_mul(bn.P[n] for n in [node, *bn.children.get(node, [])])
+    boundary = bn.markov_boundary(node)
+    if boundary:
+        if fast_normalise:
+            post = post / post.groupby(boundary).transform("sum")
+        else:
+            post = post.groupby(boundary, group_keys=False).apply(lambda g: g / g.sum())
+        post = post.reorder_levels([*boundary, node])
+    return post.sort_index(), boundary
+
+
+def test_gibbs_conditionals_vs_reference(amd):
+    """The deterministic half of the Gibbs path, pinned (SURVEY 8c left the whole path "parity unpinned" because of the
+    random stream): `mibn_gibbs_conditional` makes gibbs_kernel write the Markov-blanket conditional it would sample from,
+    and that is compared <= 1e-12 with the tables the reference builds from its own factor algebra (bayes_net.py:699-710,
+    markov_boundary 1034-1039) - on the four example networks (incl. the zero rows of Asia) with and without evidence,
+    and on a 3x3 grid with 8 states (the FAST update form of config 5; its centre node has the maximal boundary of six)."""
+    from oracle import refload
+    if not refload.available():
+        pytest.skip("oracle/_ref was not built (make -C oracle _ref where /root/reference is mounted)")
+    ref_mod = refload.load()
+    rng = np.random.default_rng(3)
+    nets = [(mk, getattr(ref_mod.examples, mk)()) for mk in ("alarm", "asia", "sprinkler", "grades")]
+    nets.append(("grid3x3k8", netspec.build(netspec.grid_spec(3, 3, 8, seed=2), ref_mod.BayesNet)))
+    worst, n_checked, n_zero = 0.0, 0, 0
+    for mk, ref in nets:
+        bn = netspec.build(netspec.dump(ref, mk), amd.BayesNet)
+        be = bn.backend
+        f = be.flat
+        n = len(f.card)
+        for with_event in ((False, True) if not mk.startswith("grid") else (False,)):
+            ev_ids = [int(v) for v in rng.choice(n, size=min(2, n - 2), replace=False)] if with_event else []
+            ev_codes = [int(rng.integers(0, f.card[v])) for v in ev_ids]
+            states = np.stack([rng.integers(0, f.card[v], size=256) for v in range(n)], axis=1).astype(np.uint8)
+            for v, c in zip(ev_ids, ev_codes):
+                states[:, v] = c
+            free = [v for v in range(n) if v not in ev_ids]
+            cycle = sorted(free, key=lambda v: str(f.names[v]))
+            for v in free:
+                node = f.names[v]
+                table, boundary = _reference_conditionals(ref_mod, ref, node, fast_normalise=len(ref.markov_boundary(node)) > 4)
+                got = be.engine.gibbs_conditional(v, states, ev_ids, ev_codes, cycle=cycle)
+                lookup = table.to_dict()
+                labels = list(f.dom_index[v])
+                for r in range(len(states)):
+                    cond = tuple(f.dom_index[f.id[b]][states[r, f.id[b]]] for b in boundary)
+                    want = np.array([lookup.get((*cond, lab) if boundary else lab, 0.0) for lab in labels])
+                    if want.sum() == 0:  # a boundary configuration of probability zero: no row in the reference, no draw here
+                        n_zero += 1
+                        assert not got[r].any(), (mk, node, cond)
+                        continue
+                    worst = max(worst, float(np.max(np.abs(got[r] - want))))
+                    n_checked += 1
+    assert worst <= 1e-12, worst
+    assert n_checked > 5000 and n_zero > 0, (n_checked, n_zero)
 
 
 def test_gibbs_chain_shards_reproduce_the_whole(amd):

@@ -672,6 +672,43 @@ def check_accelerated_reference_object(ref_mod, backend_factory):
     assert calls["n"] >= 160
 
 
+def check_accelerated_gibbs(ref_mod, backend_factory, n_iterations, tol):
+    """`accelerate(ref_bn)._gibbs_sampling` (the seam bayes_net.py:851-853): the reference's own query(..., algorithm="gibbs")
+    on a live reference object must dispatch to the rebound method, name / index the answer like the exact path does
+    (869-875) and agree with the exact posterior within `tol` (one chain of n_iterations single-site updates)."""
+    calls = {"n": 0}
+    cases = [("sprinkler", ("Rain",), {"Sprinkler": True}), ("sprinkler", ("Wet grass", "Rain"), {"Cloudy": False}),
+             ("alarm", ("Alarm", "Earthquake"), {"John calls": True}), ("alarm", ("Burglary",), {"Mary calls": True})]
+    # (strictly positive networks only: on Asia's deterministic "TB or cancer" a single-site chain is not ergodic - in the
+    #  reference just as here)
+    for mk, q, ev in cases:
+        ref = getattr(ref_mod.examples, mk)()
+        acc = sorobn_amd.accelerate(getattr(ref_mod.examples, mk)(), backend_factory=backend_factory)
+        inner = acc._gibbs_sampling
+
+        def counted(*query, event, n_iterations, _inner=inner):
+            calls["n"] += 1
+            return _inner(*query, event=event, n_iterations=n_iterations)
+
+        acc._gibbs_sampling = counted
+        want = ref.query(*q, event=ev)
+        got = acc.query(*q, event=ev, algorithm="gibbs", n_iterations=n_iterations)
+        assert got.name == want.name and list(got.index.names) == list(want.index.names)
+        assert type(got.index) is type(want.index) and got.dtype == np.float64
+        assert abs(got.sum() - 1.0) < 1e-9
+        assert set(got.index) <= set(want.index), (mk, q)  # a state of probability zero is never visited
+        full = got.reindex(want.index, fill_value=0.0)
+        assert float(np.max(np.abs(full.to_numpy() - want.to_numpy()))) <= tol, (mk, q, full, want)
+    assert calls["n"] == len(cases)
+
+
+def test_accelerate_gibbs_rebind_dispatches():
+    """CPU twin of the GPU test: the rebind, the dispatch and the Series construction with a stand-in chain (the simulator's
+    `gibbs` returns the exact posterior as counts - it has no chain of its own; the chain itself is a device kernel)."""
+    ref_mod = _reference_or_skip()
+    check_accelerated_gibbs(ref_mod, simengine.sim_backend, n_iterations=100_000, tol=1e-4)
+
+
 def test_accelerate_live_reference_object_query_and_impute():
     ref_mod = _reference_or_skip()
     check_accelerated_reference_object(ref_mod, simengine.sim_backend)

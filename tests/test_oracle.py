@@ -139,3 +139,25 @@ def test_oracle_reproduces_reference_grid10x10():
     # the sparse CPU oracle is as slow as the reference on wide requests: keep the suite in minutes
     n = _check_net(gu.grid_spec_from_recipe(entry), entry["requests"], max_ref_seconds=1.0)
     assert n >= 10
+
+
+def test_oracle_reproduces_the_reference_on_the_c2_stream():
+    """BASELINE config 2 (the Asia stream of bench.py / netspec.asia_requests): the C oracle against the unmodified reference
+    on the first 400 requests - same rows (zero rows absent, empty answers for zero-probability evidence) and values."""
+    import netspec
+    from oracle import refload
+    if not refload.available():
+        pytest.skip("neither /root/reference nor oracle/_ref is present")
+    ref = refload.load().examples.asia()
+    on = orc.OracleNet(netspec.dump(ref, "asia"))
+    n_empty = 0
+    for q, ev in netspec.asia_requests(list(ref.nodes), 400, seed=0):
+        want = ref.query(q, event=ev)
+        names, labels, vals = on.query((q,), ev)
+        assert names == [q]
+        assert [lab[0] for lab in labels] == list(want.index), (q, ev)
+        if len(want):
+            assert float(np.max(np.abs(np.asarray(vals) - want.to_numpy()))) <= 1e-9
+        else:
+            n_empty += 1
+    assert n_empty > 0
