@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Benchmark of the exact-inference hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched one rank per GPU by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: `python bench.py --gpus N` spawns the N ranks itself (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE in the
+environment, the RCCL id through a private directory) - no PyTorch anywhere; launched by `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` (the driver's contract) the ranks torchrun started are used as they are.
 
 A "step" is one pass of the hot path over one batch of synthetic requests: `--batch` exact posterior queries per GPU
 (1 query node + 4 evidence nodes, the BASELINE C3 stream from default_rng(1)) on the synthetic 10x10 grid BN with 4
@@ -38,12 +42,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# HBM bytes per launch come from the rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE / WRITE_SIZE
-# runs, corrected as MI355X_MICROARCH.md prescribes): they cannot be collected inside this process, so the bench
-# reports the figure of the newest committed pass (profiles/r*_pmc.json) together with its provenance, or null.
+# HBM bytes per launch come from rocprofv3 PMC passes of this same command (separate --pmc FETCH_SIZE / WRITE_SIZE runs,
+# corrected as MI355X_MICROARCH.md prescribes and calibrated on known byte counts): they cannot be collected inside this
+# process, and an absolute figure of another session next to this run's algorithmic bytes means nothing (other requests per
+# launch) - so the line carries the RATIO traffic / algorithmic of the newest committed PMC session (profiles/r*_pmc.json,
+# written by tools/make_pmc_json.py), both sides measured in that session, with its provenance; `traffic` itself is null.
 
 
-def pmc_traffic(kernel):
+def pmc_ratio(kernel):
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
@@ -51,49 +57,34 @@ def pmc_traffic(kernel):
             d = json.load(open(f))
         except Exception:
             continue
-        if kernel in d.get("per_kernel", {}):  # (round 2 on: one entry per kernel of the exact path)
-            best = (f, d["per_kernel"][kernel])
-        elif d.get("kernel") == kernel:
-            best = (f, d)
+        k = d.get("per_kernel", {}).get(kernel)
+        if k and k.get("alg_bytes_per_launch_same_run"):
+            best = (f, k)
     if not best:
         return None, None
-    f, d = best
-    return d["traffic_bytes_per_launch"], {"file": os.path.relpath(f, ROOT), "alg_bytes_per_launch_same_run": d.get("alg_bytes_per_launch_same_run")}
+    f, k = best
+    return k["traffic_bytes_per_launch"] / k["alg_bytes_per_launch_same_run"], {
+        "file": os.path.relpath(f, ROOT), "session_traffic_bytes_per_launch": k["traffic_bytes_per_launch"],
+        "session_alg_bytes_per_launch": k["alg_bytes_per_launch_same_run"], "fetch_correction": k.get("fetch_correction")}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
 
-def cpu_reference(budget_s, n_procs, first=200, workload="c3"):
-    """The unmodified reference on this box's host cores (oracle/ref_worker.py): one process works through requests
-    0, 1, 2, ... of the stream (the single-core figure; the reference cannot use more than one core) while `n_procs`
-    more processes work through interleaved shards of the same first `first` requests (the aggregate).  No cost
-    filter; a request still running when the budget ends is abandoned and counted as unfinished.  Returns
-    (single, aggregate, answers {request index: (index rows, values)}) or None when oracle/_ref is unavailable."""
-    from oracle import refload
-    if not refload.available():
-        return None
+def _run_ref_workers(specs, wall_s):
+    """Spawn oracle/ref_worker.py once per entry of `specs` (argument lists), collect their JSON lines.  -> list of
+    (closing record with "times" and "answers", stderr tail) or None per worker that failed."""
     env = dict(os.environ, PYTHONHASHSEED="0", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     worker = os.path.join(ROOT, "oracle", "ref_worker.py")
-
-    def spawn(shard, nshards):
-        return subprocess.Popen([sys.executable, worker, "--workload", workload, "--first", str(first), "--shard", str(shard),
-                                 "--nshards", str(nshards), "--budget", str(budget_s)], env=env, stdout=subprocess.PIPE,
-                                stderr=subprocess.PIPE, text=True)
-
-    procs = [spawn(0, 1)] + [spawn(i, n_procs) for i in range(n_procs)]
-    outs = []
+    procs = [subprocess.Popen([sys.executable, worker, *map(str, sp)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for sp in specs]
+    out = []
     for p in procs:
         try:
-            so, se = p.communicate(timeout=budget_s + 120)
+            so, se = p.communicate(timeout=wall_s + 120)
         except subprocess.TimeoutExpired:
             p.kill()
             so, se = p.communicate()
-        outs.append((so, se, p.returncode))
-    answers = {}
-    summaries = []
-    for so, se, rc in outs:
-        done = None
-        times = []
+        done, times, answers = None, {}, {}
         for line in so.splitlines():
             try:
                 d = json.loads(line)
@@ -103,29 +94,67 @@ def cpu_reference(budget_s, n_procs, first=200, workload="c3"):
                 done = d
             elif "i" in d:
                 answers[d["i"]] = (d["index"], d["values"])
-                times.append(d["s"])
-        if done is None:
-            return {"error": f"reference worker failed (rc {rc}): {se[-400:]}"}, None, {}
-        done["times"] = times
-        summaries.append(done)
-    one = summaries[0]
-    single = {"value": one["finished"] / one["elapsed"] if one["elapsed"] > 0 else 0.0, "unit": "queries/s", "cores": 1,
-              "kind": "reference",
-              "sample": f"unmodified sorobn (oracle/_ref, loaded from '{one['reference']}'; BayesNet.query, pandas 2.3.3, PYTHONHASHSEED=0, "
-                        f"hash-ordered names => row-major elimination): requests 0..{one['attempted'] - 1} of the C3 stream (rng seed 1) in "
-                        f"stream order, NO cost filter, wall budget {budget_s:.0f} s: {one['finished']} finished, "
-                        f"{one['attempted'] - one['finished']} in flight at the end (abandoned, its time counted); median "
-                        f"{(float(np.median(one['times'])) if one['times'] else float('nan')):.2f} s per finished request",
-              "finished": one["finished"], "attempted": one["attempted"], "elapsed_s": one["elapsed"]}
-    agg = summaries[1:]
-    fin = sum(d["finished"] for d in agg)
-    att = sum(d["attempted"] for d in agg)
-    el = max(d["elapsed"] for d in agg) if agg else 0.0
-    aggregate = {"value": fin / el if el > 0 else 0.0, "unit": "queries/s", "processes": len(agg), "cores": len(agg),
-                 "finished": fin, "attempted": att, "elapsed_s": el,
-                 "sample": f"{len(agg)} independent reference processes over interleaved shards (i mod {len(agg)}) of the first {first} "
-                           f"requests of the same stream, same wall budget, running beside the single-process leg"}
+                times[d["i"]] = d["s"]
+        if done is not None:
+            done["times"], done["answers"] = times, answers
+        out.append((done, se[-400:]))
+    return out
+
+
+def cpu_reference(cap_s, n_req=16):
+    """The unmodified reference on this box's host cores (oracle/ref_worker.py), on a FIXED request set: requests 0 .. n_req - 1
+    of the C3 stream, one single-threaded process each (the reference cannot use more than one core), every request under
+    the same cap of `cap_s` seconds of wall time; a request that does not finish is abandoned and its cap counted.
+      single    the per-core rate: finished / sum of the per-request times - what ONE core does on this request set
+      aggregate finished / wall time of the n_req processes running side by side (cores = n_req)
+    Round 2 ran "whatever fits a 20 s budget" - three requests, +-50 % from run to run; the same sixteen requests every time
+    make the figure comparable between runs and boxes.  Returns (single, aggregate, answers) or None without oracle/_ref."""
+    from oracle import refload
+    if not refload.available():
+        return None
+    res = _run_ref_workers([["--workload", "c3", "--first", n_req, "--shard", i, "--nshards", n_req, "--budget", cap_s] for i in range(n_req)], cap_s)
+    if any(d is None for d, _ in res):
+        bad = next(se for d, se in res if d is None)
+        return {"error": f"reference worker failed: {bad}"}, None, {}
+    answers, secs = {}, []
+    for i, (d, _) in enumerate(res):
+        answers.update(d["answers"])
+        secs.append(d["times"].get(i))  # None: abandoned at the cap
+    fin = sum(t is not None for t in secs)
+    spent = sum(t if t is not None else cap_s for t in secs)
+    wall = max(d["elapsed"] for d, _ in res)
+    dist = ", ".join(f"{t:.1f}" if t is not None else f">{cap_s:.0f}" for t in secs)
+    single = {"value": fin / spent if spent > 0 else 0.0, "unit": "queries/s", "cores": 1, "kind": "reference",
+              "sample": f"unmodified sorobn (oracle/_ref, loaded from '{res[0][0]['reference']}'; BayesNet.query, pandas 2.3.3, PYTHONHASHSEED=0, "
+                        f"hash-ordered names => row-major elimination) on the FIXED request set 0..{n_req - 1} of the C3 stream (rng seed 1), "
+                        f"NO cost filter, one single-threaded process per request, cap {cap_s:.0f} s each: {fin} finished, {n_req - fin} abandoned "
+                        f"(cap counted); value = finished / sum of per-request seconds = the rate of ONE core; seconds per request: [{dist}]",
+              "finished": fin, "attempted": n_req, "core_seconds": spent, "seconds_per_request": secs, "cap_s": cap_s}
+    aggregate = {"value": fin / wall if wall > 0 else 0.0, "unit": "queries/s", "processes": n_req, "cores": n_req, "finished": fin,
+                 "attempted": n_req, "elapsed_s": wall,
+                 "sample": f"the same {n_req} processes side by side: finished / wall time ({n_req} cores; quota of this box: see host)"}
     return single, aggregate, answers
+
+
+def cpu_reference_small(budget_s=40.0, n=2000):
+    """C1 / C2 beside their GPU figures ("time all requests or a 2 000-request sample"): the reference's query() on
+    the alarm request of config 1, repeated, and on the first `n` requests of the Asia stream of config 2 - one process each,
+    side by side."""
+    from oracle import refload
+    if not refload.available():
+        return {}
+    res = _run_ref_workers([["--workload", w, "--first", n, "--shard", 0, "--nshards", 1, "--budget", budget_s] for w in ("c1", "c2")], budget_s)
+    out = {}
+    for w, (d, se) in zip(("c1", "c2"), res):
+        if d is None:
+            out[w] = {"error": se}
+            continue
+        out[w] = {"value": d["finished"] / d["elapsed"] if d["elapsed"] > 0 else 0.0, "unit": "queries/s", "cores": 1, "kind": "reference",
+                  "ms_per_query": 1e3 * d["elapsed"] / max(1, d["finished"]),
+                  "sample": f"unmodified sorobn (oracle/_ref): BayesNet.query on " +
+                            ("the config-1 request, repeated" if w == "c1" else "the first requests of the config-2 Asia stream (seed 0)") +
+                            f": {d['finished']} of {n} requests in {d['elapsed']:.1f} s (budget {budget_s:.0f} s), one core"}
+    return out
 
 
 def cpu_port(spec, qv, ev, ec, gpu_post, budget_s, max_rows=3e7):
@@ -164,7 +193,7 @@ def cpu_port(spec, qv, ev, ec, gpu_post, budget_s, max_rows=3e7):
 
 # ------------------------------------------------------------------------------------------------ other configs
 
-def other_configs(device):
+def other_configs(device, with_cpu=True):
     """C1 / C2 / C5 of BASELINE.json in this process (N = 1, after the C3 region)."""
     import golden_util as gu
     import netspec
@@ -217,6 +246,12 @@ def other_configs(device):
         out[f"C5_gibbs_{chains}_chains_x_100k"] = {"wall_ms": dt * 1e3, "updates_per_s": chains * 100_000 / dt,
                                                    "max_abs_err_vs_exact": float(np.max(np.abs(got - exact)))}
     out["C5_note"] = "latency/LDS-bound (CPTs resident in LDS), HBM roofline n/a; 128 chains = one GPU's share of config 5"
+    if with_cpu:
+        small = cpu_reference_small()
+        if "c1" in small:
+            out["C1_alarm_single_query"]["cpu_baseline"] = small["c1"]
+        if "c2" in small:
+            out["C2_asia_100k"]["cpu_baseline"] = small["c2"]
     return out
 
 
@@ -243,6 +278,45 @@ def make_comm(backend, world, rank, local_rank, engine):
     return sharding.TorchComm(), backend
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) with the environment a launcher
+    would give them - RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR / MASTER_PORT (only the gloo test hook opens
+    a socket on it) - plus a private directory and a nonce for the out-of-band RCCL id (sharding.exchange_id), wait for them,
+    and pass rank 0's line through.  No PyTorch: the ranks talk RCCL through the C-ABI (mibn_comm_*)."""
+    import secrets
+    import shutil
+    import socket
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    comm_dir = tempfile.mkdtemp(prefix="mibn_launch_")
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                MIBN_COMM_DIR=comm_dir, MIBN_LAUNCH_NONCE=secrets.token_hex(8), MIBN_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=dict(base, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(n)]
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:  # a rank died: the others would wait for it in a collective for ever
+                    rc = code
+                    for other in pending:
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(comm_dir, ignore_errors=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,8 +327,9 @@ def main():
     ap.add_argument("--n-evidence", type=int, default=4)
     ap.add_argument("--balance", default="count", choices=["count", "cost"],
                     help="split of a step's global batch over the ranks: equal counts, or equal planner cost estimates")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall budget of the reference leg of cpu_baseline")
-    ap.add_argument("--cpu-procs", type=int, default=8, help="reference processes of the aggregate figure")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="cap per request of the reference leg of cpu_baseline (wall seconds)")
+    ap.add_argument("--cpu-procs", type=int, default=16, help="size of the fixed request set of the reference leg (one process per request)")
+    ap.add_argument("--full-stream", action="store_true", help="after the stepped measurement: the whole 1 M-request C3 stream once, end to end")
     ap.add_argument("--port-seconds", type=float, default=6.0, help="wall budget of the C-port leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true")
@@ -269,9 +344,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        if world == 1 and a.gpus > 1 and not os.environ.get("MIBN_BENCH_CHILD"):
+            sys.exit(spawn_ranks(a.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher
         a.gpus = world
 
     # Transport of the final gather: "rccl" (default) = mibn_comm_* of the C-ABI, RCCL over xGMI, no PyTorch.
@@ -400,7 +474,8 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak",  # every rank processes --batch requests of its own per step, whatever N (BASELINE C4's fixed 1 M
+                                # requests are i.i.d.: N ranks finish them in 1 / (N x efficiency) of the time - the same curve)
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -425,7 +500,7 @@ def main():
                         for n, d in sorted(kagg.items(), key=lambda kv: -kv[1]["ms"])},
             "breakdown_ms_per_step": {k: agg[k] / a.steps for k in ("plan_ms", "h2d_ms", "kernel_ms", "d2h_ms", "total_ms")},
         }
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(dom)
+        out["roofline"]["traffic_over_alg"], out["roofline"]["traffic_source"] = pmc_ratio(dom)
         # the exact path has two kernels since round 2 (ve_level_kernel, ve_sweep_kernel) with about the same share of the
         # time: the same figures for each of them, so that the line does not depend on which one is ahead in this run
         out["roofline"]["per_kernel"] = {}
@@ -433,8 +508,32 @@ def main():
             la = max(1.0, d["launches"])
             gbps = d["alg_bytes"] / max(d["ms"], 1e-9) / 1e6
             out["roofline"]["per_kernel"][n] = {"achieved": gbps, "frac": gbps / HBM_PEAK_GBS, "alg_bytes_per_launch": d["alg_bytes"] / la,
-                                                "ms_per_launch": d["ms"] / la, "launches": la, "traffic": pmc_traffic(n)[0],
+                                                "ms_per_launch": d["ms"] / la, "launches": la, "traffic": None, "traffic_over_alg": pmc_ratio(n)[0],
                                                 "share_of_kernel_time": d["ms"] / agg["kernel_ms"]}
+        if a.full_stream and world == 1:
+            # BASELINE config 3 as written: the 1 M requests of the stream, once, end to end (pipelined batches of --batch
+            # requests like the stepped measurement above; request generation outside the clock, everything else inside)
+            n_full = 1_000_000
+            fq, fe, fc = netspec.c3_requests(100, 4, n_full, a.n_evidence, seed=1)
+            eng.synchronize()
+            t_full = time.perf_counter()
+            pending, n_done, checksum = None, 0, 0.0
+            for lo_ in range(0, n_full, a.batch):
+                hi_ = min(n_full, lo_ + a.batch)
+                nxt = eng.submit_fixed(to_var[fq[lo_:hi_]][:, None], to_var[fe[lo_:hi_]], fc[lo_:hi_])
+                if pending is not None:
+                    post = eng.wait(pending)
+                    n_done += len(post)
+                    checksum += float(post.sum())
+                pending = nxt
+            post = eng.wait(pending)
+            n_done += len(post)
+            checksum += float(post.sum())
+            eng.drain()
+            dt_full = time.perf_counter() - t_full
+            out["full_stream"] = {"requests": n_done, "seconds": dt_full, "queries_per_s": n_done / dt_full,
+                                  "posterior_mass": checksum,  # = requests (every posterior sums to 1): nothing was skipped
+                                  "note": "the whole C3 stream (1 M requests, rng seed 1) in one pass, beside the stepped figure `value`"}
         if world > 1:
             lo = a.warmup * G
             cost = eng.estimate_costs(to_var[qv[lo:lo + G]][:, None], to_var[ev[lo:lo + G]])
@@ -445,14 +544,14 @@ def main():
                         "so equal counts already balance to ~1 %"}
         if world == 1 and not a.no_configs:
             try:
-                out["configs"] = other_configs(device)
+                out["configs"] = other_configs(device, with_cpu=not a.no_cpu)
             except Exception as e:  # the headline line must not die with a side measurement
                 out["configs"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu:
             # GPU posteriors of the first 200 requests of the stream (what the reference legs work on)
             n_ref = 200
             post200 = eng.query_fixed(to_var[qv[:n_ref]][:, None], to_var[ev[:n_ref]], ec[:n_ref])
-            ref = cpu_reference(a.cpu_seconds, a.cpu_procs, first=n_ref) if a.cpu_seconds > 0 else None
+            ref = cpu_reference(a.cpu_seconds, a.cpu_procs) if a.cpu_seconds > 0 else None
             port, err_port = cpu_port(spec, qv[:n_ref], ev[:n_ref], ec[:n_ref], post200, a.port_seconds)
             if ref is not None and "error" not in ref[0]:
                 single, aggregate, answers = ref

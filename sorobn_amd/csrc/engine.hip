@@ -178,8 +178,8 @@ struct mibn_ctx {
     } comm;
     std::string err;
     mibn_stats stats{}, total{};               // last call / since creation
-    mibn_kernel_stat kstats[kNumKernels + 2];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel
-    mibn_kernel_stat ktotal[kNumKernels + 2];
+    mibn_kernel_stat kstats[kNumKernels + 3];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
+    mibn_kernel_stat ktotal[kNumKernels + 3];
     // options
     double arena_gb = 180.0;  // scratch budget of all lanes together (of the 288 GB)
     hipStream_t stream2 = nullptr;  // lane 1 (lane 0 = stream)
@@ -535,6 +535,11 @@ void ensure_pool(mibn_ctx *h) {
     }
 }
 
+// name of statistics slot k: the classes of work (split_kinds), then the kernels as launched
+const char *stat_name(int k) {
+    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : "ve_sweep_dma_kernel"));
+}
+
 // wait for a set's launches and book their HIP-event durations per kernel
 int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     if (!st.busy) return MIBN_OK;
@@ -560,7 +565,7 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         h->total.n_launches += 1;
         for (mibn_kernel_stat *ks : {&h->kstats[t.kid], &h->ktotal[t.kid]}) {
             if (ks == &h->kstats[t.kid] && !mine) continue;
-            if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", t.kid < kNumKernels ? kernel_name(t.kid) : "ve_level_kernel");
+            if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", stat_name(t.kid));
             ks->launches += 1;
             ks->ms += ms;
             ks->alg_bytes += t.bytes;
@@ -789,9 +794,9 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     ++h->call_id;
     h->search_ms = 0;
     h->stats = mibn_stats{};
-    for (int k = 0; k <= kNumKernels + 1; ++k) {
+    for (int k = 0; k <= kNumKernels + 2; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
-        std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : "tiny_kernel"));
+        std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", stat_name(k));
     }
     const int slot = h->next_slot;
     if (h->pend[slot].active) { h->err = "two asynchronous calls are already in flight: mibn_wait the older one first"; return MIBN_E_STATE; }
@@ -994,7 +999,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 else if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
                 else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, S, A);
                 if ((rc = next_event(h, st, e1, S))) return rc;
-                st.timed.push_back({sweep ? kKidSweep : (h->split_kinds ? L.kid : kNumKernels), e0, e1, bytes, (double)grid, h->call_id});
+                st.timed.push_back({sweep ? (h->sweep_dma ? kNumKernels + 2 : kKidSweep) : (h->split_kinds ? L.kid : kNumKernels), e0, e1, bytes, (double)grid, h->call_id});
                 n_wg += (double)grid;
                 li = lj;
             }
@@ -1120,7 +1125,7 @@ extern "C" int mibn_total_stats(const mibn_t *h, mibn_stats *out) {
 extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 1 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 2 && k < cap; ++i)
         if (h->ktotal[i].launches > 0) out[k++] = h->ktotal[i];
     *n = k;
     return MIBN_OK;
@@ -1129,7 +1134,7 @@ extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel
 extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 1 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 2 && k < cap; ++i)
         if (h->kstats[i].launches > 0) out[k++] = h->kstats[i];
     *n = k;
     return MIBN_OK;

@@ -80,18 +80,54 @@ class SoloComm:
         pass
 
 
-def _id_file():
-    """Where rank 0 leaves the RCCL id for the other ranks of this launch: the ranks of one node share the launcher
-    (same parent pid), the rendezvous port and the elastic run id."""
-    tag = "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+def _launcher_start():
+    """Epoch seconds at which this rank's parent process (the launcher: bench.py --gpus N, torchrun's agent, a shell) started -
+    from /proc, so that every rank of a launch computes the same value; None where /proc is not readable."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])  # field 22: starttime, in clock ticks since boot
+        with open("/proc/stat") as f:
+            btime = next(float(line.split()[1]) for line in f if line.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, StopIteration, IndexError):
+        return None
+
+
+def _comm_dir():
+    return os.environ.get("MIBN_COMM_DIR") or tempfile.gettempdir()
+
+
+def _launch_tag():
+    """What the ranks of ONE launch on a node share and no other launch does: the launcher's nonce (bench.py --gpus N creates
+    a private directory and a random MIBN_LAUNCH_NONCE per launch), else the rendezvous port, the elastic run id and the
+    launcher's pid."""
+    nonce = os.environ.get("MIBN_LAUNCH_NONCE")
+    if nonce:
+        return nonce
+    return "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
                                      os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid()))
-    return os.path.join(os.environ.get("MIBN_COMM_DIR") or tempfile.gettempdir(), f"mibn_comm_{tag}.id")
+
+
+def _id_file():
+    return os.path.join(_comm_dir(), f"mibn_comm_{_launch_tag()}.id")
+
+
+def _fresh(path, t0):
+    """A file of THIS launch: written after the launcher started (a crashed earlier launch with the same tag - same port, same
+    recycled pid - cannot have done that); without /proc: not older than ten minutes."""
+    start = _launcher_start()
+    return os.path.getmtime(path) >= (start - 1.0 if start is not None else t0 - 600.0)
 
 
 def exchange_id(rank, world, make_id, path=None, timeout_s=120.0):
-    """Rank 0 calls make_id() and publishes the bytes (atomic rename); the others wait for the file."""
+    """Rank 0 calls make_id() and publishes the bytes (atomic rename, after removing whatever an earlier launch left under the
+    same name); the others wait for a file of this launch."""
     path = path or _id_file()
     if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
         uid = make_id()
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
@@ -101,8 +137,7 @@ def exchange_id(rank, world, make_id, path=None, timeout_s=120.0):
     t0 = time.time()
     while True:
         try:
-            # a file older than this process's launch belongs to an earlier run that died before cleaning up
-            if os.path.getmtime(path) >= t0 - 600:
+            if _fresh(path, t0):
                 with open(path, "rb") as f:
                     uid = f.read()
                 if len(uid) >= 128:
@@ -114,6 +149,35 @@ def exchange_id(rank, world, make_id, path=None, timeout_s=120.0):
         time.sleep(0.01)
 
 
+def all_agree(rank, world, ok, what, timeout_s=120.0):
+    """A collective boolean AND over the ranks of a node without a communicator (it decides whether one can be built): every
+    rank leaves a marker file of this launch, then reads everybody's.  Returns True iff every rank reported ok; a rank that
+    does not report within the timeout counts as a failure."""
+    base = os.path.join(_comm_dir(), f"mibn_vote_{_launch_tag()}_{what}")
+    mine = f"{base}.{rank}"
+    tmp = f"{mine}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        f.write("1" if ok else "0")
+    os.replace(tmp, mine)
+    t0 = time.time()
+    verdict = True
+    for r in range(world):
+        p = f"{base}.{r}"
+        while True:
+            try:
+                if _fresh(p, t0):
+                    with open(p) as f:
+                        verdict = verdict and f.read().strip() == "1"
+                    break
+            except OSError:
+                pass
+            if time.time() - t0 > timeout_s:
+                verdict = False
+                break
+            time.sleep(0.01)
+    return verdict
+
+
 class RcclComm:
     """mibn_comm_* of include/mibn.h on the engine's own device and stream (RCCL over xGMI)."""
 
@@ -121,7 +185,17 @@ class RcclComm:
         self.engine = engine
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
-        uid, path = exchange_id(self.rank, self.world, engine.comm_unique_id)
+        # What can fail on one rank only - loading librccl.so - happens BEFORE anybody enters the collective
+        # ncclCommInitRank, and the ranks agree on the outcome: either all of them build the communicator or all of them
+        # raise (and the caller falls back as a whole); a rank that failed alone would leave the others hanging in the init.
+        try:
+            probe = engine.comm_unique_id()  # (dlopen + ncclGetUniqueId; only rank 0's id is used)
+            err = None
+        except Exception as e:  # noqa: BLE001
+            probe, err = None, e
+        if not all_agree(self.rank, self.world, err is None, "rccl_load"):
+            raise RuntimeError(f"mibn_comm_* unavailable on at least one rank of the node (this rank: {err!r})")
+        uid, path = exchange_id(self.rank, self.world, lambda: probe)
         engine.comm_init(self.rank, self.world, uid)
         engine.comm_barrier()  # every rank has read the id
         if self.rank == 0:

