@@ -181,7 +181,7 @@ struct mibn_ctx {
     mibn_kernel_stat kstats[kNumKernels + 3];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
     mibn_kernel_stat ktotal[kNumKernels + 3];
     // options
-    double arena_gb = 180.0;  // scratch budget of all lanes together (of the 288 GB)
+    double arena_gb = 200.0;  // scratch budget of all lanes together (of the 288 GB)
     hipStream_t stream2 = nullptr;  // lane 1 (lane 0 = stream)
     hipEvent_t epoch = nullptr;     // reference of the busy-time bookkeeping (re-recorded when the GPU is idle)
     hipEvent_t lane_ev = nullptr, zero_ev = nullptr;  // end of lane 1's work of a call / results buffer zeroed
@@ -196,7 +196,10 @@ struct mibn_ctx {
     int sweep_dma = 1;    // the sweep kernel: 1 = ve_sweep_dma_kernel (round 3: LDS-DMA fill, 16-byte LDS accesses, wave-local stage pairs,
                           // wave-owned tail); 0 = round 2's register-staged ve_sweep_kernel (reference for A/B runs and the bit-for-bit test)
     int gibbs_lds = 1;    // Gibbs: keep the CPTs in LDS when they fit (0: always read them through L2)
-    int64_t chunk = 16384;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i
+    int64_t chunk = 32768;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i.  Round 3: 32 768 (16 384 before):
+                            // half as many, twice as large launches - the tails of the ~150 launches of a chunk cost the same time
+                            // whatever their size: 4.13-4.24 -> 4.30-4.38 TB/s over all kernels (profiles/r03_d_chunk.log); the
+                            // arena of a C3 chunk doubles to ~145 GB of the 288
 };
 
 #define HIP_TRY(h, expr)                                                                              \
@@ -881,7 +884,13 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error: do not leave it for the check after the launches)
     const bool short_first = h->first_chunk == 2 || (h->first_chunk == 1 && !gpu_busy);
     for (int64_t b0 = 0, b1 = 0; b0 < B; b0 = b1, ++n_chunks) {
-        b1 = std::min(B, b0 + (b0 == 0 && B > h->chunk && short_first ? std::max<int64_t>(1024, h->chunk / 4) : h->chunk));
+        // (also a call of a single chunk starts with a short one when the GPU is idle: the pipeline of a stream of calls fills in a
+        //  quarter of the time; in steady state - the previous call still running - it stays one chunk)
+        //  With the device order search on, every call starts with a short chunk - an eighth - whose orders the host searches
+        //  while ONE launch searches the rest of the call: a call of a single chunk would otherwise be searched on the host whole)
+        const int64_t first_n = std::max<int64_t>(1024, search_on ? h->chunk / 8 : h->chunk / 4);
+        b1 = std::min(B, b0 + (b0 == 0 && B > first_n && ((short_first && (B > h->chunk || !gpu_busy)) || (search_on && h->gpu_search == 1))
+                                   ? first_n : h->chunk));
         const int64_t n = b1 - b0;
         mibn_ctx::Set &st = h->set[h->set_cursor];
         const int lane = n_lanes > 1 ? (h->set_cursor & 1) : 0;  // consecutive chunks alternate between the lanes

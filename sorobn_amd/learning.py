@@ -115,6 +115,10 @@ def partial_fit(bn, X):
         if len(names) > 1:
             bn.P[node] = counts / counts.groupby(level=list(names[:-1])).transform("sum")
         else:
+            # Deliberate deviation for a ROOT column with missing values (NaN / None): the reference divides the counts of
+            # the observed labels by the number of ROWS seen so far (`_P_sizes[root] += len(X)`, bayes_net.py:503-508), so
+            # its P(root) sums to less than 1 when rows were missing; here the CPT stays a distribution (counts / their
+            # sum).  Without missing values in the column the two agree exactly.
             bn.P[node] = counts / counts.sum()
     bn.prepare()
     return bn
@@ -174,7 +178,10 @@ def chow_liu(X, root=None, device=None):
     union-find over the edges in descending MI order, ties in sorted-pair order like the reference's stable sort),
     oriented away from `root` (default: the first column).  Returns (parent, child) tuples.  Like the reference's
     `kruskal` (structure.py:108-117) the scan stops as soon as every vertex has a neighbour - which can be before the
-    components are joined: the result is then the part of that forest reachable from `root`."""
+    components are joined: the result is then the part of that forest reachable from `root`.
+    The ORDER of the returned edge list is unspecified (the reference orients the tree by iterating Python sets, the order
+    depends on the hash seed): compare trees as sets of directed edges.
+    """
     mi = mutual_information(X, device=device)
     ranked = sorted(mi, key=lambda e: mi[e], reverse=True)  # stable: equal MI keeps combinations() order
     leader = {v: v for v in X.columns}

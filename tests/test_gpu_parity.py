@@ -262,7 +262,7 @@ def test_arena_budget_exceeded_path(amd):
     with pytest.raises(_capi.MibnError) as err:
         be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
     assert err.value.code == _capi.E_NOMEM and "above the arena budget" in str(err.value)
-    be.engine.set_option("arena_gb", 180.0)
+    be.engine.set_option("arena_gb", 200.0)
     assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base)  # the context is still usable
 
 

@@ -4,9 +4,9 @@
 
 FETCH_SIZE / WRITE_SIZE come from separate rocprofv3 --pmc passes of the bench command (tools/gpu_profile.sh).  On gfx950
 FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM section): doubled for ve_level_kernel, whose
-waves read 512 contiguous bytes per instruction.  ve_sweep_kernel reads runs of 64 bytes, which the counter tallies in
-full: calibrated on a known byte count (tools/gpu_r02_calib.sh, profiles/r02_u_pmc_calibration.log: WRITE_SIZE exact,
-FETCH_SIZE = bytes read), so no correction there.  The algorithmic bytes per launch of the same command are taken from
+waves read 512 contiguous bytes per instruction.  The sweep kernels read runs of 64 bytes, which the counter tallies in
+full - register-staged loads and LDS-DMA alike: calibrated on a known byte count (tools/gpu_r03_session.sh,
+profiles/r03_*_pmc_calibration.log: FETCH_SIZE 8.582 GB for 8.590 GB read, WRITE_SIZE 8.608 / 8.590), so no correction there.  The algorithmic bytes per launch of the same command are taken from
 the bench line at the end of the summary.  bench.py's `roofline.traffic` reads
 the newest profiles/r*_pmc.json.
 """
@@ -26,10 +26,16 @@ per = {}
 for name in sorted(set(fetch) & set(write)):
     f, w = fetch[name][1], write[name][1]
     k = bench.get("kernels", {}).get(name)
-    corr = 1.0 if name == "ve_sweep_kernel" else 2.0
+    corr = 1.0 if name in ("ve_sweep_kernel", "ve_sweep_dma_kernel") else 2.0  # (see the session's *_pmc_calibration.log)
+    # The counter passes see EVERY launch of the command (warm-up steps and the short first chunk of the pipeline included), the
+    # bench line books the timed steps only: compare totals - traffic of all launches against the algorithmic bytes of all
+    # steps (the steps are i.i.d. request batches of one size: algorithmic bytes per step x (steps + warm-up)) - and express
+    # both per launch of the counter pass.
+    steps_all = (bench.get("steps", 0) + bench.get("warmup", 0)) / max(1, bench.get("steps", 1))
+    alg_per_launch = (k["alg_GB"] * 1e9 * steps_all / fetch[name][0]) if k else None
     per[name] = {"launches_under_the_counters": fetch[name][0], "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
                  "fetch_correction": corr, "traffic_bytes_per_launch": corr * f * 1024 + w * 1024,
-                 "alg_bytes_per_launch_same_run": (k["alg_GB"] * 1e9 / k["launches"]) if k else None}
+                 "alg_bytes_per_launch_same_run": alg_per_launch}
 out = {"source": path + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of the bench command)",
        "note": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled for ve_level_kernel; ve_sweep_kernel's 64-byte runs are "
                "counted in full (calibration: profiles/r02_u_pmc_calibration.log); WRITE_SIZE as reported", "per_kernel": per}
