@@ -497,7 +497,19 @@ extern "C" int plan_sim_query_batch(int32_t n_vars, const int32_t *card, const i
                 req_level[it.req] = L.level;
             }
             if (it.a & kItemSegment) {
-                if (L.kid != kKidSeg || it.b != wg) { g_err = "segment item inconsistent"; rc = -11; break; }
+                // a workgroup of segments: item k and the it.b - 1 items behind it, one per wave (planner.h kSegPerWg)
+                if (L.kid != kKidSeg || it.b < 1 || it.b > (uint32_t)kSegPerWg || k + it.b > L.first + L.count) { g_err = "segment group inconsistent"; rc = -11; break; }
+                if ((k - L.first) % kSegPerWg != 0) { g_err = "segment group not aligned"; rc = -11; break; }
+                for (uint32_t wv = 0; wv < it.b && rc == 0; ++wv) {
+                const Item &sg = sc.items[k + wv];
+                if (!(sg.a & kItemSegment) || (wv > 0 && sg.b != 0) || sg.req >= (uint32_t)B) { g_err = "segment group member inconsistent"; rc = -11; break; }
+                if (wv > 0) {
+                    if (req_level[sg.req] >= L.level) { g_err = "two items of a request in one level"; rc = -11; break; }
+                    req_level[sg.req] = L.level;
+                }
+                const uint32_t *p = bufs[(size_t)bp.thread_of[sg.req]].data + bp.local_off[sg.req] + sg.rel_off;
+                const int64_t need = bp.arena_need[sg.req];
+                const Item &it = sg;  // (the steps below belong to this wave's item)
                 const uint32_t n_steps = it.a & ~kItemSegment;
                 for (uint32_t s = 0; s < n_steps && rc == 0; ++s) {
                     if ((p[0] & 0xff) != kKindGeneric) { g_err = "FIBER / SWEEP step inside a segment"; rc = -10; break; }
@@ -511,6 +523,7 @@ extern "C" int plan_sim_query_batch(int32_t n_vars, const int32_t *card, const i
                             for (int64_t i = 0; i < cells; ++i) res[oo + i] /= total;
                     }
                     p += p[6];
+                }
                 }
             } else {
                 if (kernel_id_of_step(p) != L.kid) { g_err = "tile scheduled under the wrong class"; rc = -11; break; }

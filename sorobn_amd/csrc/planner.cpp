@@ -2287,14 +2287,26 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
                 }
             }
             const size_t wg_first = wg;
-            for (size_t q = count[k]; q < count[k + 1]; ++q) {
-                const uint32_t wgs = out.items[q].b;
-                out.items[q].b = (uint32_t)(wg - wg_level);
-                std::fill(out.wg_item.begin() + wg, out.wg_item.begin() + wg + wgs, (uint32_t)q);
-                wg += wgs;
+            if (kid == kKidSeg) {
+                // Segments are chains of dependent tiny steps - latency, not bandwidth - and a wave is enough for one (< 4 096
+                // output cells per step): a workgroup runs FOUR, one per wave, with nothing shared but the launch.  Twelve
+                // chains per CU in flight instead of three (the level kernel's 40 KB of LDS admit three workgroups per CU).
+                for (size_t q = count[k]; q < count[k + 1]; q += kSegPerWg) {
+                    const size_t m = std::min<size_t>(kSegPerWg, count[k + 1] - q);
+                    for (size_t t = 0; t < m; ++t) out.items[q + t].b = t == 0 ? (uint32_t)m : 0u;
+                    out.wg_item[wg++] = (uint32_t)q;
+                }
+            } else {
+                for (size_t q = count[k]; q < count[k + 1]; ++q) {
+                    const uint32_t wgs = out.items[q].b;
+                    out.items[q].b = (uint32_t)(wg - wg_level);
+                    std::fill(out.wg_item.begin() + wg, out.wg_item.begin() + wg + wgs, (uint32_t)q);
+                    wg += wgs;
+                }
             }
             out.launches.push_back({level, kid, count[k], count[k + 1] - count[k], wg_first, wg - wg_first, wg_level, bytes[k]});
         }
+    out.wg_item.resize(wg);  // (sized for one workgroup per segment above)
 }
 
 }  // namespace mibn

@@ -285,10 +285,14 @@ void estimate_costs(const Network &net, ThreadPool &pool, int64_t B, const int64
 struct Item {
     uint32_t req;      // request index within the wave
     uint32_t rel_off;  // word offset of the (first) step inside the request's program
-    uint32_t a, b;     // SEGMENT: a = number of steps | kItemSegment.  TILED step: a = hi iterations per tile.
-                       // b = index of the item's first workgroup within its level
+    uint32_t a, b;     // SEGMENT: a = number of steps | kItemSegment; b = segments of its workgroup (first item of a group of
+                       // kSegPerWg) or 0.  TILED step: a = hi iterations per tile; b = index of the item's first workgroup
+                       // within its level
 };
 constexpr uint32_t kItemSegment = 1u << 31;
+constexpr int kSegPerWg = 4;  // segments per workgroup of the level kernel: one per wave (the items of a level's segments are
+                              // contiguous; workgroup g runs items first + 4 g .. + 3, Item::b of the group's first item = how
+                              // many of the four exist)
 struct Launch {
     int level, kid;       // kid: the class of work (kernel_name), for per-class accounting
     size_t first, count;  // range in Schedule::items

@@ -72,7 +72,21 @@ __device__ __forceinline__ const double *table_ptr(uint32_t lo, uint32_t hi, con
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------------------------------- GENERIC
-template <int NIN, int MAXC, int CX>
+// LANES = kWG: a tile of a big step, the whole workgroup.  LANES = 64: a step of a SEGMENT - one wave runs a request's chain
+// of tiny steps on its own (four segments per workgroup, planner.h kSegPerWg): no workgroup barrier, the hand-over between
+// dependent steps is the wave's own program order plus a fence.
+template <int LANES>
+__device__ __forceinline__ void lanes_sync() {
+    if constexpr (LANES == kWG) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (this wave's stores to the arena / LDS before its next reads)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <int NIN, int MAXC, int CX, int LANES>
 __device__ __forceinline__ void generic_body(const uint32_t *sw, int (*sh_hoff)[kTileMax], const double *__restrict__ pool,
                                              double *__restrict__ slot, double *__restrict__ results, const int tid,
                                              const int h_begin, const int h_end) {
@@ -95,25 +109,9 @@ __device__ __forceinline__ void generic_body(const uint32_t *sw, int (*sh_hoff)[
     const uint32_t *card = sw + kHdrWords + 3 * NIN;
     const int *strd = (const int *)(card + na);  // strd[j * na + a]
 
-    int lo_off[NIN][MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-#pragma unroll
-        for (int j = 0; j < NIN; ++j) lo_off[j][c] = 0;
-        const int l = tid + c * kWG;
-        if (l < lo_cells) {
-            int r = l;
-            for (int a = 0; a < nlo; ++a) {
-                const int cd = (int)card[a];
-                const int q = r / cd;
-                const int d = r - q * cd;
-                r = q;
-#pragma unroll
-                for (int j = 0; j < NIN; ++j) lo_off[j][c] += d * strd[j * na + a];
-            }
-        }
-    }
-
+    // the lane-varying block holds up to MAXC * kWG cells: a workgroup covers it in one pass of MAXC cells per lane, a single
+    // wave (a segment's step) in up to four (static register indices either way: one pass's offsets live in registers)
+    const int passes = LANES == kWG ? 1 : (lo_cells + MAXC * LANES - 1) / (MAXC * LANES);
     for (int h0 = h_begin; h0 < h_end; h0 += kTileMax) {
         {
             const int h = h0 + tid;
@@ -134,60 +132,84 @@ __device__ __forceinline__ void generic_body(const uint32_t *sw, int (*sh_hoff)[
                 for (int j = 0; j < NIN; ++j) sh_hoff[j][tid] = acc[j];
             }
         }
-        __syncthreads();
+        lanes_sync<LANES>();
         const int nh = min(kTileMax, h_end - h0);
-        for (int hh = 0; hh < nh; ++hh) {
-            int ho[NIN];
-#pragma unroll
-            for (int j = 0; j < NIN; ++j) ho[j] = sh_hoff[j][hh];
-            const size_t orow = (size_t)(h0 + hh) * (size_t)lo_cells;
+        for (int pass = 0; pass < passes; ++pass) {
+            const int l0 = tid + pass * (MAXC * LANES);
+            int lo_off[NIN][MAXC];
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
-                const int l = tid + c * kWG;
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) lo_off[j][c] = 0;
+                const int l = l0 + c * LANES;
                 if (l < lo_cells) {
-                    double acc = 0.0;
-                    if (CX) {
+                    int r = l;
+                    for (int a = 0; a < nlo; ++a) {
+                        const int cd = (int)card[a];
+                        const int q = r / cd;
+                        const int d = r - q * cd;
+                        r = q;
 #pragma unroll
-                        for (int x = 0; x < (CX ? CX : 1); ++x) {
-                            double p = inp[0][ho[0] + lo_off[0][c] + x * xs[0]];
-#pragma unroll
-                            for (int j = 1; j < NIN; ++j) p *= inp[j][ho[j] + lo_off[j][c] + x * xs[j]];
-                            acc += p;
-                        }
-                    } else {
-                        for (int x = 0; x < cx; ++x) {
-                            double p = inp[0][ho[0] + lo_off[0][c] + x * xs[0]];
-#pragma unroll
-                            for (int j = 1; j < NIN; ++j) p *= inp[j][ho[j] + lo_off[j][c] + x * xs[j]];
-                            acc += p;
-                        }
+                        for (int j = 0; j < NIN; ++j) lo_off[j][c] += d * strd[j * na + a];
                     }
-                    outp[orow + l] = acc;
+                }
+            }
+            for (int hh = 0; hh < nh; ++hh) {
+                int ho[NIN];
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) ho[j] = sh_hoff[j][hh];
+                const size_t orow = (size_t)(h0 + hh) * (size_t)lo_cells;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int l = l0 + c * LANES;
+                    if (l < lo_cells) {
+                        double acc = 0.0;
+                        if (CX) {
+#pragma unroll
+                            for (int x = 0; x < (CX ? CX : 1); ++x) {
+                                double p = inp[0][ho[0] + lo_off[0][c] + x * xs[0]];
+#pragma unroll
+                                for (int j = 1; j < NIN; ++j) p *= inp[j][ho[j] + lo_off[j][c] + x * xs[j]];
+                                acc += p;
+                            }
+                        } else {
+                            for (int x = 0; x < cx; ++x) {
+                                double p = inp[0][ho[0] + lo_off[0][c] + x * xs[0]];
+#pragma unroll
+                                for (int j = 1; j < NIN; ++j) p *= inp[j][ho[j] + lo_off[j][c] + x * xs[j]];
+                                acc += p;
+                            }
+                        }
+                        outp[orow + l] = acc;
+                    }
                 }
             }
         }
-        __syncthreads();
+        lanes_sync<LANES>();
     }
 }
 
-template <int NIN, int MAXC>
+template <int NIN, int MAXC, int LANES>
 __device__ __forceinline__ void generic_call(const uint32_t *sw, int (*sh_hoff)[kTileMax], const double *pool, double *slot,
                                           double *results, int tid, int h_begin, int h_end) {
     const int cx = (int)(sw[1] & 0xffff);
-    if (cx == 4) generic_body<NIN, MAXC, 4>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
-    else if (cx == 2) generic_body<NIN, MAXC, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
-    else generic_body<NIN, MAXC, 0>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
+    if (cx == 4) generic_body<NIN, MAXC, 4, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
+    else if (cx == 2) generic_body<NIN, MAXC, 2, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
+    else generic_body<NIN, MAXC, 0, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end);
 }
 
+// (cells per lane: the lane-varying block holds up to kLoMax = 512 cells for <= 3 inputs, kLoTarget = 256 beyond)
+template <int LANES>
 __device__ __forceinline__ void generic_dispatch(int n_in, const uint32_t *sw, int (*sh_hoff)[kTileMax], const double *pool,
                                                  double *slot, double *results, int tid, int h_begin, int h_end) {
+    constexpr int M3 = LANES == kWG ? kLoMax / kWG : 2, M6 = LANES == kWG ? kLoTarget / kWG : 1;  // cells per lane and pass
     switch (n_in) {
-        case 1: generic_call<1, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
-        case 2: generic_call<2, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
-        case 3: generic_call<3, 2>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
-        case 4: generic_call<4, 1>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
-        case 5: generic_call<5, 1>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
-        default: generic_call<6, 1>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 1: generic_call<1, M3, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 2: generic_call<2, M3, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 3: generic_call<3, M3, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 4: generic_call<4, M6, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        case 5: generic_call<5, M6, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
+        default: generic_call<6, M6, LANES>(sw, sh_hoff, pool, slot, results, tid, h_begin, h_end); break;
     }
 }
 
@@ -859,18 +881,49 @@ __device__ __forceinline__ void chain_mfma_call(const uint32_t *sw, double *__re
     }
 }
 
-// posterior / posterior.sum()  (bayes_net.py:790); an all-zero table (zero-probability evidence) stays zero
-__device__ __forceinline__ void normalise(double *__restrict__ p, int n, double *sh_red, int tid) {
+// posterior / posterior.sum()  (bayes_net.py:790); an all-zero table (zero-probability evidence) stays zero.  One wave (a segment).
+// The summation order - lane-strided partial sums, then the butterfly - is the one a workgroup of four waves used up to
+// round 2 only for tables of at most 64 cells (every query of one or two variables): larger final tables round differently
+// in the last bit.
+__device__ __forceinline__ void normalise_wave(double *__restrict__ p, int n, int lane) {
     double s = 0.0;
-    for (int i = tid; i < n; i += kWG) s += p[i];
+    for (int i = lane; i < n; i += 64) s += p[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((tid & 63) == 0) sh_red[tid >> 6] = s;
-    __syncthreads();
-    const double total = (sh_red[0] + sh_red[1]) + (sh_red[2] + sh_red[3]);
+    const double total = __shfl(s, 0, 64);
     if (total > 0.0)
-        for (int i = tid; i < n; i += kWG) p[i] = p[i] / total;
-    __syncthreads();
+        for (int i = lane; i < n; i += 64) p[i] = p[i] / total;
+}
+
+// A workgroup of SEGMENTS (planner.h kSegPerWg): wave w runs item first + w - the small GENERIC steps of one request, back to
+// back, on its own.  A chain of dependent tiny steps is latency, not bandwidth, and a wave is enough for one (< 4 096 output
+// cells per step): four chains per workgroup, twelve per CU, hide four times as much of it as one.  The wave's copy of the
+// step descriptor and its offset table live in its quarter of the first 12 KB of shT (a segment has no T).
+__device__ __forceinline__ void segment_wave(const LevelArgs &A, const uint32_t first, const int n_valid, double *shT, const int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave >= n_valid) return;
+    const uint32_t idx = first + (uint32_t)wave;
+    const uint32_t req = (uint32_t)uni((int)A.items[idx].req), rel_off = (uint32_t)uni((int)A.items[idx].rel_off);
+    const int n_steps = (int)((uint32_t)uni((int)A.items[idx].a) & ~kItemSegment);
+    const uint64_t ao = A.arena_off[req], po = A.prog_off[req];
+    double *slot = A.arena + (((uint64_t)(uint32_t)uni((int)(ao >> 32)) << 32) | (uint32_t)uni((int)(ao & 0xffffffffu)));
+    const uint32_t *p = A.prog + (((uint64_t)(uint32_t)uni((int)(po >> 32)) << 32) | (uint32_t)uni((int)(po & 0xffffffffu))) + rel_off;
+    unsigned char *wbase = reinterpret_cast<unsigned char *>(shT) + wave * (kMaxStepWords * 4 + kMaxIn * kTileMax * 4);
+    uint32_t *w_step = reinterpret_cast<uint32_t *>(wbase);
+    int (*w_hoff)[kTileMax] = reinterpret_cast<int (*)[kTileMax]>(wbase + kMaxStepWords * 4);
+    for (int s = 0; s < n_steps; ++s) {
+        const int words = (int)p[6];
+        lanes_sync<64>();  // the previous step's stores are done and visible to this wave; its descriptor copy is reusable
+        for (int i = lane; i < words; i += 64) w_step[i] = p[i];
+        lanes_sync<64>();
+        generic_dispatch<64>((w_step[0] >> 8) & 0xff, w_step, w_hoff, A.pool, slot, A.results, lane, 0, (int)w_step[3]);
+        if ((w_step[1] >> 16) & kFlagFinal) {
+            const uint64_t out_off = (uint64_t)w_step[4] | ((uint64_t)w_step[5] << 32);
+            lanes_sync<64>();
+            normalise_wave(A.results + out_off, (int)(w_step[2] * w_step[3]), lane);
+        }
+        p += words;
+    }
 }
 
 #ifndef MIBN_PATHS
@@ -891,7 +944,6 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
     __shared__ __attribute__((aligned(16))) uint32_t shX[4 * 64 * kXRow];
     __shared__ uint32_t sh_step[kMaxStepWords];
     __shared__ int sh_hoff[kMaxIn][kTileMax];
-    __shared__ double sh_red[kWG / 64];
     const int tid = threadIdx.x;
     const uint32_t wg = blockIdx.x + A.wg_base;
     // (everything about the work item is wave-uniform: kept in scalar registers explicitly - as lane values the arena and
@@ -902,26 +954,13 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
     it.rel_off = (uint32_t)uni((int)A.items[item_idx].rel_off);
     it.a = (uint32_t)uni((int)A.items[item_idx].a);
     it.b = (uint32_t)uni((int)A.items[item_idx].b);
+    if (it.a & kItemSegment) {
+        segment_wave(A, item_idx, (int)it.b, shT, tid);
+        return;
+    }
     const uint64_t ao = A.arena_off[it.req], po = A.prog_off[it.req];
     double *slot = A.arena + (((uint64_t)(uint32_t)uni((int)(ao >> 32)) << 32) | (uint32_t)uni((int)(ao & 0xffffffffu)));
     const uint32_t *p = A.prog + (((uint64_t)(uint32_t)uni((int)(po >> 32)) << 32) | (uint32_t)uni((int)(po & 0xffffffffu))) + it.rel_off;
-    if (it.a & kItemSegment) {
-        // SEGMENT: small GENERIC steps of one request, back to back
-        const int n_steps = (int)(it.a & ~kItemSegment);
-        for (int s = 0; s < n_steps; ++s) {
-            const int words = (int)p[6];
-            __syncthreads();  // previous step's stores are done and visible to the workgroup; sh_step reusable
-            for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
-            __syncthreads();
-            if constexpr (MIBN_PATHS & 64) generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, 0, (int)sh_step[3]);
-            if ((sh_step[1] >> 16) & kFlagFinal) {
-                const uint64_t out_off = (uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32);
-                normalise(A.results + out_off, (int)(sh_step[2] * sh_step[3]), sh_red, tid);
-            }
-            p += words;
-        }
-        return;
-    }
     // TILE of a big step: hi iterations [h0, h1)
     const int words = (int)p[6];
     for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
@@ -960,7 +999,7 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
 #endif
         }
     } else {
-        if constexpr (MIBN_PATHS & 64) generic_dispatch((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);
+        if constexpr (MIBN_PATHS & 64) generic_dispatch<kWG>((sh_step[0] >> 8) & 0xff, sh_step, sh_hoff, A.pool, slot, A.results, tid, h0, h1);
     }
 }
 #undef MIBN_FIBER_CASES
