@@ -884,13 +884,18 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error: do not leave it for the check after the launches)
     const bool short_first = h->first_chunk == 2 || (h->first_chunk == 1 && !gpu_busy);
     for (int64_t b0 = 0, b1 = 0; b0 < B; b0 = b1, ++n_chunks) {
-        // (also a call of a single chunk starts with a short one when the GPU is idle: the pipeline of a stream of calls fills in a
-        //  quarter of the time; in steady state - the previous call still running - it stays one chunk)
-        //  With the device order search on, every call starts with a short chunk - an eighth - whose orders the host searches
-        //  while ONE launch searches the rest of the call: a call of a single chunk would otherwise be searched on the host whole)
-        const int64_t first_n = std::max<int64_t>(1024, search_on ? h->chunk / 8 : h->chunk / 4);
-        b1 = std::min(B, b0 + (b0 == 0 && B > first_n && ((short_first && (B > h->chunk || !gpu_busy)) || (search_on && h->gpu_search == 1))
-                                   ? first_n : h->chunk));
+        // A call that finds the GPU idle (the first of a stream of calls, a blocking call) starts with a short chunk - a quarter -
+        // that gets the GPU going while the host plans the rest; in steady state - the previous call still running - a call
+        // is cut into full chunks.  (Ramping the chunks up from 1 024 requests, doubling, was measured and dropped: seven small
+        // plan_batch calls cost 95 ms of host time instead of 63, and the chunk sets - their pinned buffers sized by the small
+        // chunks they had seen - grew under the clock: profiles/r03_i_pipeline_start.log.)
+        // With the device order search on, every call starts with an eighth of a chunk whose orders the host searches while
+        // ONE launch searches the rest of the call (a call of a single chunk would otherwise be searched on the host whole).
+        const bool dev_split = search_on && h->gpu_search == 1;
+        int64_t size = h->chunk;
+        if (b0 == 0 && dev_split) size = std::max<int64_t>(1024, h->chunk / 8);
+        else if (b0 == 0 && short_first && (B > h->chunk || !gpu_busy)) size = std::max<int64_t>(1024, h->chunk / 4);
+        b1 = std::min(B, b0 + size);
         const int64_t n = b1 - b0;
         mibn_ctx::Set &st = h->set[h->set_cursor];
         const int lane = n_lanes > 1 ? (h->set_cursor & 1) : 0;  // consecutive chunks alternate between the lanes
