@@ -379,7 +379,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
             if (!h->planner_only) return upload_order_net(h);
         }
     }
-    else if (n == "order_weights") h->net.order_weights = value != 0;  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
+    else if (n == "order_weights") h->net.order_weights = std::max(0, std::min(64, (int)value));  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
     else if (n == "sweep_adapt") h->net.sweep_adapt = std::max(0, (int)value);  // fewer tiles per workgroup in sweep launches below this many workgroups
     else if (n == "sweep_iters") h->net.sweep_iters = std::max(1, std::min(kTileMax, (int)value));  // tiles per workgroup of the sweep kernel

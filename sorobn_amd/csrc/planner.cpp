@@ -161,7 +161,7 @@ OrderNet Network::order_view() const {
     o.hint_sorted = hint_flat.data();
     o.prune = prune;
     o.minfill_above = minfill_above;
-    o.chain_weight = (fuse && sweep >= 4 && order_weights) ? 0.25 : 1.0;
+    o.chain_weight = (fuse && sweep >= 4 && order_weights) ? (order_weights == 1 ? 0.25 : 1.0 / (double)order_weights) : 1.0;  // (option value k > 1: weight 1 / k)
     o.big_cells = (double)small_cells;
     return o;
 }

@@ -81,8 +81,9 @@ struct Network {
     int sweep = 5;           // SWEEP form: up to this many 4-state variables of one big table per pass, tile resident in LDS (0 = off)
     int sweep_iters = kSweepItersDefault;  // tiles per workgroup of the sweep kernel
     int sweep_adapt = 4096;  // build_schedule: fewer tiles per workgroup (down to 2) in sweep launches of fewer workgroups than this (0: off)
-    int builtin_sweeps = 0;  // 1: two depth-first topological orders (grid: row- and column-major) as candidate orders next to the host's
-                             // hints: -2 % bytes on C3, no measurable time (profiles/r02_w_builtin_sweeps.log): off by default
+    int builtin_sweeps = 1;  // two depth-first topological orders (grid: row- and column-major) as candidate orders next to the host's
+                             // hints: -2 % bytes on C3.  Off in round 2 (no measurable time then); with round 3's kernels the bytes
+                             // show: 269 -> 278 k queries/s, 4 ms more planning per 32 768 requests (profiles/r03_j_orders.log)
     int order_weights = 1;   // compare candidate orders with single-table eliminations at a quarter of their bytes (order_search.h)
     int sweep_canon = 1;     // 0 (test hook): never flag a SWEEP step canonical - the kernel's general path runs everything
 
