@@ -193,6 +193,8 @@ struct mibn_ctx {
     int threads = 0;
     int trace = 0;        // debug: one stderr line per launch
     int split_kinds = 0;  // profiling: one launch per (level, class of work) instead of one per level
+    int overlap = 1;      // the sweep launch of a level goes to a second stream, beside the level kernel's launch of the same level (their
+                          // items belong to different requests): the tail of one runs under the body of the other, +1-2 % (profiles/r03_k_overlap.log)
     int sweep_dma = 1;    // the sweep kernel: 1 = ve_sweep_dma_kernel (round 3: LDS-DMA fill, 16-byte LDS accesses, wave-local stage pairs,
                           // wave-owned tail); 0 = round 2's register-staged ve_sweep_kernel (reference for A/B runs and the bit-for-bit test)
     int gibbs_lds = 1;    // Gibbs: keep the CPTs in LDS when they fit (0: always read them through L2)
@@ -358,6 +360,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "chunk_sets") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->n_sets = std::max(2, std::min(kChunkSets, (int)value)); h->set_cursor = 0; }
     else if (n == "trace") h->trace = (int)value;
     else if (n == "split_kinds") h->split_kinds = value != 0;
+    else if (n == "overlap") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->overlap = value != 0; }
     else if (n == "sweep_dma") h->sweep_dma = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
     else if (n == "tiny") h->tiny = value != 0;
@@ -992,6 +995,13 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             size_t e_first = 0;
             if ((rc = next_event(h, st, e_first, S))) return rc;
             A.items = st.d_items;
+            // option overlap: the sweep launch of a level goes to a second stream, next to the level kernel's launch of the same
+            // level (their items belong to different requests); level L + 1 starts on either stream when BOTH launches of level L
+            // have finished.  The tail of one launch - a sweep workgroup lives ~100 us - then runs under the body of the other.
+            const bool two = h->overlap && n_lanes == 1;
+            hipStream_t S2 = h->stream2;
+            long last_a = -1, last_b = -1, a_saw_b = -1, b_saw_a = (long)e_first;  // event indices: last launch end on S / S2, and what the other stream has waited for
+            if (two) HIP_TRY(h, hipStreamWaitEvent(S2, st.ev[e_first], 0));  // (the uploads, the previous wave's kernels: the arena is theirs until then)
             for (size_t li = 0; li < sc.launches.size();) {
                 // one launch of the level kernel per level (all its classes of work together) unless split_kinds, and one
                 // of the sweep kernel for the level's SWEEP items (the last class of a level: its own LDS budget)
@@ -1008,16 +1018,23 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 A.wg_item = st.d_wg_item + L.wg_level;
                 A.wg_base = (uint32_t)(L.wg_first - L.wg_level);
                 size_t e0 = 0, e1 = 0;
-                if ((rc = next_event(h, st, e0, S))) return rc;
-                if (sweep && h->sweep_dma) hipLaunchKernelGGL(ve_sweep_dma_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
-                else if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, S, A);
-                else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, S, A);
-                if ((rc = next_event(h, st, e1, S))) return rc;
+                hipStream_t Sx = (two && sweep) ? S2 : S;
+                if (two) {  // the previous level's launch on the other stream
+                    if (sweep && last_a > b_saw_a) { HIP_TRY(h, hipStreamWaitEvent(S2, st.ev[(size_t)last_a], 0)); b_saw_a = last_a; }
+                    if (!sweep && last_b > a_saw_b) { HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)last_b], 0)); a_saw_b = last_b; }
+                }
+                if ((rc = next_event(h, st, e0, Sx))) return rc;
+                if (sweep && h->sweep_dma) hipLaunchKernelGGL(ve_sweep_dma_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, Sx, A);
+                else if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, Sx, A);
+                else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, Sx, A);
+                if ((rc = next_event(h, st, e1, Sx))) return rc;
+                if (two) (sweep ? last_b : last_a) = (long)e1;
                 st.timed.push_back({sweep ? (h->sweep_dma ? kNumKernels + 2 : kKidSweep) : (h->split_kinds ? L.kid : kNumKernels), e0, e1, bytes, (double)grid, h->call_id});
                 n_wg += (double)grid;
                 li = lj;
             }
             {
+                if (two && last_b > a_saw_b) HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)last_b], 0));  // the wave ends on S
                 size_t e_last = 0;
                 if ((rc = next_event(h, st, e_last, S))) return rc;
                 st.timed.push_back({-1, e_first, e_last, 0.0, 0.0, h->call_id});

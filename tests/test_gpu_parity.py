@@ -460,7 +460,7 @@ def test_schedule_and_effort_options_do_not_change_answers(amd):
     be.engine.set_option("stagger", 1)
     # round 2: the sweep kernel on its own stream, other workgroup sizes of its launches, the chunking of a call - the same
     # programs in another schedule: bit for bit
-    for name, value, back in (("streams", 2, 1), ("sweep_iters", 4, 8), ("sweep_iters", 2, 8), ("sweep_adapt", 0, 4096),
+    for name, value, back in (("overlap", 0, 1), ("streams", 2, 1), ("sweep_iters", 4, 8), ("sweep_iters", 2, 8), ("sweep_adapt", 0, 4096),
                               ("first_chunk", 0, 1), ("first_chunk", 2, 1), ("chunk_sets", 3, 2), ("chunk", 4096, 32768)):
         be.engine.set_option(name, value)
         assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base), (name, value)
