@@ -24,12 +24,13 @@
 using namespace mibn;
 
 static std::string g_err;
-static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1, g_chain = 1, g_sweep = 5;
+static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1, g_chain = 1, g_sweep = 5, g_sweep_min = 2;
 extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
 extern "C" void plan_sim_set_tiling(int big_iters, int tile_h) { g_big_iters = big_iters; g_tile_h = tile_h; }
 extern "C" void plan_sim_set_fuse(int fuse) { g_fuse = fuse; }
 extern "C" void plan_sim_set_chain(int chain) { g_chain = chain; }
 extern "C" void plan_sim_set_sweep(int sweep) { g_sweep = sweep; }
+extern "C" void plan_sim_set_sweep_min(int k) { g_sweep_min = k; }
 extern "C" void plan_sim_set_prune(int prune) { g_prune = prune; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
@@ -84,7 +85,7 @@ static int exec_step(const Network &net, const uint32_t *p, int64_t h_begin, int
         // variables, the k stages applied in place on a tile-sized scratch - what ve_sweep_kernel does in LDS
         const int k = na, rb = (w0 >> 24) & 0xff;
         const int64_t Rt = int64_t(1) << rb, tiles = p[3], Rcells = tiles * Rt;
-        if (k < 3 || k > 5 || rb != 13 - 2 * k || lo != kSweepTileCells || cx != (1 << (2 * k))) { g_err = "malformed SWEEP header"; return -9; }
+        if (k < 2 || k > 5 || rb != 13 - 2 * k || lo != kSweepTileCells || cx != (1 << (2 * k))) { g_err = "malformed SWEEP header"; return -9; }
         const int kout = (int)(p[7] & 0xffff), t_total = (int)(p[7] >> 16);
         if (kout > k || t_total > kSweepMaxT) { g_err = "SWEEP: bad output rank or T size"; return -9; }
         const uint32_t *q = p + kHdrWords;
@@ -444,6 +445,7 @@ extern "C" int plan_sim_query_batch(int32_t n_vars, const int32_t *card, const i
     net.fuse = g_fuse;
     net.chain = g_chain;
     net.sweep = g_sweep;
+    net.sweep_min = g_sweep_min;
     net.prune = g_prune;
     net.stagger = stagger;
     net.set_hints(n_hints, hints);
@@ -581,6 +583,7 @@ extern "C" int64_t plan_sim_cache_check(int32_t n_vars, const int32_t *card, con
     net.fuse = g_fuse;
     net.chain = g_chain;
     net.sweep = g_sweep;
+    net.sweep_min = g_sweep_min;
     net.prune = g_prune;
     std::vector<int64_t> out_off(B + 1, 0);
     for (int64_t b = 0; b < B; ++b) {
@@ -631,6 +634,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     net.fuse = g_fuse;
     net.chain = g_chain;
     net.sweep = g_sweep;
+    net.sweep_min = g_sweep_min;
     net.prune = g_prune;
     net.set_hints(n_hints, hints);
     Request rq;
@@ -654,6 +658,7 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     if (!g_err.empty()) return -1;
     net.chain = g_chain;
     net.sweep = g_sweep;
+    net.sweep_min = g_sweep_min;
     net.set_hints(n_hints, hints);
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
     for (int64_t b = 0; b <= B; ++b) { q_off[b] = b * nq; e_off[b] = b * ne; out_off[b] = b * 4; }

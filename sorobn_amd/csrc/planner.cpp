@@ -1061,7 +1061,7 @@ struct Emitter {
     // tile resident in LDS.  Does its own bookkeeping (layout of the output, arena, statistics); returns false - nothing
     // emitted, nothing allocated - when the step does not fit.
     bool emit_sweep(const PF *const *ins, int n_in, const int *X, int k, PF &out) {
-        if (k < 3 || k > 5 || n_in - 1 > kSweepMaxSmall) return false;
+        if (k < 2 || k > 5 || n_in - 1 > kSweepMaxSmall) return false;
         const PF *F = nullptr;
         for (int j = 0; j < n_in; ++j)
             if (ins[j]->cells > net.small_cells) {
@@ -1498,7 +1498,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
         // that mentions them small.  Four and five variables are tried first, three only after the CHAIN form below.
         int sweep_max = 0, sweep_n[5] = {0, 0, 0, 0, 0};
         const PF *sweep_ins[kSweepMaxSmall + 2];
-        if (net.fuse && net.sweep >= 3 && i + 2 < best.size() && net.card[x] == 4 && sw <= 16 && n_in - 1 <= kSweepMaxSmall &&
+        if (net.fuse && net.sweep >= 3 && i + (size_t)std::min(2, net.sweep_min - 1) < best.size() && net.card[x] == 4 && sw <= 16 && n_in - 1 <= kSweepMaxSmall &&
             pool.size() + 1 <= pool.capacity()) {
             int nbig = 0;
             const PF *bigf = nullptr;
@@ -1584,6 +1584,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
             }
         }
         if (sweep_max >= 3 && try_sweep(3, 3)) continue;
+        if (net.sweep_min <= 2 && sweep_max >= 2 && try_sweep(2, 2)) continue;  // (a pair of one big table: before the FIBER pair form)
         if (net.fuse && i + 1 < best.size() && n_in < kMaxIn && pool.size() + 1 <= pool.capacity()) {
             const int32_t x2 = best[i + 1];
             bool link = false;
@@ -1907,7 +1908,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_adapt); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_min); mix((uint64_t)net.sweep_adapt); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }

@@ -79,6 +79,8 @@ struct Network {
     int chain = 1;           // CHAIN form: a third 4-state variable eliminated in the registers of the same pass
     int stagger = 1;         // build_schedule: groups of requests whose levels are staggered inside a chunk (1 = all in phase)
     int sweep = 5;           // SWEEP form: up to this many 4-state variables of one big table per pass, tile resident in LDS (0 = off)
+    int sweep_min = 2;       // fewest variables of a SWEEP pass: 2 also takes the PAIR steps of one big table (two stages: a pass bound by
+                             // HBM rather than by the LDS) away from the level kernel's MFMA pair class
     int sweep_iters = kSweepItersDefault;  // tiles per workgroup of the sweep kernel
     int sweep_adapt = 4096;  // build_schedule: fewer tiles per workgroup (down to 2) in sweep launches of fewer workgroups than this (0: off)
     int builtin_sweeps = 1;  // two depth-first topological orders (grid: row- and column-major) as candidate orders next to the host's
@@ -199,6 +201,8 @@ constexpr uint32_t kFlagSweepCanon = 16;  // stage j contracts digit k-1-j (firs
 constexpr int sweep_loop_digit(int k, int dig) {
     for (int d = k - 1; d >= 0; --d)
         if (d != dig && d != dig - 1) return d;
+    for (int d = k - 1; d >= 0; --d)  // k = 2: the only other digit, lower neighbour or not
+        if (d != dig) return d;
     return -1;
 }
 constexpr int kRowStrideShift = 20;  // w1 bits 20..27

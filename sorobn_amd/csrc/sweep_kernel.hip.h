@@ -358,11 +358,14 @@ constexpr SweepGeom sweep_geom(const int K, const int J) {
             default: return {0, 2, {1, 3, 7}, true};
         }
     }
-    switch (J) {  // K == 3: one field, a wave = all R pairs of one (field, half): no two stages share their cells
-        case 0: return {2, 0, {1, 7, 7}, true};
-        case 1: return {1, 2, {0, 7, 7}, true};
-        default: return {0, 2, {1, 7, 7}, true};
+    if (K == 3) {
+        switch (J) {  // one field, a wave = all R pairs of one (field, half): no two stages share their cells
+            case 0: return {2, 0, {1, 7, 7}, true};
+            case 1: return {1, 2, {0, 7, 7}, true};
+            default: return {0, 2, {1, 7, 7}, true};
+        }
     }
+    return J == 0 ? SweepGeom{1, 0, {7, 7, 7}, true} : SweepGeom{0, 1, {7, 7, 7}, true};  // K == 2: no field at all
 }
 
 // cell index of a lane's first cell in stage (K, J): lane bits = rp, the fields in order, the half of the loop digit
@@ -722,6 +725,7 @@ __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_dma_kernel(const LevelAr
     else if (canon && k == 4 && kout == 4 && surv == 0x3210u) sweep_tiles_dma<4, true>(L, T, stw, 4, 5, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else if (canon && k == 4) sweep_tiles_dma<4, false>(L, T, stw, 4, 5, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else if (canon && k == 3) sweep_tiles_dma<3, false>(L, T, stw, 3, 7, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (canon && k == 2) sweep_tiles_dma<2, false>(L, T, stw, 2, 9, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else sweep_tiles_dma<0, false>(L, T, stw, k, rb, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
 }
 

@@ -34,6 +34,7 @@ def lib():
         L.plan_sim_set_fuse.argtypes = [C.c_int]
         L.plan_sim_set_chain.argtypes = [C.c_int]
         L.plan_sim_set_sweep.argtypes = [C.c_int]
+        L.plan_sim_set_sweep_min.argtypes = [C.c_int]
         L.plan_sim_set_prune.argtypes = [C.c_int]
         _lib = L
     return _lib
@@ -48,6 +49,7 @@ class SimEngine:
         self.fuse = fuse                # joint elimination of two variables per FIBER step
         self.prune = 1                  # 0: multiply every CPT (full_joint_dist / predict_proba)
         self.chain = 1                  # CHAIN form (three variables per pass), on by default like the product
+        self.sweep_min = 2              # fewest variables of a SWEEP pass (2: pair steps too)
         self.sweep = 5                  # SWEEP form (up to five variables per pass, tile in LDS), on by default like the product
         self.f = flat
         self.card = flat.card
@@ -71,6 +73,7 @@ class SimEngine:
         L.plan_sim_set_prune(int(self.prune))
         L.plan_sim_set_chain(int(self.chain))
         L.plan_sim_set_sweep(int(self.sweep))
+        L.plan_sim_set_sweep_min(int(self.sweep_min))
         rc = L.plan_sim_query(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64),
                               p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
                               p(f.values, C.c_double), self.hints.shape[0], p(hints, C.c_int32),
@@ -105,6 +108,7 @@ class SimEngine:
         L.plan_sim_set_prune(int(self.prune))
         L.plan_sim_set_chain(int(self.chain))
         L.plan_sim_set_sweep(int(self.sweep))
+        L.plan_sim_set_sweep_min(int(self.sweep_min))
         ev_ = evars.reshape(-1) if ne else np.zeros(1, np.int32)
         ec_ = ecodes.reshape(-1) if ne else np.zeros(1, np.int32)
         rc = L.plan_sim_query_batch(len(f.card), p(f.card, C.c_int32), p(f.scope_off, C.c_int64), p(f.scope_vars, C.c_int32),
@@ -133,6 +137,8 @@ class SimEngine:
             self.chain = int(value)
         elif name == "sweep":
             self.sweep = int(value)
+        elif name == "sweep_min":
+            self.sweep_min = int(value)
         elif name == "tiny":
             pass  # (the small-network kernel exists on the device only)
         else:
