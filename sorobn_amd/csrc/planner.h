@@ -17,34 +17,9 @@
 #include <string>
 #include <vector>
 
-#include "order_search.h"
+#include "emit_core.h"
 
 namespace mibn {
-
-constexpr int kMaxVars = 1024;            // bitset capacity
-constexpr int kWords = kMaxVars / 64;
-constexpr int kMaxIn = 6;                 // input factors per step (larger products are pre-multiplied)
-constexpr int kMaxAxes = 32;              // output axes per step after merging
-constexpr int kLoTarget = 256;            // lane-varying block: first axes whose product reaches this
-constexpr int kLoMax = 512;               // ... but never more than this many cells (2 per lane)
-constexpr uint64_t kConstFlag = 1ull << 63;  // in_off bit: table lives in the constants pool
-constexpr int kSweepItersDefault = 8;     // SWEEP: tiles per workgroup (Network::sweep_iters)
-
-struct Bits {
-    std::array<uint64_t, kWords> w{};
-    int nw = kWords;
-    void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
-    void clr(int i) { w[i >> 6] &= ~(1ull << (i & 63)); }
-    bool test(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
-    bool any() const { for (int k = 0; k < nw; ++k) if (w[k]) return true; return false; }
-    void or_(const Bits &o) { for (int k = 0; k < nw; ++k) w[k] |= o.w[k]; }
-    void andnot(const Bits &o) { for (int k = 0; k < nw; ++k) w[k] &= ~o.w[k]; }
-    bool intersects(const Bits &o) const { for (int k = 0; k < nw; ++k) if (w[k] & o.w[k]) return true; return false; }
-    int count() const { int c = 0; for (int k = 0; k < nw; ++k) c += __builtin_popcountll(w[k]); return c; }
-    template <class F> void for_each(F f) const {
-        for (int k = 0; k < nw; ++k) { uint64_t m = w[k]; while (m) { int b = __builtin_ctzll(m); f(k * 64 + b); m &= m - 1; } }
-    }
-};
 
 struct Network {
     int n_vars = 0;
@@ -64,6 +39,11 @@ struct Network {
     std::vector<B2> anc2, scope2;
     std::vector<int32_t> hint_flat;
     OrderNet order_view() const;
+    // what the shared host / device emission reads (emit_core.h): the CPT scopes as one CSR, the ancestor sets as n x nw words
+    std::vector<int32_t> scope_off32, scope_flat;
+    std::vector<int64_t> cstride_flat;
+    std::vector<uint64_t> anc_flat;
+    EmitNet emit_view() const;
     int nw = 1;
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
@@ -187,35 +167,6 @@ struct PlanStats {
 //      flag SWEEP_CANON (w1): see kFlagSweepCanon.  The loop digit of a stage is sweep_loop_digit(k, dig), the thread fields are
 //      the other free digits in ascending order.
 //      A work item = Network::sweep_iters consecutive tiles; one workgroup of kSweepWG lanes per item.
-constexpr uint32_t kFlagFinal = 1, kFlagContig = 2, kFlagOuter = 4, kFlagChain = 8;
-constexpr uint32_t kKindSweep = 2;
-constexpr int kSweepTileCells = 8192;  // 64 KiB of LDS
-constexpr int kSweepMaxT = 1024;       // T cells of all stages together (8 KiB)
-constexpr int kSweepMaxSmall = 16;     // small inputs of all stages together
-constexpr int kSweepWG = 512;
-constexpr int kSweepStageWords = 5, kSweepSmallWords = 7;
-constexpr uint32_t kFlagSweepCanon = 16;  // stage j contracts digit k-1-j (first eliminated = slowest axis, the layout rule): the
-                                          // kernel's compile-time stage geometry applies
-// the loop digit of a stage (the digit a lane's four fibers differ in): the highest one that is neither contracted nor -
-// the usual ctrl of a grid sweep - its lower neighbour
-constexpr int sweep_loop_digit(int k, int dig) {
-    for (int d = k - 1; d >= 0; --d)
-        if (d != dig && d != dig - 1) return d;
-    for (int d = k - 1; d >= 0; --d)  // k = 2: the only other digit, lower neighbour or not
-        if (d != dig) return d;
-    return -1;
-}
-constexpr int kRowStrideShift = 20;  // w1 bits 20..27
-constexpr int kHdrWords = 10;
-constexpr uint32_t kKindGeneric = 0, kKindFiber = 1;  // (kKindSweep = 2 above)
-constexpr int kMaxNC = 16;         // N-fiber length held in registers
-constexpr int kMaxT = 2048;        // T cells (16 KiB of LDS)
-constexpr int kMaxSmall = 4;
-constexpr int kFiberLoMax = 256;    // R cells in the lane-varying block of a FIBER step (1 per lane)
-constexpr int kMaxCx = 16;          // eliminated combinations of a FIBER step (register fiber of loads)
-constexpr int kMaxStepWords = 384;  // LDS copy of one step descriptor
-constexpr int kTileMax = 64;        // hi iterations per tile (their offsets are decoded in one go)
-
 // Growable word buffer the planner appends programs to.  The engine backs it with pinned host memory
 // (so the upload is a true async DMA) and keeps it across calls; the default backing is malloc.
 struct ProgBuf {
@@ -247,14 +198,7 @@ private:
 };
 
 // Plan requests [b0, b1) of a CSR batch: worker t plans a contiguous share into bufs[t].
-// One work item of a request, tagged while the request's program is still in the planning worker's cache.
-struct Tag {
-    uint32_t rel_off;  // word offset of the (first) step inside the request's program
-    uint32_t a;        // SEGMENT: number of steps | kItemSegment.  TILED step: hi iterations per tile.  SWEEP step: its tiles
-    uint32_t wgs;      // workgroups: 1, or the number of tiles
-    uint16_t level, kid;
-    float bytes;       // algorithmic bytes
-};
+// (Tag - one work item of a request, tagged while the request's program is still in the planning worker's cache - lives in emit_core.h)
 struct BatchPlan {
     std::vector<std::vector<Tag>> tags;        // per worker: the items of its requests, request by request
     std::vector<uint32_t> tag_first, tag_count;  // per request: its range in tags[thread_of[i]]
@@ -294,7 +238,6 @@ struct Item {
                        // kSegPerWg) or 0.  TILED step: a = hi iterations per tile; b = index of the item's first workgroup
                        // within its level
 };
-constexpr uint32_t kItemSegment = 1u << 31;
 constexpr int kSegPerWg = 4;  // segments per workgroup of the level kernel: one per wave (the items of a level's segments are
                               // contiguous; workgroup g runs items first + 4 g .. + 3, Item::b of the group's first item = how
                               // many of the four exist)
@@ -306,21 +249,8 @@ struct Launch {
     size_t wg_level;      // wg_item index of the level's first workgroup (Item::b is relative to it)
     double alg_bytes;     // algorithmic bytes of the steps in this launch
 };
-constexpr int kKidSeg = 0;         // segments of small GENERIC steps
-constexpr int kKidFiber0 = 1;      // 36 FIBER tile classes: 1 + (n_big-1)*18 + cx_class*6 + nc_class
-constexpr int kKidChain = 36;      // CHAIN steps (takes the id of the impossible FIBER class <2, cxN, outer-mfma>)
-constexpr int kKidGeneric0 = 37;   // 6 GENERIC tile classes: 37 + (n_in - 1)
-constexpr int kKidSweep = 43;      // SWEEP steps: a kernel of their own (ve_sweep_kernel), launched after the level kernel
-constexpr int kNumKernels = 44;
 const char *kernel_name(int kid);
-int kernel_id_of_step(const uint32_t *w);  // which tile kernel executes this step
-int fiber_cx_class(const uint32_t *w);     // 0: cx = 4   1: cx = 16 = 4 x 4   2: anything else (runtime loop)
-int fiber_nc_class(const uint32_t *w);     // 0: NC = 1   1: NC = 4 contiguous   2: NC = 16 contiguous   3: anything else
-                                           // 4: NC = 16, cx 4 or 16, row stride != 0 -> fp64 MFMA 16x16x4
-                                           // 5: OUTER form (always MFMA)
-int64_t step_cost_bytes(const uint32_t *w);
-bool step_is_tiled(const Network &net, const uint32_t *w);
-int step_tile_h(const Network &net, const uint32_t *w);
+// (kernel_id_of_step, fiber_cx_class / fiber_nc_class, step_cost_bytes, step_is_tiled, step_tile_h: emit_core.h)
 
 struct Schedule {
     std::vector<Item> items;
