@@ -24,8 +24,8 @@ constexpr uint64_t kConstFlag = 1ull << 63;  // in_off bit: table lives in the c
 constexpr int kSweepItersDefault = 8;     // SWEEP: tiles per workgroup (Network::sweep_iters)
 
 struct Bits {
+    int nw = kWords;  // words in use (first: in the same cache line as w[0], w[1] - all a network of <= 128 variables touches)
     uint64_t w[kWords] = {};
-    int nw = kWords;
     MIBN_HD void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
     MIBN_HD void clr(int i) { w[i >> 6] &= ~(1ull << (i & 63)); }
     MIBN_HD bool test(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
@@ -141,15 +141,16 @@ MIBN_HD inline uint32_t *EmitBuf::extend(size_t words) {
 
 constexpr int kRawAxes = 40;  // axes of one factor before merging (cells < 2^31 => <= 31 non-trivial axes)
 
-struct PF {  // planning-time factor (plain data)
-    Bits scope;                  // free (non-evidence) variables
+struct alignas(64) PF {  // planning-time factor (plain data).  Field order = cache lines of a typical factor (<= 8 axes): the header and
+             // vars[0..8) share one, strides[0..8) is the next one touched, the scope's live words the third
     int n = 0;                   // axes
-    int32_t vars[kRawAxes];
-    int64_t strides[kRawAxes];   // stride (doubles) per axis
+    int32_t src = -1;            // initial factor: the variable whose CPT it slices (its offset depends on the evidence codes)
     uint64_t off = 0;            // arena offset, or pool offset | kConstFlag
     int64_t cells = 0;           // product of the free cardinalities
     int64_t alloc = 0;           // arena cells owned (0 for constants)
-    int32_t src = -1;            // initial factor: the variable whose CPT it slices (its offset depends on the evidence codes)
+    int32_t vars[kRawAxes];
+    int64_t strides[kRawAxes];   // stride (doubles) per axis
+    Bits scope;                  // free (non-evidence) variables
     MIBN_HD PF() {}              // (user-provided: a new pool entry does not zero the 480 bytes of vars / strides)
 };
 

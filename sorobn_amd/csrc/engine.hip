@@ -46,10 +46,16 @@ struct OrderArgs {
     uint8_t *orders;       // [B][128]
     int32_t *order_len;    // [B]
     OrderScratch *scratch; // [B]
+    uint32_t *zero;        // a counter the launch resets (emit_kernel's item cursor: no memset on the planning stream), or null
+    int32_t lanes;         // requests per wave (the other lanes of the 64 leave at once: the lanes of a wave run different requests -
+                           // every data-dependent branch diverges - so a wave's time grows with the lanes in use; fewer lanes in more
+                           // waves finish sooner, as long as the chip has SIMDs to spare: option plan_lanes)
 };
 
 __global__ __launch_bounds__(64) void order_kernel(const OrderArgs A) {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (A.zero && blockIdx.x == 0 && threadIdx.x == 0) *A.zero = 0;
+    if ((int)threadIdx.x >= A.lanes) return;
+    const int64_t b = (int64_t)blockIdx.x * A.lanes + threadIdx.x;
     if (b >= A.B) return;
     OrderScratch &S = A.scratch[b];
     const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
@@ -58,6 +64,75 @@ __global__ __launch_bounds__(64) void order_kernel(const OrderArgs A) {
     uint8_t *out = A.orders + b * 128;
     for (int i = 0; i < S.n_best; ++i) out[i] = S.best[i];
     A.order_len[b] = S.n_best;
+}
+
+// Device program emission (emit_core.h: the code the host's planning workers run): one request per lane turns its elimination
+// order (order_kernel's output, never copied to the host) into its step program, written straight into the request's slot
+// of the chunk's device program buffer, and cuts it into work items.  The host only lays out the schedule of the chunk
+// (build_schedule, from the work items): a rank needs no planning threads.
+struct EmitMeta {  // per request
+    uint32_t words, n_tags, tag_first;
+    int32_t err;  // kEmitErr* (any error: the host plans the chunk itself)
+    double alg_bytes, alg_flops, n_steps, max_step_cells;
+    int64_t arena_cells;
+};
+struct EmitArgs {
+    EmitNet net;
+    const int64_t *q_off, *e_off, *out_off;  // [B + 1]; out_off relative to the chunk's first request
+    const int32_t *q_vars, *e_vars, *e_codes;
+    const char *skip;                        // [B] evidence outside the domain: zero steps
+    const uint8_t *orders;                   // [B][128]
+    const int32_t *order_len;                // [B]
+    int64_t B;
+    uint32_t flags;
+    uint32_t *prog;                          // [B][prog_stride]
+    uint32_t prog_stride;
+    EmitMeta *meta;                          // [B]
+    Tag *tags;                               // [tag_cap]: the work items of all requests, a request's contiguous
+    uint32_t *tag_cursor;
+    uint32_t tag_cap;
+    char *scratch;                           // [B][scratch_stride] planning state (EmitScratch)
+    size_t scratch_stride;
+    int32_t lanes;                           // requests per wave (see OrderArgs)
+};
+
+__global__ __launch_bounds__(64, 4) void emit_kernel(const EmitArgs A) {
+    if ((int)threadIdx.x >= A.lanes) return;
+    const int64_t b = (int64_t)blockIdx.x * A.lanes + threadIdx.x;
+    if (b >= A.B) return;
+    EmitMeta m;
+    m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
+    m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
+    m.arena_cells = 0;
+    uint32_t *slot = A.prog + (size_t)b * A.prog_stride;
+    if (A.skip[b]) { slot[0] = 0; A.meta[b] = m; return; }
+    EmitScratch S;
+    emit_scratch_carve(S, A.scratch + (size_t)b * A.scratch_stride, A.net.n_vars);
+    const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
+    const int nq = (int)(A.q_off[b + 1] - q0), ne = (int)(A.e_off[b + 1] - e0);
+    int err = emit_begin(A.net, S, nq, A.q_vars + q0, ne, A.e_vars + e0, A.e_codes + e0, (A.flags & MIBN_Q_NOPRUNE) != 0);
+    EmitBuf buf;
+    buf.data = slot;
+    buf.cap = A.prog_stride;
+    EmitStats st;
+    if (!err) err = emit_run(A.net, S, buf, st, nullptr, nq, A.q_vars + q0, A.out_off[b], A.orders + b * 128, (int)A.order_len[b]);
+    if (!err) {
+        const uint32_t nt = tag_program(A.net, slot, [](const Tag &) {});
+        const uint32_t first = atomicAdd(A.tag_cursor, nt);
+        if (first + nt <= A.tag_cap) {
+            uint32_t k = first;
+            tag_program(A.net, slot, [&](const Tag &t) { A.tags[k++] = t; });
+            m.n_tags = nt;
+            m.tag_first = first;
+        } else {
+            err = kEmitErrWords;
+        }
+    }
+    m.err = err;
+    m.words = (uint32_t)buf.size;
+    m.alg_bytes = st.alg_bytes; m.alg_flops = st.alg_flops; m.n_steps = st.n_steps; m.max_step_cells = st.max_step_cells;
+    m.arena_cells = st.arena_cells;
+    A.meta[b] = m;
 }
 
 // Chunk sets (pinned program buffers, device copies, schedule, launch events): with n sets in use the host plans chunk
@@ -136,8 +211,10 @@ struct mibn_ctx {
     // requests instead; both are given back when the host has slack again
     int adaptive = 0;
     bool auto_search = false;  // gpu_search was switched on by the adaptive policy
+    bool auto_emit = false;    // gpu_emit was
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
     // device order search (order_kernel)
+    int plan_lanes = 16;             // requests per wave of order_kernel / emit_kernel (1..64)
     int gpu_search = 0;              // option: 1 = search elimination orders on the device (networks of <= 128 variables)
     hipStream_t search_stream = nullptr;
     char *d_order_net = nullptr;     // the OrderNet arrays
@@ -153,6 +230,24 @@ struct mibn_ctx {
     size_t order_scratch_cap = 0;
     Staging search_in, search_out;   // pinned: request arrays in, orders + lengths out
     double search_ms = 0;            // host wall time spent waiting for the device search (last call)
+    // device program emission (emit_kernel)
+    int gpu_emit = 0;                // option: 1 = the device plans whole chunks (order search + emission), 2 = the same, checked
+                                     // word for word against the host's planner (tests)
+    char *d_emit_net = nullptr;      // the EmitNet arrays
+    EmitNet emit_net_dev;            // pointers into d_emit_net
+    bool emit_net_ok = false;
+    char *d_emit_scratch = nullptr;  // planning state, one slice per lane
+    size_t emit_scratch_cap = 0;
+    uint32_t *d_emit_cursor = nullptr;
+    Staging emit_in, emit_out;       // pinned, read / written by the kernels themselves: request arrays in, per-request results and work items out
+    hipEvent_t emit_ev[2] = {nullptr, nullptr};  // around the planner's kernels
+    double emit_share = 0.75;        // the device's share of a chunk, the host's workers plan the rest meanwhile: follows the two measured
+                                     // rates so that both finish together (option emit_share: 0 < x <= 1 pins it)
+    double emit_share_opt = -1;
+    BatchPlan emit_dev, emit_host;   // the two parts of a chunk before they are joined
+    uint32_t emit_words = 6144;      // words of a request's program slot (doubles after a chunk that did not fit)
+    double emit_ms = 0;              // host wall time spent waiting for the device planner (last call)
+    uint64_t emit_chunks = 0, emit_fallbacks = 0;
     hipEvent_t gap_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // trace: ends of the last waves (GPU idle time between waves)
     uint64_t n_waves = 0;
     int n_sets = 2;           // chunk sets in use (option "chunk_sets": 2..4; two per lane: one on the GPU, one being planned)
@@ -248,6 +343,39 @@ static int upload_order_net(mibn_ctx *h) {
     return MIBN_OK;
 }
 
+// The arrays emit_core.h reads, in one device buffer (rebuilt by set_network).  Networks the device order search covers only.
+static int upload_emit_net(mibn_ctx *h) {
+    h->emit_net_ok = false;
+    if (h->planner_only || h->net.n_vars > 128 || h->net.n_vars < 1) return MIBN_OK;
+    const Network &net = h->net;
+    const size_t n = (size_t)net.n_vars;
+    std::vector<char> buf;
+    auto put = [&](const void *p, size_t bytes) {
+        const size_t off = (buf.size() + 15) & ~size_t(15);
+        buf.resize(off + bytes);
+        if (bytes) std::memcpy(buf.data() + off, p, bytes);
+        return off;
+    };
+    const size_t o_card = put(net.card.data(), n * 4), o_log = put(net.log2card.data(), n * 8), o_pool = put(net.pool_off.data(), n * 8);
+    const size_t o_soff = put(net.scope_off32.data(), (n + 1) * 4), o_sv = put(net.scope_flat.data(), net.scope_flat.size() * 4);
+    const size_t o_ss = put(net.cstride_flat.data(), net.cstride_flat.size() * 8), o_anc = put(net.anc_flat.data(), net.anc_flat.size() * 8);
+    if (h->d_emit_net) { HIP_TRY(h, hipFree(h->d_emit_net)); h->d_emit_net = nullptr; }
+    HIP_TRY(h, hipMalloc(&h->d_emit_net, buf.size()));
+    HIP_TRY(h, hipMemcpy(h->d_emit_net, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    EmitNet &e = h->emit_net_dev;
+    e = net.emit_view();
+    char *d = h->d_emit_net;
+    e.card = reinterpret_cast<const int32_t *>(d + o_card);
+    e.log2card = reinterpret_cast<const double *>(d + o_log);
+    e.pool_off = reinterpret_cast<const int64_t *>(d + o_pool);
+    e.scope_off = reinterpret_cast<const int32_t *>(d + o_soff);
+    e.scope_vars = reinterpret_cast<const int32_t *>(d + o_sv);
+    e.scope_stride = reinterpret_cast<const int64_t *>(d + o_ss);
+    e.anc = reinterpret_cast<const uint64_t *>(d + o_anc);
+    h->emit_net_ok = true;
+    return MIBN_OK;
+}
+
 extern "C" {
 
 const char *mibn_version(void) { return "mibn 0.1 (gfx950)"; }
@@ -316,6 +444,11 @@ void mibn_destroy(mibn_t *h) {
         (void)hipFree(h->d_orders);
         (void)hipFree(h->d_order_len);
         (void)hipFree(h->d_order_scratch);
+        (void)hipFree(h->d_emit_net);
+        (void)hipFree(h->d_emit_scratch);
+        (void)hipFree(h->d_emit_cursor);
+        if (h->emit_in.p) (void)hipHostFree(h->emit_in.p);
+        if (h->emit_out.p) (void)hipHostFree(h->emit_out.p);
         if (h->search_in.p) (void)hipHostFree(h->search_in.p);
         if (h->search_out.p) (void)hipHostFree(h->search_out.p);
         if (h->search_stream) (void)hipStreamDestroy(h->search_stream);
@@ -364,6 +497,10 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "sweep_dma") h->sweep_dma = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
     else if (n == "tiny") h->tiny = value != 0;
+    else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
+    else if (n == "plan_lanes") h->plan_lanes = std::max(1, std::min(64, (int)value));  // requests per wave of the device planner's kernels
+    else if (n == "emit_share") { h->emit_share_opt = value > 0 ? std::min(1.0, value) : -1; if (value > 0) h->emit_share = h->emit_share_opt; }  // the device's share of a chunk (<= 0: follows the measured rates)
+    else if (n == "emit_words") h->emit_words = (uint32_t)std::max(1024, std::min(1 << 20, (int)value));  // words of a request's device program slot
     else if (n == "gpu_search") h->gpu_search = std::max(0, std::min(2, (int)value));  // elimination-order search on the device
         // (order_kernel): 1 = the first chunk of a call on the host, the rest of the call by one launch; 2 = every chunk, synchronously (tests)
     else if (n == "adaptive") { h->adaptive = value != 0; if (!h->adaptive) h->net.minfill_above = h->base_minfill; }
@@ -418,6 +555,7 @@ int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64
             if (!h->d_tiny_bad) HIP_TRY(h, hipMalloc(&h->d_tiny_bad, 8));
             h->tiny_ok = tiny_lds_bytes((int)h->net.pool.size(), h->tiny_meta_words) <= 64 * 1024;
         }
+        if (int rc = upload_emit_net(h)) return rc;
         return upload_order_net(h);
     }
     return MIBN_OK;
@@ -678,7 +816,9 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
         A.orders = h->d_orders + s0 * 128;
         A.order_len = h->d_order_len + s0;
         A.scratch = h->d_order_scratch;
-        hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, h->search_stream, A);
+        A.zero = nullptr;
+        A.lanes = h->plan_lanes;
+        hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + A.lanes - 1) / A.lanes)), dim3(64), 0, h->search_stream, A);
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipMemcpyAsync(h->search_out.p, h->d_orders, (size_t)n * 128, hipMemcpyDeviceToHost, h->search_stream));
@@ -688,6 +828,174 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
 
 int search_wait(mibn_ctx *h) {
     HIP_TRY(h, hipStreamSynchronize(h->search_stream));
+    return MIBN_OK;
+}
+
+// Device planning of requests [b0, b1) - one chunk - into set `st`: order_kernel, then emit_kernel, on the planning stream (high
+// priority: its few waves must not queue behind the level kernels of the chunk in flight); the programs stay on the device
+// (st.d_prog, one slot of h->emit_words words per request), the per-request results and the work items come back and fill
+// the BatchPlan like plan_batch would.  Returns MIBN_OK, an error, or 1: a request did not fit its slot / the item buffer
+// (the caller plans the chunk on the host; the slots double for the next chunk).
+constexpr int64_t kPlanSlice = 32768;  // requests per launch pair: 1.1 GB of search state + ~8 GB of emission state (100 variables)
+int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off,
+                          const int32_t *e_vars, const int32_t *e_codes, const int64_t *out_off, const char *skip, mibn_ctx::Set &st, size_t prog_words) {
+    const int64_t n = b1 - b0;
+    int rc;
+    if (!h->search_stream) {
+        int lo = 0, hi = 0;
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->search_stream, hipStreamNonBlocking, hi));
+    }
+    hipStream_t P = h->search_stream;
+    const size_t nq = (size_t)(q_off[b1] - q_off[b0]), ne = (size_t)(e_off[b1] - e_off[b0]);
+    const size_t off_bytes = (size_t)(n + 1) * 8;
+    const size_t in_bytes = 3 * off_bytes + (nq + 2 * ne) * 4 + (size_t)n + 64;
+    const size_t stride = h->emit_words;
+    const size_t tag_cap = (size_t)n * 64;
+    const size_t scratch_stride = emit_scratch_bytes(h->net.n_vars);
+    const int64_t slice = std::min(n, kPlanSlice);
+    if ((rc = pinned(h, h->emit_in, in_bytes))) return rc;
+    if ((rc = pinned(h, h->emit_out, (size_t)n * sizeof(EmitMeta) + tag_cap * sizeof(Tag) + 64))) return rc;
+    if ((rc = ensure(h, h->d_orders, h->orders_cap, (size_t)n * 128))) return rc;
+    if ((rc = ensure(h, h->d_order_len, h->order_len_cap, (size_t)n))) return rc;
+    if ((rc = ensure(h, h->d_order_scratch, h->order_scratch_cap, (size_t)slice))) return rc;
+    if (!h->d_emit_cursor) HIP_TRY(h, hipMalloc(&h->d_emit_cursor, 64));
+    if ((size_t)slice * scratch_stride > h->emit_scratch_cap) {
+        if (h->d_emit_scratch) { HIP_TRY(h, hipFree(h->d_emit_scratch)); h->d_emit_scratch = nullptr; h->emit_scratch_cap = 0; }
+        const size_t want = (size_t)std::max<int64_t>(slice, std::min<int64_t>(h->chunk, kPlanSlice)) * scratch_stride;
+        HIP_TRY(h, hipMalloc(&h->d_emit_scratch, want));
+        h->emit_scratch_cap = want;
+    }
+    if ((rc = ensure(h, st.d_prog, st.prog_cap, std::max(prog_words, (size_t)n * stride)))) return rc;  // (+ room for the host's share of the chunk)
+    if (!h->emit_ev[0]) { HIP_TRY(h, hipEventCreate(&h->emit_ev[0])); HIP_TRY(h, hipEventCreate(&h->emit_ev[1])); }
+    // one pinned staging buffer, one DMA: [q_off | e_off | out_off | q_vars | e_vars | e_codes | skip]
+    char *pin = h->emit_in.p;
+    int64_t *qo = reinterpret_cast<int64_t *>(pin), *eo = qo + (n + 1), *oo = eo + (n + 1);
+    for (int64_t i = 0; i <= n; ++i) { qo[i] = q_off[b0 + i] - q_off[b0]; eo[i] = e_off[b0 + i] - e_off[b0]; oo[i] = out_off[b0 + i] - out_off[b0]; }
+    char *pv = pin + 3 * off_bytes;
+    std::memcpy(pv, q_vars + q_off[b0], nq * 4);
+    if (ne) { std::memcpy(pv + nq * 4, e_vars + e_off[b0], ne * 4); std::memcpy(pv + (nq + ne) * 4, e_codes + e_off[b0], ne * 4); }
+    std::memcpy(pv + (nq + 2 * ne) * 4, skip + b0, (size_t)n);
+    // No copies on the planning stream: its kernels read the request arrays from, and write their results to, pinned host
+    // memory.  (A DMA copy on this stream queued behind the previous call's result download - which waits for that call's
+    // kernels - on the copy engine: the planner started when the chunk in flight had finished, never beside it.)
+    HIP_TRY(h, hipEventRecord(h->emit_ev[0], P));
+    const char *d = pin;
+    EmitMeta *meta_out = reinterpret_cast<EmitMeta *>(h->emit_out.p);
+    Tag *tags_out = reinterpret_cast<Tag *>(h->emit_out.p + (size_t)n * sizeof(EmitMeta) + 64);
+    for (int64_t s0 = 0; s0 < n; s0 += kPlanSlice) {
+        const int64_t m = std::min(kPlanSlice, n - s0);
+        OrderArgs O;
+        O.net = h->order_net_dev;
+        O.net.prune = h->net.prune;
+        O.net.minfill_above = h->net.minfill_above;
+        {   // (options set after the network: the model weights follow them like on the host)
+            const OrderNet hv = h->net.order_view();
+            O.net.chain_weight = hv.chain_weight;
+            O.net.big_cells = hv.big_cells;
+        }
+        O.q_off = reinterpret_cast<const int64_t *>(d) + s0;
+        O.e_off = reinterpret_cast<const int64_t *>(d + off_bytes) + s0;
+        O.q_vars = reinterpret_cast<const int32_t *>(d + 3 * off_bytes);
+        O.e_vars = O.q_vars + nq;
+        O.B = m;
+        O.flags = flags;
+        O.orders = h->d_orders + s0 * 128;
+        O.order_len = h->d_order_len + s0;
+        O.scratch = h->d_order_scratch;
+        O.zero = s0 == 0 ? h->d_emit_cursor : nullptr;
+        O.lanes = h->plan_lanes;
+        hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + O.lanes - 1) / O.lanes)), dim3(64), 0, P, O);
+        EmitArgs A;
+        {   // the pointers of the device copy, the options of the moment
+            A.net = h->net.emit_view();
+            const EmitNet &dv = h->emit_net_dev;
+            A.net.card = dv.card; A.net.log2card = dv.log2card; A.net.pool_off = dv.pool_off; A.net.scope_off = dv.scope_off;
+            A.net.scope_vars = dv.scope_vars; A.net.scope_stride = dv.scope_stride; A.net.anc = dv.anc;
+        }
+        A.q_off = O.q_off;
+        A.e_off = O.e_off;
+        A.out_off = reinterpret_cast<const int64_t *>(d + 2 * off_bytes) + s0;
+        A.q_vars = O.q_vars;
+        A.e_vars = O.e_vars;
+        A.e_codes = A.e_vars + ne;
+        A.skip = reinterpret_cast<const char *>(A.e_codes + ne) + s0;
+        A.orders = O.orders;
+        A.order_len = O.order_len;
+        A.B = m;
+        A.flags = flags;
+        A.prog = st.d_prog + (size_t)s0 * stride;
+        A.prog_stride = (uint32_t)stride;
+        A.meta = meta_out + s0;
+        A.tags = tags_out;
+        A.tag_cursor = h->d_emit_cursor;
+        A.tag_cap = (uint32_t)tag_cap;
+        A.scratch = h->d_emit_scratch;
+        A.scratch_stride = scratch_stride;
+        A.lanes = h->plan_lanes;
+        hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((m + A.lanes - 1) / A.lanes)), dim3(64), 0, P, A);
+        HIP_TRY(h, hipGetLastError());
+    }
+    HIP_TRY(h, hipEventRecord(h->emit_ev[1], P));
+    return MIBN_OK;
+}
+
+// Waits for the device planner and fills `ck` for the n requests it planned, like plan_batch would (one "worker": the device).
+// *dev_ms = duration of the kernels.  Returns MIBN_OK, an error, or 1 (see above).
+int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, double *dev_ms) {
+    hipStream_t P = h->search_stream;
+    const size_t stride = h->emit_words;
+    const size_t tag_cap = (size_t)n * 64;
+    const EmitMeta *meta = reinterpret_cast<const EmitMeta *>(h->emit_out.p);
+    const Tag *tags = reinterpret_cast<const Tag *>(h->emit_out.p + (size_t)n * sizeof(EmitMeta) + 64);
+    HIP_TRY(h, hipStreamSynchronize(P));
+    {
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->emit_ev[0], h->emit_ev[1]));
+        if (dev_ms) *dev_ms = ms;
+    }
+    size_t n_tags = 0;  // (a request's items are contiguous, the requests' ranges in the order the lanes finished)
+    for (int64_t i = 0; i < n; ++i)
+        if (!meta[i].err) n_tags = std::max<size_t>(n_tags, (size_t)meta[i].tag_first + meta[i].n_tags);
+    n_tags = std::min(n_tags, tag_cap);
+    // the BatchPlan plan_batch would have filled (one "worker": the device)
+    ck.st = PlanStats{};
+    ck.arena_cells = 0;
+    ck.err.clear();
+    ck.prog_off.assign(n, 0);
+    ck.cost.assign(n, 0.0);
+    ck.arena_need.assign(n, 0);
+    ck.thread_of.assign(n, 0);
+    ck.local_off.assign(n, 0);
+    ck.thread_words.clear();  // (nothing to upload: the programs are on the device)
+    ck.tag_first.assign(n, 0);
+    ck.tag_count.assign(n, 0);
+    ck.tags.resize(1);
+    ck.tags[0].assign(tags, tags + n_tags);
+    bool refused = false;
+    for (int64_t i = 0; i < n; ++i) {
+        const EmitMeta &m = meta[i];
+        if (m.err == kEmitErrWords) { refused = true; continue; }
+        if (m.err) { h->err = "request " + std::to_string(b0 + i) + ": " + emit_error_message(m.err); return MIBN_E_LIMIT; }
+        ck.prog_off[i] = (uint64_t)i * stride;
+        ck.local_off[i] = ck.prog_off[i];
+        ck.tag_first[i] = m.tag_first;
+        ck.tag_count[i] = m.n_tags;
+        ck.cost[i] = m.alg_bytes;
+        ck.arena_need[i] = m.arena_cells;
+        ck.st.alg_bytes += m.alg_bytes;
+        ck.st.alg_flops += m.alg_flops;
+        ck.st.n_steps += m.n_steps;
+        ck.st.max_step_cells = std::max(ck.st.max_step_cells, m.max_step_cells);
+        ck.arena_cells = std::max(ck.arena_cells, m.arena_cells);
+    }
+    ck.total_words = (size_t)n * stride;
+    if (refused) {
+        h->emit_words = std::min<uint32_t>(h->emit_words * 2, 1u << 20);
+        ++h->emit_fallbacks;
+        return 1;
+    }
+    ++h->emit_chunks;
     return MIBN_OK;
 }
 
@@ -800,6 +1108,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     const double t_start = now_ms();
     ++h->call_id;
     h->search_ms = 0;
+    h->emit_ms = 0;
     h->stats = mibn_stats{};
     for (int k = 0; k <= kNumKernels + 2; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
@@ -832,6 +1141,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         }
     }
     ensure_pool(h);
+    if (h->trace) std::fprintf(stderr, "[mibn plan] validation of %lld requests %.2f ms\n", (long long)B, now_ms() - t_start);
     if (h->adaptive) {
         // over the calls since the last adjustment: host planning wall time against GPU kernel time (retired launches)
         const double dp = h->total.plan_ms - h->seen_plan_ms, dk = h->total.kernel_ms - h->seen_kernel_ms;
@@ -839,10 +1149,15 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             h->seen_plan_ms = h->total.plan_ms;
             h->seen_kernel_ms = h->total.kernel_ms;
         } else if (dp > 20.0 && dk > 20.0) {
-            if (dp > 1.15 * dk) {
+            if (h->auto_emit && h->emit_share <= 0.3) {
+                // (the share follows the host's rate: its workers would plan most of a chunk in the planner kernels' time)
+                h->gpu_emit = 0;
+                h->auto_emit = false;
+            } else if (dp > 1.15 * dk) {
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
                 // not cover give up the min-fill search for ever more expensive requests instead
-                if (h->order_net_ok && !h->gpu_search) { h->gpu_search = 1; h->auto_search = true; }
+                if (h->order_net_ok && h->emit_net_ok && !h->gpu_emit) { h->gpu_emit = 1; h->auto_emit = true; }  // the whole planning, not only the search
+                else if (h->order_net_ok && !h->emit_net_ok && !h->gpu_search) { h->gpu_search = 1; h->auto_search = true; }
                 else if (!h->order_net_ok) h->net.minfill_above = std::min(h->net.minfill_above * 8.0, 1e18);
             } else if (dp < 0.3 * dk) {
                 if (h->net.minfill_above > h->base_minfill) h->net.minfill_above = std::max(h->net.minfill_above / 8.0, h->base_minfill);
@@ -878,7 +1193,8 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes[0] + h->arena_bytes[1])) / 8.0) / n_lanes;
     bool lane1_used = false;
     int64_t n_chunks = 0;
-    const bool search_on = h->gpu_search && h->order_net_ok;
+    const bool emit_on = h->gpu_emit && h->order_net_ok && h->emit_net_ok;  // whole chunks planned on the device
+    const bool search_on = !emit_on && h->gpu_search && h->order_net_ok;
     int64_t search_b0 = -1;
     bool search_done = false;
     // a short first chunk gets an idle GPU going while the host plans the first full-size one (first_chunk = 2: also when
@@ -898,6 +1214,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         const bool dev_split = search_on && h->gpu_search == 1;
         int64_t size = h->chunk;
         if (b0 == 0 && dev_split) size = std::max<int64_t>(1024, h->chunk / 8);
+        else if (emit_on) size = h->chunk;  // (the host has nothing to plan while a short first chunk runs)
         else if (b0 == 0 && short_first && (B > h->chunk || !gpu_busy)) size = std::max<int64_t>(1024, h->chunk / 4);
         b1 = std::min(B, b0 + size);
         const int64_t n = b1 - b0;
@@ -928,17 +1245,104 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             }
         }
         BatchPlan &ck = st.plan;
-        plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck,
-                   (flags & MIBN_Q_NOPRUNE) != 0, orders, order_len);
+        bool on_device = false;
+        int64_t nd = 0;          // requests [b0, b0 + nd) planned by the device, the rest by the host's workers meanwhile
+        size_t prog_base = 0;    // words of st.d_prog the device has written (the host's programs follow)
+        if (emit_on) {
+            nd = h->gpu_emit == 2 ? n : std::min<int64_t>(n, std::max<int64_t>(64, (int64_t)((double)n * std::min(h->emit_share, h->emit_share_opt > 0 ? 1.0 : 0.95) + 0.5)));
+            if (n - nd < 256) nd = n;  // (without a pinned share the host keeps at least a twentieth: its rate stays measured)
+            const size_t stride = h->emit_words;
+            if ((rc = plan_on_device_launch(h, flags, b0, b0 + nd, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), st, (size_t)n * stride))) return rc;
+            const double t_launched = now_ms();
+            BatchPlan &hp = h->emit_host, &dp = h->emit_dev;
+            double host_ms = 0, dev_ms = 0;
+            if (nd < n) {
+                const double th = now_ms();
+                plan_batch(h->net, *h->pool, st.bufs, b0 + nd, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), hp,
+                           (flags & MIBN_Q_NOPRUNE) != 0, nullptr, nullptr, b0);
+                host_ms = now_ms() - th;
+                if (!hp.err.empty()) { h->err = hp.err; (void)hipStreamSynchronize(h->search_stream); return MIBN_E_LIMIT; }
+            }
+            const double tw = now_ms();
+            rc = plan_on_device_collect(h, b0, nd, nd < n ? dp : ck, &dev_ms);
+            h->emit_ms += now_ms() - tw;
+            if (h->trace) std::fprintf(stderr, "[mibn plan] chunk of %lld: device %lld requests (upload + launch %.2f ms, kernels %.2f ms, wait + collect %.2f ms), host %lld requests %.2f ms\n",
+                                       (long long)n, (long long)nd, t_launched - t0, dev_ms, now_ms() - tw, (long long)(n - nd), host_ms);
+            if (rc < 0 || rc > 1) return rc;
+            if (rc == 0 && nd < n && hp.total_words > (size_t)(n - nd) * stride) rc = 1;  // (the host's programs do not fit behind the device's)
+            on_device = rc == 0;
+            if (on_device && nd < n) {
+                // join the two parts: the device's requests first
+                const int T = (int)hp.tags.size();
+                ck.st = dp.st;
+                ck.st.alg_bytes += hp.st.alg_bytes; ck.st.alg_flops += hp.st.alg_flops; ck.st.n_steps += hp.st.n_steps;
+                ck.st.max_step_cells = std::max(dp.st.max_step_cells, hp.st.max_step_cells);
+                ck.arena_cells = std::max(dp.arena_cells, hp.arena_cells);
+                ck.err.clear();
+                ck.tags.resize((size_t)T + 1);
+                for (int t = 0; t < T; ++t) ck.tags[(size_t)t].swap(hp.tags[(size_t)t]);
+                ck.tags[(size_t)T].swap(dp.tags[0]);
+                ck.thread_words = hp.thread_words;
+                auto join = [&](auto &dst, const auto &a, const auto &b) { dst.assign(a.begin(), a.end()); dst.insert(dst.end(), b.begin(), b.end()); };
+                join(ck.cost, dp.cost, hp.cost);
+                join(ck.arena_need, dp.arena_need, hp.arena_need);
+                join(ck.tag_first, dp.tag_first, hp.tag_first);
+                join(ck.tag_count, dp.tag_count, hp.tag_count);
+                join(ck.local_off, dp.local_off, hp.local_off);
+                ck.thread_of.assign((size_t)nd, T);
+                ck.thread_of.insert(ck.thread_of.end(), hp.thread_of.begin(), hp.thread_of.end());
+                prog_base = (size_t)nd * stride;
+                ck.prog_off = dp.prog_off;
+                for (uint64_t o : hp.prog_off) ck.prog_off.push_back(prog_base + o);
+                ck.total_words = prog_base + hp.total_words;
+                // the share that would have let both finish together (the device's kernels ran beside the chunk in flight, like they will)
+                // The planner's kernels are latency-bound - one request per lane, their duration hardly depends on how many
+                // requests they plan - so the host's share is what its workers plan in that time, at the rate just measured.
+                if (h->emit_share_opt <= 0 && host_ms > 1.0 && dev_ms > 1.0) {
+                    const double host_n = (double)(n - nd) / host_ms * dev_ms;
+                    h->emit_share = std::max(0.25, std::min(1.0, 0.5 * h->emit_share + 0.5 * (1.0 - host_n / (double)n)));
+                }
+            }
+        }
+        if (!on_device)
+            plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck,
+                       (flags & MIBN_Q_NOPRUNE) != 0, orders, order_len);
+        if (on_device && h->gpu_emit == 2) {
+            // test mode: the host plans the chunk too - programs, work items and statistics must agree exactly
+            const size_t stride = h->emit_words;
+            std::vector<uint32_t> dev((size_t)n * stride);
+            HIP_TRY(h, hipMemcpy(dev.data(), st.d_prog, dev.size() * 4, hipMemcpyDeviceToHost));
+            BatchPlan ref;
+            plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ref,
+                       (flags & MIBN_Q_NOPRUNE) != 0, nullptr, nullptr);
+            if (!ref.err.empty()) { h->err = ref.err; return MIBN_E_LIMIT; }
+            for (int64_t i = 0; i < n; ++i) {
+                const uint32_t *hw = st.bufs[ref.thread_of[i]].data + ref.local_off[i], *dw = dev.data() + (size_t)i * stride;
+                size_t words = 1;
+                for (uint32_t k = 0; k < hw[0]; ++k) words += hw[words + 6];
+                for (size_t k = 0; k < words; ++k)
+                    if (hw[k] != dw[k]) {
+                        h->err = "device planner: request " + std::to_string(b0 + i) + " word " + std::to_string(k) + " of " + std::to_string(words) + ": host " +
+                                 std::to_string(hw[k]) + " device " + std::to_string(dw[k]);
+                        return MIBN_E_STATE;
+                    }
+                const Tag *ht = ref.tags[ref.thread_of[i]].data() + ref.tag_first[i], *dt = ck.tags[0].data() + ck.tag_first[i];
+                bool same = ref.tag_count[i] == ck.tag_count[i] && ref.arena_need[i] == ck.arena_need[i] && ref.cost[i] == ck.cost[i];
+                for (uint32_t k = 0; same && k < ref.tag_count[i]; ++k)
+                    same = ht[k].rel_off == dt[k].rel_off && ht[k].a == dt[k].a && ht[k].wgs == dt[k].wgs && ht[k].level == dt[k].level &&
+                           ht[k].kid == dt[k].kid && ht[k].bytes == dt[k].bytes;
+                if (!same) { h->err = "device planner: work items / statistics of request " + std::to_string(b0 + i) + " differ from the host's"; return MIBN_E_STATE; }
+            }
+        }
         if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->stream2); return MIBN_E_LIMIT; }
         for (auto &b : st.bufs)
             if (b.cap && !b.data) { h->err = "pinned host allocation failed"; return MIBN_E_HIP; }
         h->stats.plan_ms += now_ms() - t0;
-        if ((rc = ensure(h, st.d_prog, st.prog_cap, ck.total_words))) return rc;
+        if (!on_device && (rc = ensure(h, st.d_prog, st.prog_cap, ck.total_words))) return rc;
         if ((rc = ensure(h, st.d_prog_off, st.prog_off_cap, (size_t)n))) return rc;
         if ((rc = ensure(h, st.d_arena_off, st.arena_off_cap, (size_t)n))) return rc;
         t0 = now_ms();
-        size_t base = 0;
+        size_t base = prog_base;
         for (size_t t = 0; t < ck.thread_words.size(); ++t) {
             if (ck.thread_words[t])
                 HIP_TRY(h, hipMemcpyAsync(st.d_prog + base, st.bufs[t].data, ck.thread_words[t] * 4, hipMemcpyHostToDevice, h->copy_stream));
@@ -960,6 +1364,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             Schedule &sc = st.sched;
             build_schedule(h->net, ck, st.bufs, r0, r1, sc);
             h->stats.plan_ms += now_ms() - t0;
+            if (h->trace) std::fprintf(stderr, "[mibn plan] build_schedule %.2f ms (%zu items, %zu workgroups, %zu launches)\n", now_ms() - t0, sc.items.size(), sc.wg_item.size(), sc.launches.size());
             const size_t need_bytes = (size_t)std::max<int64_t>(16, sc.arena_cells) * sizeof(double);
             if (need_bytes > h->arena_bytes[lane]) {
                 // grow with headroom (chunks differ by ~10 %): re-allocating tens of GB costs hundreds of ms
@@ -1074,6 +1479,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         HIP_TRY(h, hipEventRecord(h->lane_ev, h->stream2));
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->lane_ev, 0));
     }
+    if (h->trace) std::fprintf(stderr, "[mibn plan] call of %lld requests: %.2f ms to the last launch (plan %.2f, h2d %.2f)\n", (long long)B, now_ms() - t_start, h->stats.plan_ms, h->stats.h2d_ms);
     if (ticket) {
         mibn_ctx::Pending &pd = h->pend[slot];
         mibn_ctx::Staging &sg = h->res_stage[slot];

@@ -824,7 +824,7 @@ PlanCache &plan_cache(const TemplateStore *ts) {
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
                 const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &ck, bool no_prune,
-                const uint8_t *orders, const int32_t *order_len) {
+                const uint8_t *orders, const int32_t *order_len, int64_t out_first) {
     const int64_t n = b1 - b0;
     const int T = pool.size();
     if ((int)bufs.size() < T) bufs.resize(T);
@@ -870,7 +870,7 @@ void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs
             rq.ne = (int32_t)(e_off[b + 1] - e_off[b]);
             rq.evars = e_vars + e_off[b];
             rq.ecodes = e_codes + e_off[b];
-            rq.out_off = out_off[b] - out_off[b0];
+            rq.out_off = out_off[b] - out_off[out_first >= 0 ? out_first : b0];
             rq.no_prune = no_prune;
             if (orders) { rq.order = orders + (size_t)i * 128; rq.n_order = order_len[i]; }
             PlanStats st;

@@ -182,6 +182,7 @@ struct ProgBuf {
 
 // Plan one request; appends the program to `prog`.  Returns "" or an error message.
 std::string plan_request(const Network &net, const Request &rq, ProgBuf &prog, PlanStats &st);
+std::string emit_error_message(int err);  // message of a kEmitErr* code (emit_core.h)
 std::string plan_request(const Network &net, const Request &rq, std::vector<uint32_t> &prog, PlanStats &st);
 
 // Persistent host worker threads (planning a 16 k-request batch spawns no threads and faults no pages).
@@ -216,7 +217,9 @@ struct BatchPlan {
 void plan_batch(const Network &net, ThreadPool &pool, std::vector<ProgBuf> &bufs, int64_t b0, int64_t b1,
                 const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
                 const int32_t *e_codes, const int64_t *out_off, const char *skip, BatchPlan &bp, bool no_prune = false,
-                const uint8_t *orders = nullptr, const int32_t *order_len = nullptr);  // orders[(b - b0) * 128 ..]: device order search
+                const uint8_t *orders = nullptr, const int32_t *order_len = nullptr,  // orders[(b - b0) * 128 ..]: device order search
+                int64_t out_first = -1);  // result offsets relative to out_off[out_first] (default: b0) - the host's share of a chunk whose
+                                          // first requests the device plans
 
 // Shard-balancing estimate (mibn_estimate_costs): section-8(d) bytes of the cheaper of the two sweep orders of every
 // request of a CSR batch - the byte model only, nothing is emitted.

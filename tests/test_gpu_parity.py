@@ -478,6 +478,62 @@ def test_schedule_and_effort_options_do_not_change_answers(amd):
     assert float(np.max(np.abs(sweeps - base))) <= 1e-12
 
 
+def test_device_planner_writes_the_host_programs(amd):
+    """Option gpu_emit: whole chunks are planned on the device - order_kernel, then emit_kernel: one request per lane runs
+    the very code of csrc/emit_core.h that the host's planning workers run, and writes the step program into the chunk's
+    device buffer.  Mode 2 makes the engine plan every chunk on the host as well and compare programs, work items and
+    statistics word for word (an error otherwise); the posteriors are then the host-planned ones bit for bit - on the C3
+    stream, with two query variables and the no-prune flag, with out-of-domain evidence, and on random DAGs with mixed
+    cardinalities."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 6144, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    host = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    host_stats = be.engine.stats()
+    # mode 1: the device plans a share of every chunk, the host's workers the rest meanwhile (the share follows the two rates)
+    for mode, chunk, share in ((2, 4096, -1), (1, 32768, -1), (1, 2048, 0.3), (1, 32768, 1.0)):
+        be.engine.set_option("gpu_emit", mode)
+        be.engine.set_option("chunk", chunk)
+        be.engine.set_option("emit_share", share)
+        dev = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+        st = be.engine.stats()
+        assert abs(st["alg_bytes"] - host_stats["alg_bytes"]) <= 1e-9 * host_stats["alg_bytes"] and st["n_steps"] == host_stats["n_steps"]
+        assert np.array_equal(dev, host), (mode, chunk, share)
+    be.engine.set_option("chunk", 32768)
+    be.engine.set_option("emit_share", -1)
+    be.engine.set_option("gpu_emit", 2)
+    from sorobn_amd import _capi
+    two_q = to_var[np.stack([q[:512], ev[:512, 0]], 1)]
+    two = be.engine.query_fixed(two_q, to_var[ev[:512, 1:]], ec[:512, 1:], flags=_capi.Q_NOPRUNE)
+    bad = ec[:512].copy()
+    bad[::7, 2] = 9  # a label outside the domain: an all-zero posterior, no steps
+    skipped = be.engine.query_fixed(to_var[q[:512]][:, None], to_var[ev[:512]], bad)
+    be.engine.set_option("emit_words", 1024)  # programs that do not fit their slot: the host plans the chunk, the slots double
+    small = be.engine.query_fixed(to_var[q[:512]][:, None], to_var[ev[:512]], ec[:512])
+    assert np.array_equal(small, host[:512])
+    be.engine.set_option("gpu_emit", 0)
+    assert np.array_equal(two, be.engine.query_fixed(two_q, to_var[ev[:512, 1:]], ec[:512, 1:], flags=_capi.Q_NOPRUNE))
+    assert np.array_equal(skipped, be.engine.query_fixed(to_var[q[:512]][:, None], to_var[ev[:512]], bad))
+    assert np.all(skipped[::7] == 0) and np.array_equal(skipped[1::7], host[:512][1::7])
+    nets = [(net["spec"], net["requests"]) for fname in ("random_dags.json", "wide_cards.json") for net in gu.load(fname)]
+    nets += [(gu.grid_spec_from_recipe(e), e["requests"]) for e in gu.load("grids_small.json")]
+    for net_spec, requests in nets:
+        for small_cells, big_iters in ((1024, 4096), (3, 4)):  # (the second: tiled FIBER steps on small networks)
+            b = netspec.build(net_spec, amd.BayesNet)
+            b.backend.engine.set_option("tiny", 0)
+            b.backend.engine.set_option("small_cells", small_cells)
+            b.backend.engine.set_option("big_iters", big_iters)
+            reqs = [(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in requests]
+            want = b.query_many(reqs)
+            b.backend.engine.set_option("gpu_emit", 2)
+            got = b.query_many(reqs)
+            for a, w in zip(got, want):
+                assert a.index.equals(w.index) and np.array_equal(a.to_numpy(), w.to_numpy())
+            _check_requests(b, requests, net_spec["name"] + " gpu_emit")
+
+
 def test_device_order_search_reproduces_the_host_search(amd):
     """Option gpu_search: the elimination-order search runs as a kernel (order_kernel: one request per lane, the very
     code of csrc/order_search.h that the host runs).  Same orders => same programs => the same posteriors bit for bit

@@ -6,7 +6,7 @@ mkdir -p $OUT
 IFS=';' read -ra SETS <<< "$1"
 for rep in $(seq 1 ${2:-2}); do
 for args in "${SETS[@]}"; do
-  timeout 300 python bench.py --steps ${STEPS:-6} --warmup 2 --no-cpu --no-configs --no-adaptive $args 2>&1 | python -c "
+  timeout 300 python bench.py --steps ${STEPS:-6} --warmup ${WARMUP:-2} --no-cpu --no-configs ${ADAPT:---no-adaptive} $args 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{\"metric\"'):

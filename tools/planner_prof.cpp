@@ -1,6 +1,7 @@
 // Host-planner profiling harness (CPU only): plans a random 1-query + 4-evidence stream on an R x C grid network with K
 // states and reports us per request.  Build with -pg for gprof:
 //   g++ -O2 -g -pg -mpopcnt -std=c++17 tools/planner_prof.cpp sorobn_amd/csrc/planner.cpp -lpthread -o /tmp/planner_prof
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -75,6 +76,17 @@ int main(int argc, char **argv) {
         for (const uint32_t *p = w; p < end; ++p) h = (h ^ *p) * 1099511628211ull;
     }
     std::printf("program fingerprint %016llx\n", (unsigned long long)h);
+    {   // the longest program and the most work items of a request (what the device emission has to reserve per request)
+        size_t max_words = 0, max_tags = 0;
+        for (int64_t b = 0; b < B; ++b) {
+            const uint32_t *w = bufs[bp.thread_of[b]].data + bp.local_off[b];
+            size_t off = 1;
+            for (uint32_t s = 0; s < w[0]; ++s) off += w[off + 6];
+            max_words = std::max(max_words, off);
+            max_tags = std::max<size_t>(max_tags, bp.tag_count[b]);
+        }
+        std::printf("longest program %zu words, most work items of a request %zu\n", max_words, max_tags);
+    }
     std::printf("threads %d: %.1f ms for %lld requests = %.2f us/request/thread (x%d threads), %.0f req/s; %.1f steps, %.0f words, %.2f MB per request\n",
                 threads, best, (long long)B, best * 1e3 / B * threads, threads, B / best * 1e3, bp.st.n_steps / B, (double)bp.total_words / B, bp.st.alg_bytes / B / 1e6);
     return 0;
