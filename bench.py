@@ -459,7 +459,8 @@ def main():
     if rank == 0:
         n_queries = a.steps * world * a.batch
         # dominant kernel = the specialisation with the most HIP-event time over the timed region
-        dom = max(kagg, key=lambda n: kagg[n]["ms"])
+        # (the device planner's pair of kernels moves no section-8(d) bytes: it is listed under "kernels", never the roofline's kernel)
+        dom = max((n for n in kagg if kagg[n]["alg_bytes"] > 0), key=lambda n: kagg[n]["ms"])
         launches = max(1.0, kagg[dom]["launches"])
         bytes_per_launch = kagg[dom]["alg_bytes"] / launches
         ms_per_launch = kagg[dom]["ms"] / launches
@@ -487,7 +488,10 @@ def main():
                                   "nccl-fallback": "RCCL via torch.distributed (mibn_comm_init failed on this node: see stderr)",
                                   "gloo": "gloo via torch.distributed (test hook)"}[transport],
                        "shard_balance": a.balance, "planner_threads": a.threads or "auto (cgroup quota / ranks)",
-                       "adaptive_planning": not a.no_adaptive},
+                       "adaptive_planning": not a.no_adaptive,
+                       # chunks planned by order_kernel + emit_kernel in the timed region (option gpu_emit, or the adaptive policy when
+                       # the host's planning workers bound the pipeline)
+                       "device_planned_requests_per_step": kagg.get("order_kernel+emit_kernel", {}).get("items", 0.0) / a.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": dom, "alg_bytes_per_launch": bytes_per_launch,

@@ -52,10 +52,14 @@ struct OrderArgs {
                            // waves finish sooner, as long as the chip has SIMDs to spare: option plan_lanes)
 };
 
-__global__ __launch_bounds__(64) void order_kernel(const OrderArgs A) {
+// (Workgroups of up to 16 waves - no cooperation between them, only placement: the waves of a workgroup share a CU, so the 512
+// waves of a chunk take 32 CUs whole instead of one workgroup's worth of registers on every CU - beside the level and sweep
+// kernels, whose workgroups fill a CU's register file exactly, that is an eighth of the chip instead of a third to a half.)
+__global__ __launch_bounds__(1024) void order_kernel(const OrderArgs A) {
     if (A.zero && blockIdx.x == 0 && threadIdx.x == 0) *A.zero = 0;
-    if ((int)threadIdx.x >= A.lanes) return;
-    const int64_t b = (int64_t)blockIdx.x * A.lanes + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
+    if (lane >= A.lanes) return;
+    const int64_t b = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
     if (b >= A.B) return;
     OrderScratch &S = A.scratch[b];
     const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
@@ -96,9 +100,10 @@ struct EmitArgs {
     int32_t lanes;                           // requests per wave (see OrderArgs)
 };
 
-__global__ __launch_bounds__(64, 4) void emit_kernel(const EmitArgs A) {
-    if ((int)threadIdx.x >= A.lanes) return;
-    const int64_t b = (int64_t)blockIdx.x * A.lanes + threadIdx.x;
+__global__ __launch_bounds__(1024) void emit_kernel(const EmitArgs A) {
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
+    if (lane >= A.lanes) return;
+    const int64_t b = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
     if (b >= A.B) return;
     EmitMeta m;
     m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
@@ -214,7 +219,8 @@ struct mibn_ctx {
     bool auto_emit = false;    // gpu_emit was
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
     // device order search (order_kernel)
-    int plan_lanes = 16;             // requests per wave of order_kernel / emit_kernel (1..64)
+    int plan_lanes = 32;             // requests per wave of order_kernel / emit_kernel (1..64)
+    int plan_waves = 16;             // waves per workgroup of the two (1..16): see order_kernel
     int gpu_search = 0;              // option: 1 = search elimination orders on the device (networks of <= 128 variables)
     hipStream_t search_stream = nullptr;
     char *d_order_net = nullptr;     // the OrderNet arrays
@@ -273,8 +279,8 @@ struct mibn_ctx {
     } comm;
     std::string err;
     mibn_stats stats{}, total{};               // last call / since creation
-    mibn_kernel_stat kstats[kNumKernels + 3];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
-    mibn_kernel_stat ktotal[kNumKernels + 3];
+    mibn_kernel_stat kstats[kNumKernels + 4];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
+    mibn_kernel_stat ktotal[kNumKernels + 4];  // + the device planner's pair of kernels
     // options
     double arena_gb = 200.0;  // scratch budget of all lanes together (of the 288 GB)
     hipStream_t stream2 = nullptr;  // lane 1 (lane 0 = stream)
@@ -498,6 +504,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
     else if (n == "tiny") h->tiny = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
+    else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
     else if (n == "plan_lanes") h->plan_lanes = std::max(1, std::min(64, (int)value));  // requests per wave of the device planner's kernels
     else if (n == "emit_share") { h->emit_share_opt = value > 0 ? std::min(1.0, value) : -1; if (value > 0) h->emit_share = h->emit_share_opt; }  // the device's share of a chunk (<= 0: follows the measured rates)
     else if (n == "emit_words") h->emit_words = (uint32_t)std::max(1024, std::min(1 << 20, (int)value));  // words of a request's device program slot
@@ -682,7 +689,7 @@ void ensure_pool(mibn_ctx *h) {
 
 // name of statistics slot k: the classes of work (split_kinds), then the kernels as launched
 const char *stat_name(int k) {
-    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : "ve_sweep_dma_kernel"));
+    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : (k == kNumKernels + 2 ? "ve_sweep_dma_kernel" : "order_kernel+emit_kernel")));
 }
 
 // wait for a set's launches and book their HIP-event durations per kernel
@@ -818,7 +825,10 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
         A.scratch = h->d_order_scratch;
         A.zero = nullptr;
         A.lanes = h->plan_lanes;
-        hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + A.lanes - 1) / A.lanes)), dim3(64), 0, h->search_stream, A);
+        {
+            const int64_t per_wg = (int64_t)A.lanes * h->plan_waves;
+            hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, h->search_stream, A);
+        }
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipMemcpyAsync(h->search_out.p, h->d_orders, (size_t)n * 128, hipMemcpyDeviceToHost, h->search_stream));
@@ -905,7 +915,8 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         O.scratch = h->d_order_scratch;
         O.zero = s0 == 0 ? h->d_emit_cursor : nullptr;
         O.lanes = h->plan_lanes;
-        hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + O.lanes - 1) / O.lanes)), dim3(64), 0, P, O);
+        const int64_t per_wg = (int64_t)h->plan_lanes * h->plan_waves;
+        hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, P, O);
         EmitArgs A;
         {   // the pointers of the device copy, the options of the moment
             A.net = h->net.emit_view();
@@ -933,7 +944,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         A.scratch = h->d_emit_scratch;
         A.scratch_stride = scratch_stride;
         A.lanes = h->plan_lanes;
-        hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((m + A.lanes - 1) / A.lanes)), dim3(64), 0, P, A);
+        hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, P, A);
         HIP_TRY(h, hipGetLastError());
     }
     HIP_TRY(h, hipEventRecord(h->emit_ev[1], P));
@@ -1110,7 +1121,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     h->search_ms = 0;
     h->emit_ms = 0;
     h->stats = mibn_stats{};
-    for (int k = 0; k <= kNumKernels + 2; ++k) {
+    for (int k = 0; k <= kNumKernels + 3; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
         std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", stat_name(k));
     }
@@ -1266,6 +1277,12 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             const double tw = now_ms();
             rc = plan_on_device_collect(h, b0, nd, nd < n ? dp : ck, &dev_ms);
             h->emit_ms += now_ms() - tw;
+            for (mibn_kernel_stat *ks : {&h->kstats[kNumKernels + 3], &h->ktotal[kNumKernels + 3]}) {  // (beside the chunk in flight: their time is not GPU busy time of its own)
+                if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", stat_name(kNumKernels + 3));
+                ks->launches += 2;
+                ks->ms += dev_ms;
+                ks->items += (double)nd;
+            }
             if (h->trace) std::fprintf(stderr, "[mibn plan] chunk of %lld: device %lld requests (upload + launch %.2f ms, kernels %.2f ms, wait + collect %.2f ms), host %lld requests %.2f ms\n",
                                        (long long)n, (long long)nd, t_launched - t0, dev_ms, now_ms() - tw, (long long)(n - nd), host_ms);
             if (rc < 0 || rc > 1) return rc;
@@ -1563,7 +1580,7 @@ extern "C" int mibn_total_stats(const mibn_t *h, mibn_stats *out) {
 extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 2 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 3 && k < cap; ++i)
         if (h->ktotal[i].launches > 0) out[k++] = h->ktotal[i];
     *n = k;
     return MIBN_OK;
@@ -1572,7 +1589,7 @@ extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel
 extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 2 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 3 && k < cap; ++i)
         if (h->kstats[i].launches > 0) out[k++] = h->kstats[i];
     *n = k;
     return MIBN_OK;

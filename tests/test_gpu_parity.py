@@ -503,6 +503,12 @@ def test_device_planner_writes_the_host_programs(amd):
         assert np.array_equal(dev, host), (mode, chunk, share)
     be.engine.set_option("chunk", 32768)
     be.engine.set_option("emit_share", -1)
+    for lanes, waves in ((64, 1), (5, 3), (32, 16)):  # the geometry of the planner's launches: requests per wave, waves per workgroup
+        be.engine.set_option("plan_lanes", lanes)
+        be.engine.set_option("plan_waves", waves)
+        assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), host), (lanes, waves)
+    names = [k["name"] for k in be.engine.kernel_stats()]
+    assert "order_kernel+emit_kernel" in names and "ve_sweep_dma_kernel" in names
     be.engine.set_option("gpu_emit", 2)
     from sorobn_amd import _capi
     two_q = to_var[np.stack([q[:512], ev[:512, 0]], 1)]

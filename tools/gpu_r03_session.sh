@@ -29,13 +29,14 @@ PY
 done
 find $OUT -name "*.db" -path "*calib*" -delete
 cd $ROOT
-# few host threads per rank (8 ranks on a small CPU quota): planner threads 2 and 4, adaptive planning on
-for t in 2 4; do
-  timeout 300 python bench.py --steps 6 --warmup 3 --no-cpu --no-configs --threads $t 2>&1 | python -c "
+# few host threads per rank (8 ranks on a small CPU quota): the default bench (adaptive policy: the device planner - order_kernel +
+# emit_kernel - takes over when the host's planning workers bound the pipeline), and the host planner alone beside it
+for args in "--threads 1" "--threads 2" "--threads 4" "--threads 8" "--threads 2 --no-adaptive" "--threads 4 --no-adaptive"; do
+  timeout 300 python bench.py --steps 10 --warmup 8 --no-cpu --no-configs $args 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{\"metric\"'):
         d = json.loads(l); b = d['breakdown_ms_per_step']
-        print('threads $t: %.0f q/s  ms/step %.1f  kernel %.1f plan %.1f' % (d['value'], d['ms_per_step'], b['kernel_ms'], b['plan_ms']))
+        print('%-28s %.0f q/s  ms/step %.1f  kernel %.1f plan %.1f  device-planned requests per step %.0f' % ('$args', d['value'], d['ms_per_step'], b['kernel_ms'], b['plan_ms'], d['config']['device_planned_requests_per_step']))
 " | tee -a $OUT/${TAG}_threads.log
 done
