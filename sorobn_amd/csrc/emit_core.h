@@ -23,19 +23,27 @@ constexpr int kLoMax = 512;               // ... but never more than this many c
 constexpr uint64_t kConstFlag = 1ull << 63;  // in_off bit: table lives in the constants pool
 constexpr int kSweepItersDefault = 8;     // SWEEP: tiles per workgroup (Network::sweep_iters)
 
+// The device planner covers networks of up to 128 variables: there every bit set is two words, the loops below have a
+// compile-time bound, unroll, and a local set lives in registers instead of the lane's private memory.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MIBN_BITS_WORDS(nw) 2
+#else
+#define MIBN_BITS_WORDS(nw) (nw)
+#endif
+
 struct Bits {
     int nw = kWords;  // words in use (first: in the same cache line as w[0], w[1] - all a network of <= 128 variables touches)
     uint64_t w[kWords] = {};
     MIBN_HD void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
     MIBN_HD void clr(int i) { w[i >> 6] &= ~(1ull << (i & 63)); }
     MIBN_HD bool test(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
-    MIBN_HD bool any() const { for (int k = 0; k < nw; ++k) if (w[k]) return true; return false; }
-    MIBN_HD void or_(const Bits &o) { for (int k = 0; k < nw; ++k) w[k] |= o.w[k]; }
-    MIBN_HD void andnot(const Bits &o) { for (int k = 0; k < nw; ++k) w[k] &= ~o.w[k]; }
-    MIBN_HD bool intersects(const Bits &o) const { for (int k = 0; k < nw; ++k) if (w[k] & o.w[k]) return true; return false; }
-    MIBN_HD int count() const { int c = 0; for (int k = 0; k < nw; ++k) c += __builtin_popcountll(w[k]); return c; }
+    MIBN_HD bool any() const { for (int k = 0; k < MIBN_BITS_WORDS(nw); ++k) if (w[k]) return true; return false; }
+    MIBN_HD void or_(const Bits &o) { for (int k = 0; k < MIBN_BITS_WORDS(nw); ++k) w[k] |= o.w[k]; }
+    MIBN_HD void andnot(const Bits &o) { for (int k = 0; k < MIBN_BITS_WORDS(nw); ++k) w[k] &= ~o.w[k]; }
+    MIBN_HD bool intersects(const Bits &o) const { for (int k = 0; k < MIBN_BITS_WORDS(nw); ++k) if (w[k] & o.w[k]) return true; return false; }
+    MIBN_HD int count() const { int c = 0; for (int k = 0; k < MIBN_BITS_WORDS(nw); ++k) c += __builtin_popcountll(w[k]); return c; }
     template <class F> MIBN_HD void for_each(F f) const {
-        for (int k = 0; k < nw; ++k) { uint64_t m = w[k]; while (m) { int b = __builtin_ctzll(m); f(k * 64 + b); m &= m - 1; } }
+        for (int k = 0; k < MIBN_BITS_WORDS(nw); ++k) { uint64_t m = w[k]; while (m) { int b = __builtin_ctzll(m); f(k * 64 + b); m &= m - 1; } }
     }
 };
 
@@ -918,7 +926,7 @@ struct Emitter {
         if (out_cells >= (1ll << 31)) return false;
         int na = 0;
         out.scope.nw = net.nw;
-        for (int q = 0; q < net.nw; ++q) out.scope.w[q] = 0;
+        for (int q = 0; q < MIBN_BITS_WORDS(net.nw); ++q) out.scope.w[q] = 0;
         for (int q = 0; q < kout; ++q) {
             out.vars[na] = var_on[surv[q]];
             out.strides[na] = int64_t(1) << (2 * q);
@@ -988,7 +996,7 @@ struct Emitter {
     // the joint elimination of two variables).
     MIBN_HD bool emit(const PF *const *ins, int n_in, const int *X, int nx, bool final_, int64_t final_off, PF &out, bool fiber_only) {
         out.scope.nw = net.nw;  // (only the words the network uses: the rest of a pool entry's scope is never read)
-        for (int k = 0; k < net.nw; ++k) out.scope.w[k] = 0;
+        for (int k = 0; k < MIBN_BITS_WORDS(net.nw); ++k) out.scope.w[k] = 0;
         for (int j = 0; j < n_in; ++j) out.scope.or_(ins[j]->scope);
         for (int k = 0; k < nx; ++k) out.scope.clr(X[k]);
         int na = 0;
@@ -1109,6 +1117,15 @@ MIBN_HD inline double emit_scope_log2(const EmitNet &net, const Bits &b) {
     return s;
 }
 
+MIBN_HD inline void emit_or_ancestors(const EmitNet &net, Bits &b, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    b.w[0] |= net.anc[(size_t)v * net.nw];
+    if (net.nw > 1) b.w[1] |= net.anc[(size_t)v * net.nw + 1];
+#else
+    for (int k = 0; k < net.nw; ++k) b.w[k] |= net.anc[(size_t)v * net.nw + k];
+#endif
+}
+
 // Relevant / hidden sets and the factors of a request = the evidence-sliced CPTs of the relevant nodes (bayes_net.py:768-776):
 // the evidence axis is not copied away but folded into the base offset.  Returns 0 or a kEmitErr*.
 MIBN_HD inline int emit_begin(const EmitNet &net, EmitScratch &S, int nq, const int32_t *qvars, int ne, const int32_t *evars,
@@ -1119,11 +1136,11 @@ MIBN_HD inline int emit_begin(const EmitNet &net, EmitScratch &S, int nq, const 
     rel.nw = qb.nw = eb.nw = net.nw;
     for (int i = 0; i < nq; ++i) {
         qb.set(qvars[i]); rel.set(qvars[i]);
-        for (int k = 0; k < net.nw; ++k) rel.w[k] |= net.anc[(size_t)qvars[i] * net.nw + k];
+        emit_or_ancestors(net, rel, qvars[i]);
     }
     for (int i = 0; i < ne; ++i) {
         eb.set(evars[i]); rel.set(evars[i]);
-        for (int k = 0; k < net.nw; ++k) rel.w[k] |= net.anc[(size_t)evars[i] * net.nw + k];
+        emit_or_ancestors(net, rel, evars[i]);
     }
     if (!net.prune || no_prune)  // full_joint_dist / predict_proba multiply *all* CPTs (bayes_net.py:460): with sparse or
         for (int v = 0; v < net.n_vars; ++v) rel.set(v);  // unnormalised CPTs a barren node does not sum to 1
@@ -1139,7 +1156,7 @@ MIBN_HD inline int emit_begin(const EmitNet &net, EmitScratch &S, int nq, const 
         f.n = 0;
         f.alloc = 0;
         f.scope.nw = net.nw;
-        for (int k = 0; k < net.nw; ++k) f.scope.w[k] = 0;
+        for (int k = 0; k < MIBN_BITS_WORDS(net.nw); ++k) f.scope.w[k] = 0;
         uint64_t off = (uint64_t)net.pool_off[v];
         int64_t cells = 1;
         for (int k = net.scope_off[v]; k < net.scope_off[v + 1]; ++k) {

@@ -226,8 +226,6 @@ struct mibn_ctx {
     char *d_order_net = nullptr;     // the OrderNet arrays
     OrderNet order_net_dev;          // pointers into d_order_net
     bool order_net_ok = false;
-    char *d_search_req = nullptr;    // request arrays of the chunk
-    size_t search_req_cap = 0;
     uint8_t *d_orders = nullptr;
     size_t orders_cap = 0;
     int32_t *d_order_len = nullptr;
@@ -446,7 +444,6 @@ void mibn_destroy(mibn_t *h) {
         (void)hipFree(h->d_tiny_req);
         (void)hipFree(h->d_tiny_bad);
         (void)hipFree(h->d_order_net);
-        (void)hipFree(h->d_search_req);
         (void)hipFree(h->d_orders);
         (void)hipFree(h->d_order_len);
         (void)hipFree(h->d_order_scratch);
@@ -793,16 +790,17 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
     const size_t in_bytes = 2 * off_bytes + (nq + ne) * 4 + 64;
     if ((rc = pinned(h, h->search_in, in_bytes))) return rc;
     if ((rc = pinned(h, h->search_out, (size_t)n * 132))) return rc;
-    if ((rc = ensure(h, h->d_search_req, h->search_req_cap, in_bytes))) return rc;
-    if ((rc = ensure(h, h->d_orders, h->orders_cap, (size_t)n * 128))) return rc;
-    if ((rc = ensure(h, h->d_order_len, h->order_len_cap, (size_t)n))) return rc;
     if ((rc = ensure(h, h->d_order_scratch, h->order_scratch_cap, (size_t)std::min(n, kSearchSlice)))) return rc;
     int64_t *qo = reinterpret_cast<int64_t *>(h->search_in.p), *eo = qo + (n + 1);
     for (int64_t i = 0; i <= n; ++i) { qo[i] = q_off[b0 + i] - q_off[b0]; eo[i] = e_off[b0 + i] - e_off[b0]; }
     char *pv = h->search_in.p + 2 * off_bytes;
     std::memcpy(pv, q_vars + q_off[b0], nq * 4);
     if (ne) std::memcpy(pv + nq * 4, e_vars + e_off[b0], ne * 4);
-    HIP_TRY(h, hipMemcpyAsync(h->d_search_req, h->search_in.p, in_bytes, hipMemcpyHostToDevice, h->search_stream));
+    // (no copies on this stream - the kernel reads the request arrays from, and writes the orders to, pinned host memory: a DMA
+    // copy here queues behind the previous call's result download on the copy engine, i.e. behind that call's kernels)
+    const char *d_req = h->search_in.p;
+    uint8_t *orders_out = reinterpret_cast<uint8_t *>(h->search_out.p);
+    int32_t *len_out = reinterpret_cast<int32_t *>(h->search_out.p + (size_t)n * 128);
     for (int64_t s0 = 0; s0 < n; s0 += kSearchSlice) {
         const int64_t m = std::min(kSearchSlice, n - s0);
         OrderArgs A;
@@ -814,14 +812,14 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
             A.net.chain_weight = hv.chain_weight;
             A.net.big_cells = hv.big_cells;
         }
-        A.q_off = reinterpret_cast<const int64_t *>(h->d_search_req) + s0;
-        A.e_off = reinterpret_cast<const int64_t *>(h->d_search_req + off_bytes) + s0;
-        A.q_vars = reinterpret_cast<const int32_t *>(h->d_search_req + 2 * off_bytes);
+        A.q_off = reinterpret_cast<const int64_t *>(d_req) + s0;
+        A.e_off = reinterpret_cast<const int64_t *>(d_req + off_bytes) + s0;
+        A.q_vars = reinterpret_cast<const int32_t *>(d_req + 2 * off_bytes);
         A.e_vars = A.q_vars + nq;
         A.B = m;
         A.flags = flags;
-        A.orders = h->d_orders + s0 * 128;
-        A.order_len = h->d_order_len + s0;
+        A.orders = orders_out + s0 * 128;
+        A.order_len = len_out + s0;
         A.scratch = h->d_order_scratch;
         A.zero = nullptr;
         A.lanes = h->plan_lanes;
@@ -831,8 +829,6 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
         }
         HIP_TRY(h, hipGetLastError());
     }
-    HIP_TRY(h, hipMemcpyAsync(h->search_out.p, h->d_orders, (size_t)n * 128, hipMemcpyDeviceToHost, h->search_stream));
-    HIP_TRY(h, hipMemcpyAsync(h->search_out.p + (size_t)n * 128, h->d_order_len, (size_t)n * 4, hipMemcpyDeviceToHost, h->search_stream));
     return MIBN_OK;
 }
 
