@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "../sorobn_amd/csrc/planner.h"
@@ -38,6 +39,9 @@ int main(int argc, char **argv) {
     Network net;
     std::string e = net.set(n, card.data(), scope_off.data(), scope_vars.data(), value_off.data(), values.data());
     if (!e.empty()) { std::fprintf(stderr, "%s\n", e.c_str()); return 1; }
+    if (const char *e = std::getenv("ORDER_WEIGHTS")) net.order_weights = atoi(e);
+    if (const char *e = std::getenv("MINFILL_ABOVE")) net.minfill_above = atof(e);
+    if (const char *e = std::getenv("SWEEP_MIN")) net.sweep_min = atoi(e);
     std::vector<int32_t> hint(n);
     for (int v = 0; v < n; ++v) hint[v] = v;
     net.set_hints(1, hint.data());
@@ -86,6 +90,25 @@ int main(int argc, char **argv) {
             max_tags = std::max<size_t>(max_tags, bp.tag_count[b]);
         }
         std::printf("longest program %zu words, most work items of a request %zu\n", max_words, max_tags);
+    }
+    {   // bytes per class of work and a time estimate from the per-class rates of profiles/r03_g_probe_classes_32768.log
+        std::vector<double> by(kNumKernels, 0.0);
+        for (int t = 0; t < (int)bp.tags.size(); ++t)
+            for (const Tag &tg : bp.tags[t]) by[tg.kid] += tg.bytes;
+        double est_ms = 0, sweep = 0, mfma1 = 0, joins = 0, rest = 0;
+        for (int k = 0; k < kNumKernels; ++k) {
+            if (by[k] == 0) continue;
+            const std::string nm = kernel_name(k);
+            double rate = 1000;  // GB/s
+            if (k == kKidSweep) { rate = 4400; sweep += by[k]; }
+            else if (nm.find("fiber<1") == 0 && nm.find("mfma") != std::string::npos) { rate = nm.find("chain") != std::string::npos ? 3000 : 4300; mfma1 += by[k]; }
+            else if (nm.find("fiber<2") == 0) { rate = nm.find("outer") != std::string::npos ? 2250 : 1300; joins += by[k]; }
+            else if (nm == "fiber<1,cx4,nc4>") { rate = 3200; rest += by[k]; }
+            else rest += by[k];
+            est_ms += by[k] / rate / 1e6;
+        }
+        std::printf("per request: sweep %.2f MB, one-table MFMA %.2f MB, two-table joins %.2f MB, rest %.2f MB; estimated kernel time %.2f us per request\n",
+                    sweep / B / 1e6, mfma1 / B / 1e6, joins / B / 1e6, rest / B / 1e6, est_ms * 1e3 / B);
     }
     std::printf("threads %d: %.1f ms for %lld requests = %.2f us/request/thread (x%d threads), %.0f req/s; %.1f steps, %.0f words, %.2f MB per request\n",
                 threads, best, (long long)B, best * 1e3 / B * threads, threads, B / best * 1e3, bp.st.n_steps / B, (double)bp.total_words / B, bp.st.alg_bytes / B / 1e6);
