@@ -679,3 +679,66 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     g_err = bp.err;
     return ms;
 }
+
+// The device planner's configuration of emit_core.h, run on the CPU: the planning state of a request carved out of ONE raw
+// (deliberately dirty) slice like a lane's, the program written into a fixed slot of `slot_words` words, the elimination order
+// taken from order_search as bytes - compared word for word, work item for work item, with plan_request.  Returns the number
+// of requests whose programs fit their slot (the others must report kEmitErrWords and leave no damage), or -1 and
+// plan_sim_error().
+extern "C" int64_t plan_sim_device_style(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                                         const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
+                                         int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off,
+                                         const int32_t *e_vars, const int32_t *e_codes, int32_t slot_words, int32_t no_prune) {
+    Network net;
+    g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
+    if (!g_err.empty()) return -1;
+    if (n_vars > 128) { g_err = "the device planner covers networks of up to 128 variables"; return -1; }
+    net.small_cells = g_small_cells; net.big_iters = g_big_iters; net.tile_h = g_tile_h; net.fuse = g_fuse; net.chain = g_chain;
+    net.sweep = g_sweep; net.sweep_min = g_sweep_min; net.prune = g_prune;
+    net.set_hints(n_hints, hints);
+    const EmitNet en = net.emit_view();
+    const OrderNet on = net.order_view();
+    const size_t bytes = emit_scratch_bytes(n_vars);
+    std::vector<char> slice(bytes + 64);
+    std::vector<uint32_t> slot((size_t)slot_words);
+    std::vector<OrderScratch> os(1);
+    int64_t fitted = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int nq = (int)(q_off[b + 1] - q_off[b]), ne = (int)(e_off[b + 1] - e_off[b]);
+        const int32_t *qv = q_vars + q_off[b], *ev = e_vars + e_off[b], *ec = e_codes + e_off[b];
+        std::memset(slice.data(), 0xA5 + (int)(b & 7), slice.size());  // a lane's slice is never cleared between requests
+        std::fill(slot.begin(), slot.end(), 0xDEADBEEFu);
+        char *base = slice.data() + ((64 - (reinterpret_cast<uintptr_t>(slice.data()) & 63)) & 63);
+        EmitScratch S;
+        emit_scratch_carve(S, base, n_vars);
+        order_search(on, os[0], nq, qv, ne, ev, no_prune != 0);
+        int err = emit_begin(en, S, nq, qv, ne, ev, ec, no_prune != 0);
+        EmitBuf buf;
+        buf.data = slot.data();
+        buf.cap = (size_t)slot_words;
+        EmitStats st;
+        if (!err) err = emit_run(en, S, buf, st, nullptr, nq, qv, 1000 * b, os[0].best, (int)os[0].n_best);
+        // the host's planner on the same request
+        Request rq;
+        rq.nq = nq; rq.qvars = qv; rq.ne = ne; rq.evars = ev; rq.ecodes = ec; rq.out_off = 1000 * b; rq.no_prune = no_prune != 0;
+        std::vector<uint32_t> ref;
+        PlanStats rs;
+        g_err = plan_request(net, rq, ref, rs);
+        if (!g_err.empty()) return -1;
+        if (err == kEmitErrWords) {
+            if (ref.size() + kMaxStepWords <= (size_t)slot_words) { g_err = "request " + std::to_string(b) + ": refused although the program fits its slot"; return -1; }
+            continue;
+        }
+        if (err) { g_err = "request " + std::to_string(b) + ": " + emit_error_message(err); return -1; }
+        if (buf.size != ref.size() || std::memcmp(slot.data(), ref.data(), ref.size() * 4) != 0) {
+            g_err = "request " + std::to_string(b) + ": the slot's program differs from plan_request's (" + std::to_string(buf.size) + " vs " + std::to_string(ref.size()) + " words)";
+            return -1;
+        }
+        if (st.alg_bytes != rs.alg_bytes || st.n_steps != rs.n_steps || st.arena_cells != rs.arena_cells) { g_err = "request " + std::to_string(b) + ": statistics differ"; return -1; }
+        uint32_t n_items = 0;
+        tag_program(en, slot.data(), [&](const Tag &t) { n_items += t.rel_off > 0 && t.wgs > 0; });
+        if (!n_items) { g_err = "request " + std::to_string(b) + ": no work items"; return -1; }
+        ++fitted;
+    }
+    return fitted;
+}

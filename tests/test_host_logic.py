@@ -413,6 +413,63 @@ def test_plan_templates_reproduce_planned_programs():
     assert _cache_check(dag, reqs, small_cells=2, tiling=(4, 2)) >= 350
 
 
+def _device_style(f, reqs, slot_words, small_cells=1024, tiling=(4096, 0), no_prune=0):
+    L = simengine.lib()
+    L.plan_sim_device_style.restype = ctypes.c_int64
+    L.plan_sim_set_small_cells(int(small_cells))
+    L.plan_sim_set_tiling(int(tiling[0]), int(tiling[1]))
+    q_off = np.concatenate([[0], np.cumsum([len(r[0]) for r in reqs])]).astype(np.int64)
+    e_off = np.concatenate([[0], np.cumsum([len(r[1]) for r in reqs])]).astype(np.int64)
+    qv = np.array([v for r in reqs for v in r[0]] or [0], np.int32)
+    ev = np.array([v for r in reqs for v in r[1]] or [0], np.int32)
+    ec = np.array([v for r in reqs for v in r[2]] or [0], np.int32)
+    hints = np.ascontiguousarray(np.stack(f.hints).reshape(-1), np.int32) if len(f.hints) else np.zeros(1, np.int32)
+    p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    rc = L.plan_sim_device_style(ctypes.c_int32(len(f.card)), p(f.card, ctypes.c_int32), p(f.scope_off, ctypes.c_int64),
+                                 p(f.scope_vars, ctypes.c_int32), p(f.value_off, ctypes.c_int64), p(f.values, ctypes.c_double),
+                                 ctypes.c_int32(len(f.hints)), p(hints, ctypes.c_int32),
+                                 ctypes.c_int64(len(reqs)), p(q_off, ctypes.c_int64), p(qv, ctypes.c_int32), p(e_off, ctypes.c_int64),
+                                 p(ev, ctypes.c_int32), p(ec, ctypes.c_int32), ctypes.c_int32(slot_words), ctypes.c_int32(no_prune))
+    L.plan_sim_set_small_cells(1024)
+    L.plan_sim_set_tiling(4096, 0)
+    assert rc >= 0, L.plan_sim_error().decode()
+    return rc
+
+
+def test_device_planner_configuration_on_the_cpu():
+    """csrc/emit_core.h the way the device runs it (emit_kernel, option gpu_emit) - the planning state of a request carved out
+    of one raw, dirty slice (emit_scratch_carve), the program written into a fixed slot (EmitBuf without a ProgBuf), the
+    elimination order handed over as order_search's bytes - must write plan_request's program word for word; a program
+    that does not fit its slot is refused (kEmitErrWords), not truncated.  The GPU suite repeats the comparison with the
+    code compiled for the device (test_device_planner_writes_the_host_programs)."""
+    rng = np.random.default_rng(5)
+
+    def stream(f, n, max_q=1, max_e=4):
+        nv = len(f.card)
+        out = []
+        for _ in range(n):
+            vs = rng.permutation(nv)
+            nq, ne = int(rng.integers(1, max_q + 1)), int(rng.integers(0, max_e + 1))
+            e = vs[nq:nq + ne].tolist()
+            out.append((vs[:nq].tolist(), e, [int(rng.integers(0, f.card[v])) for v in e]))
+        return out
+
+    grid = flatten(netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet))
+    reqs = stream(grid, 300)
+    assert _device_style(grid, reqs, 6144) == len(reqs)
+    fitted = _device_style(grid, reqs, 1500)            # about half of the C3 programs are longer than 1 500 - 384 words
+    assert 0 < fitted < len(reqs)
+    assert _device_style(grid, stream(grid, 40, max_q=2), 6144, no_prune=1) == 40
+    for fname in ("random_dags.json", "wide_cards.json"):
+        for net in _nets(fname):
+            f = flatten(netspec.build(net["spec"], sorobn_amd.BayesNet))
+            if len(f.card) > 128:
+                continue
+            reqs = stream(f, 60, max_q=2, max_e=3)
+            assert _device_style(f, reqs, 8192) == len(reqs)
+            assert _device_style(f, reqs, 8192, small_cells=3, tiling=(4, 1)) == len(reqs)
+
+
 # ------------------------------------------------------------------------------------ API behaviour
 
 @pytest.fixture()
