@@ -217,6 +217,7 @@ struct mibn_ctx {
     int adaptive = 0;
     bool auto_search = false;  // gpu_search was switched on by the adaptive policy
     bool auto_emit = false;    // gpu_emit was
+    int host_bound_streak = 0;
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
     // device order search (order_kernel)
     int plan_lanes = 32;             // requests per wave of order_kernel / emit_kernel (1..64)
@@ -1160,13 +1161,17 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 // (the share follows the host's rate: its workers would plan most of a chunk in the planner kernels' time)
                 h->gpu_emit = 0;
                 h->auto_emit = false;
-            } else if (dp > 1.15 * dk) {
+            } else if (dp > 1.15 * dk && ++h->host_bound_streak >= 2) {  // (twice in a row: the kernel time of a call is booked when its
+                                                                          // launches retire, up to two calls late - one window can mislead)
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
                 // not cover give up the min-fill search for ever more expensive requests instead
                 if (h->order_net_ok && h->emit_net_ok && !h->gpu_emit) { h->gpu_emit = 1; h->auto_emit = true; }  // the whole planning, not only the search
                 else if (h->order_net_ok && !h->emit_net_ok && !h->gpu_search) { h->gpu_search = 1; h->auto_search = true; }
                 else if (!h->order_net_ok) h->net.minfill_above = std::min(h->net.minfill_above * 8.0, 1e18);
-            } else if (dp < 0.3 * dk) {
+            } else if (dp <= 1.15 * dk) {
+                h->host_bound_streak = 0;
+            }
+            if (dp < 0.3 * dk) {
                 if (h->net.minfill_above > h->base_minfill) h->net.minfill_above = std::max(h->net.minfill_above / 8.0, h->base_minfill);
                 else if (h->auto_search) { h->gpu_search = 0; h->auto_search = false; }
             }
