@@ -86,6 +86,24 @@ constexpr int kKidSweep = 43;      // SWEEP steps: a kernel of their own (sweep_
 constexpr int kNumKernels = 44;
 constexpr uint32_t kItemSegment = 1u << 31;
 
+// Phase timers of emit_kernel (tools/gpu_r03_emit_phases.sh builds the library with -DMIBN_EMIT_PROF): a tick books the time since
+// the previous one to phase k - per lane, so under divergence a phase also holds the time a lane waits for the others' branches.
+#if defined(MIBN_EMIT_PROF)  // (only the translation unit of the kernels is built with it)
+struct EmitProf { unsigned long long t, a[12]; };
+extern EmitProf g_host_emit_prof;  // (planner.cpp, host build with the flag: tools/planner_prof.cpp prints it)
+#define MIBN_PROF_ARG , EmitProf &prof_
+#define MIBN_PROF_PASS , prof_
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MIBN_TICK(k) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); prof_.a[k] += t_ - prof_.t; prof_.t = t_; }
+#else
+#define MIBN_TICK(k) { const unsigned long long t_ = __builtin_ia32_rdtsc(); prof_.a[k] += t_ - prof_.t; prof_.t = t_; }
+#endif
+#else
+#define MIBN_PROF_ARG
+#define MIBN_PROF_PASS
+#define MIBN_TICK(k)
+#endif
+
 template <class T> MIBN_HD constexpr T emit_max(T a, T b) { return a < b ? b : a; }
 template <class T> MIBN_HD constexpr T emit_min(T a, T b) { return b < a ? b : a; }
 
@@ -1187,7 +1205,7 @@ MIBN_HD inline int emit_begin(const EmitNet &net, EmitScratch &S, int nq, const 
 // request's program to `prog`.  Returns 0 or a kEmitErr*.
 template <class OrderT>
 MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, EmitStats &st, void *rec, int nq, const int32_t *qvars,
-                            int64_t out_off, const OrderT *best, int n_best) {
+                            int64_t out_off, const OrderT *best, int n_best MIBN_PROF_ARG) {
     PF *pool = S.pool;
     for (int v = 0; v < net.n_vars; ++v) { S.key[v] = 0.0; S.pos[v] = -1; }
     Emitter em{net, prog, st, Arena{}, S.key, S.pos, 0, rec};
@@ -1234,6 +1252,7 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
         pool[idx].scope.for_each([&](int v) { mem[(size_t)v * sw + (idx >> 6)] |= 1ull << (idx & 63); });
     };
     for (int idx = 0; idx < S.n0; ++idx) add_factor(idx);
+    MIBN_TICK(1)  // key / pos / slot sets
     // factors alive whose scope contains a (or b, if b >= 0), in slot order; f(idx) returns false to stop early
     auto each_with = [&](int a, int b, auto f) {
         for (int k = 0; k < sw; ++k) {
@@ -1254,6 +1273,7 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
         int n_in = 0;
         each_with(x, -1, [&](int idx) { ins[n_in++] = &pool[idx]; return true; });
         for (int j = 0; j < n_in; ++j) consume(ins[j]);
+        MIBN_TICK(2)  // factors of x
         // SWEEP: up to five consecutive 4-state variables of one big table in a single pass, the tile resident in LDS
         // (planner.h).  sweep_max = how many of the next variables could join: all on the one big input, every other factor
         // that mentions them small.  Four and five variables are tried first, three only after the CHAIN form below.
@@ -1305,7 +1325,9 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
             }
             return false;
         };
-        if (sweep_max >= 4 && try_sweep(5, 4)) continue;
+        MIBN_TICK(3)  // sweep candidates
+        if (sweep_max >= 4 && try_sweep(5, 4)) { MIBN_TICK(4) continue; }
+        MIBN_TICK(4)  // SWEEP 5 / 4
         // Joint elimination: if the factor this step creates is a big table that the very next step consumes, both
         // variables are summed out in one pass over the inputs and the intermediate never touches HBM.
         // CHAIN: three consecutive 4-state variables of one big table in a single pass (planner.h)
@@ -1339,6 +1361,7 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
                         for (int j = n_in; j < n3; ++j) consume(ins[j]);
                         add_factor(S.n_pool - 1);
                         i += 2;
+                        MIBN_TICK(5)
                         continue;
                     }
                     --S.n_pool;
@@ -1346,8 +1369,10 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
                 }
             }
         }
-        if (sweep_max >= 3 && try_sweep(3, 3)) continue;
-        if (net.sweep_min <= 2 && sweep_max >= 2 && try_sweep(2, 2)) continue;  // (a pair of one big table: before the FIBER pair form)
+        MIBN_TICK(5)  // CHAIN
+        if (sweep_max >= 3 && try_sweep(3, 3)) { MIBN_TICK(6) continue; }
+        if (net.sweep_min <= 2 && sweep_max >= 2 && try_sweep(2, 2)) { MIBN_TICK(6) continue; }  // (a pair of one big table: before the FIBER pair form)
+        MIBN_TICK(6)  // SWEEP 3 / 2
         if (net.fuse && i + 1 < n_best && n_in < kMaxIn && S.n_pool + 1 <= S.pool_cap) {
             const int32_t x2 = best[i + 1];
             bool link = false;
@@ -1380,6 +1405,7 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
                         for (int j = n_in; j < n2; ++j) consume(ins[j]);
                         add_factor(S.n_pool - 1);
                         ++i;
+                        MIBN_TICK(7)
                         continue;
                     }
                     --S.n_pool;
@@ -1387,9 +1413,11 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
                 }
             }
         }
+        MIBN_TICK(7)  // pair
         const int out = emit_limited(n_in, x, false, 0);  // pointwise_mul + sum_out (785)
         if (em.err) return em.err;
         add_factor(out);
+        MIBN_TICK(8)  // single elimination
     }
     // posterior = pointwise_mul(factors) / sum (bayes_net.py:789-790), written in the caller's
     // query order (C-order, last query variable fastest)
@@ -1403,6 +1431,7 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
     if (prog.overflow) return kEmitErrWords;
     prog.data[count_pos] = (uint32_t)(st.n_steps - steps0);
     st.arena_cells = emit_max(st.arena_cells, em.arena.top);
+    MIBN_TICK(9)  // final product
     return 0;
 }
 

@@ -100,6 +100,10 @@ struct EmitArgs {
     int32_t lanes;                           // requests per wave (see OrderArgs)
 };
 
+#if defined(MIBN_EMIT_PROF)
+__device__ unsigned long long g_emit_prof[12];  // 100 MHz ticks per phase, summed over the lanes (see MIBN_TICK in emit_core.h)
+#endif
+
 __global__ __launch_bounds__(1024) void emit_kernel(const EmitArgs A) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
     if (lane >= A.lanes) return;
@@ -111,6 +115,13 @@ __global__ __launch_bounds__(1024) void emit_kernel(const EmitArgs A) {
     m.arena_cells = 0;
     uint32_t *slot = A.prog + (size_t)b * A.prog_stride;
     if (A.skip[b]) { slot[0] = 0; A.meta[b] = m; return; }
+#if defined(MIBN_EMIT_PROF)
+    EmitProf prof_;
+    for (int k = 0; k < 12; ++k) prof_.a[k] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    prof_.t = __builtin_amdgcn_s_memrealtime();
+#endif
+#endif
     EmitScratch S;
     emit_scratch_carve(S, A.scratch + (size_t)b * A.scratch_stride, A.net.n_vars);
     const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
@@ -120,7 +131,8 @@ __global__ __launch_bounds__(1024) void emit_kernel(const EmitArgs A) {
     buf.data = slot;
     buf.cap = A.prog_stride;
     EmitStats st;
-    if (!err) err = emit_run(A.net, S, buf, st, nullptr, nq, A.q_vars + q0, A.out_off[b], A.orders + b * 128, (int)A.order_len[b]);
+    MIBN_TICK(0)  // relevant set, evidence-sliced CPTs
+    if (!err) err = emit_run(A.net, S, buf, st, nullptr, nq, A.q_vars + q0, A.out_off[b], A.orders + b * 128, (int)A.order_len[b] MIBN_PROF_PASS);
     if (!err) {
         const uint32_t nt = tag_program(A.net, slot, [](const Tag &) {});
         const uint32_t first = atomicAdd(A.tag_cursor, nt);
@@ -133,6 +145,10 @@ __global__ __launch_bounds__(1024) void emit_kernel(const EmitArgs A) {
             err = kEmitErrWords;
         }
     }
+    MIBN_TICK(10)  // work items
+#if defined(MIBN_EMIT_PROF)
+    for (int k = 0; k < 12; ++k) atomicAdd(&g_emit_prof[k], prof_.a[k]);
+#endif
     m.err = err;
     m.words = (uint32_t)buf.size;
     m.alg_bytes = st.alg_bytes; m.alg_flops = st.alg_flops; m.n_steps = st.n_steps; m.max_step_cells = st.max_step_cells;
@@ -1284,6 +1300,18 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 ks->ms += dev_ms;
                 ks->items += (double)nd;
             }
+#if defined(MIBN_EMIT_PROF)
+            if (h->trace) {
+                unsigned long long hp[12], z[12] = {0};
+                HIP_TRY(h, hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_emit_prof), sizeof(hp)));
+                HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_emit_prof), z, sizeof(z)));
+                static const char *names[11] = {"begin (relevant set, CPT slices)", "key / pos / slot sets", "factors of x", "sweep candidates", "SWEEP 5 / 4", "CHAIN",
+                                                "SWEEP 3 / 2", "pair", "single elimination", "final product", "work items"};
+                double tot = 0;
+                for (int k = 0; k < 11; ++k) tot += (double)hp[k];
+                for (int k = 0; k < 11; ++k) std::fprintf(stderr, "[mibn emit phases] %-36s %6.1f us per request  %5.1f %%\n", names[k], (double)hp[k] / 100.0 / (double)nd, 100.0 * (double)hp[k] / tot);
+            }
+#endif
             if (h->trace) std::fprintf(stderr, "[mibn plan] chunk of %lld: device %lld requests (upload + launch %.2f ms, kernels %.2f ms, wait + collect %.2f ms), host %lld requests %.2f ms\n",
                                        (long long)n, (long long)nd, t_launched - t0, dev_ms, now_ms() - tw, (long long)(n - nd), host_ms);
             if (rc < 0 || rc > 1) return rc;

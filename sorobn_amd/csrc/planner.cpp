@@ -436,6 +436,10 @@ struct PlanRecord {
 
 }  // namespace
 
+#if defined(MIBN_EMIT_PROF)
+EmitProf g_host_emit_prof = {};
+#endif
+
 // host side of emit_core.h: growth of the ProgBuf behind an EmitBuf, the plan templates' record
 uint32_t *emit_buf_grow(EmitBuf &b, size_t words) {
     uint32_t *p = b.host->extend(words);
@@ -556,7 +560,11 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     EmitStats es;
     es.alg_bytes = st.alg_bytes; es.alg_flops = st.alg_flops; es.n_steps = st.n_steps; es.max_step_cells = st.max_step_cells;
     es.arena_cells = st.arena_cells; es.out_cells = st.out_cells;
-    const int e = emit_run(en, ES, eb, es, rec, rq.nq, rq.qvars, rq.out_off, best.data(), (int)best.size());
+#if defined(MIBN_EMIT_PROF)  // (tools/planner_prof.cpp, single-threaded: phase times of the emission in TSC ticks)
+    EmitProf &prof_ = g_host_emit_prof;
+    prof_.t = __builtin_ia32_rdtsc();
+#endif
+    const int e = emit_run(en, ES, eb, es, rec, rq.nq, rq.qvars, rq.out_off, best.data(), (int)best.size() MIBN_PROF_PASS);
     st.alg_bytes = es.alg_bytes; st.alg_flops = es.alg_flops; st.n_steps = es.n_steps; st.max_step_cells = es.max_step_cells;
     st.arena_cells = es.arena_cells; st.out_cells = es.out_cells;
     return emit_error_message(e);

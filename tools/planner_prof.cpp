@@ -110,6 +110,15 @@ int main(int argc, char **argv) {
         std::printf("per request: sweep %.2f MB, one-table MFMA %.2f MB, two-table joins %.2f MB, rest %.2f MB; estimated kernel time %.2f us per request\n",
                     sweep / B / 1e6, mfma1 / B / 1e6, joins / B / 1e6, rest / B / 1e6, est_ms * 1e3 / B);
     }
+#if defined(MIBN_EMIT_PROF)  // g++ ... -DMIBN_EMIT_PROF, one thread: where the emission's time goes (phases of emit_run, emit_core.h)
+    {
+        static const char *names[11] = {"begin", "key / pos / slot sets", "factors of x", "sweep candidates", "SWEEP 5 / 4", "CHAIN", "SWEEP 3 / 2", "pair",
+                                        "single elimination", "final product", "work items"};
+        double tot = 0;
+        for (int k = 0; k < 11; ++k) tot += (double)g_host_emit_prof.a[k];
+        for (int k = 0; k < 11; ++k) std::printf("  emit phase %-24s %5.1f %%\n", names[k], 100.0 * (double)g_host_emit_prof.a[k] / tot);
+    }
+#endif
     std::printf("threads %d: %.1f ms for %lld requests = %.2f us/request/thread (x%d threads), %.0f req/s; %.1f steps, %.0f words, %.2f MB per request\n",
                 threads, best, (long long)B, best * 1e3 / B * threads, threads, B / best * 1e3, bp.st.n_steps / B, (double)bp.total_words / B, bp.st.alg_bytes / B / 1e6);
     return 0;
