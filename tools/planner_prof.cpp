@@ -107,6 +107,8 @@ int main(int argc, char **argv) {
             else rest += by[k];
             est_ms += by[k] / rate / 1e6;
         }
+        for (int k = 0; k < kNumKernels; ++k)
+            if (by[k] / B > 2e4) std::printf("  %-28s %7.3f MB per request\n", kernel_name(k), by[k] / B / 1e6);
         std::printf("per request: sweep %.2f MB, one-table MFMA %.2f MB, two-table joins %.2f MB, rest %.2f MB; estimated kernel time %.2f us per request\n",
                     sweep / B / 1e6, mfma1 / B / 1e6, joins / B / 1e6, rest / B / 1e6, est_ms * 1e3 / B);
     }
