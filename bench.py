@@ -509,6 +509,8 @@ def main():
         # time: the same figures for each of them, so that the line does not depend on which one is ahead in this run
         out["roofline"]["per_kernel"] = {}
         for n, d in kagg.items():
+            if d["alg_bytes"] <= 0:  # (the device planner's pair of kernels: no section-8(d) bytes, see "kernels")
+                continue
             la = max(1.0, d["launches"])
             gbps = d["alg_bytes"] / max(d["ms"], 1e-9) / 1e6
             out["roofline"]["per_kernel"][n] = {"achieved": gbps, "frac": gbps / HBM_PEAK_GBS, "alg_bytes_per_launch": d["alg_bytes"] / la,
