@@ -891,7 +891,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
     }
     if ((rc = ensure(h, st.d_prog, st.prog_cap, std::max(prog_words, (size_t)n * stride)))) return rc;  // (+ room for the host's share of the chunk)
     if (!h->emit_ev[0]) { HIP_TRY(h, hipEventCreate(&h->emit_ev[0])); HIP_TRY(h, hipEventCreate(&h->emit_ev[1])); }
-    // one pinned staging buffer, one DMA: [q_off | e_off | out_off | q_vars | e_vars | e_codes | skip]
+    // the request arrays of the chunk in one pinned buffer: [q_off | e_off | out_off | q_vars | e_vars | e_codes | skip]
     char *pin = h->emit_in.p;
     int64_t *qo = reinterpret_cast<int64_t *>(pin), *eo = qo + (n + 1), *oo = eo + (n + 1);
     for (int64_t i = 0; i <= n; ++i) { qo[i] = q_off[b0 + i] - q_off[b0]; eo[i] = e_off[b0 + i] - e_off[b0]; oo[i] = out_off[b0 + i] - out_off[b0]; }
