@@ -40,3 +40,18 @@ for l in sys.stdin:
         print('%-28s %.0f q/s  ms/step %.1f  kernel %.1f plan %.1f  device-planned requests per step %.0f' % ('$args', d['value'], d['ms_per_step'], b['kernel_ms'], b['plan_ms'], d['config']['device_planned_requests_per_step']))
 " | tee -a $OUT/${TAG}_threads.log
 done
+# the device planner at scale: 262 144 requests of the C3 stream planned by the host's workers and by order_kernel + emit_kernel -
+# the posteriors must agree bit for bit
+python - <<'PY' 2>&1 | tee -a $OUT/${TAG}_threads.log
+import sys, time
+sys.path.insert(0, "tests")
+import numpy as np, netspec, sorobn_amd
+bn = netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet).use_device(0)
+be = bn.backend
+to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+q, ev, ec = netspec.c3_requests(100, 4, 262144, 4, seed=1)
+t0 = time.perf_counter(); host = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec); t1 = time.perf_counter()
+be.engine.set_option("gpu_emit", 1); be.engine.set_option("emit_share", 1.0)
+dev = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec); t2 = time.perf_counter()
+print("device planner at scale: 262144 requests, posteriors identical bit for bit: %s (host-planned %.2f s, device-planned %.2f s, blocking calls)" % (bool(np.array_equal(host, dev)), t1 - t0, t2 - t1))
+PY
