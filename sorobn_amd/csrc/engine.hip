@@ -234,6 +234,7 @@ struct mibn_ctx {
     bool auto_search = false;  // gpu_search was switched on by the adaptive policy
     bool auto_emit = false;    // gpu_emit was
     int host_bound_streak = 0;
+    bool adaptive_seeded = false;
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
     // device order search (order_kernel)
     int plan_lanes = 32;             // requests per wave of order_kernel / emit_kernel (1..64)
@@ -524,7 +525,15 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "emit_words") h->emit_words = (uint32_t)std::max(1024, std::min(1 << 20, (int)value));  // words of a request's device program slot
     else if (n == "gpu_search") h->gpu_search = std::max(0, std::min(2, (int)value));  // elimination-order search on the device
         // (order_kernel): 1 = the first chunk of a call on the host, the rest of the call by one launch; 2 = every chunk, synchronously (tests)
-    else if (n == "adaptive") { h->adaptive = value != 0; if (!h->adaptive) h->net.minfill_above = h->base_minfill; }
+    else if (n == "adaptive") {
+        h->adaptive = value != 0;
+        if (!h->adaptive) {  // what the policy had switched goes back
+            h->net.minfill_above = h->base_minfill;
+            if (h->auto_emit) { h->gpu_emit = 0; h->auto_emit = false; }
+            if (h->auto_search) { h->gpu_search = 0; h->auto_search = false; }
+            h->adaptive_seeded = false;
+        }
+    }
     else if (n == "minfill_above") { h->base_minfill = value; h->net.minfill_above = value; }  // bytes of the best sweep above which min-fill runs  // small-network kernel (one lane per request, no planning) where eligible
     else if (n == "fuse") h->net.fuse = value != 0;
     else if (n == "plan_cache") h->net.plan_cache = value != 0;  // plan templates for repeated request shapes
@@ -560,6 +569,8 @@ int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64
     std::string e = h->net.set(n_vars, card, scope_off, scope_vars, value_off, values);
     if (!e.empty()) { h->err = e; h->has_net = false; return MIBN_E_ARG; }
     h->has_net = true;
+    h->adaptive_seeded = false;  // (the adaptive policy starts over with a new network)
+    if (h->auto_emit) { h->gpu_emit = 0; h->auto_emit = false; }
     if (!h->planner_only) {
         HIP_TRY(h, hipSetDevice(h->device));
         if (h->d_pool) { HIP_TRY(h, hipFree(h->d_pool)); h->d_pool = nullptr; }
@@ -1166,6 +1177,13 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     }
     ensure_pool(h);
     if (h->trace) std::fprintf(stderr, "[mibn plan] validation of %lld requests %.2f ms\n", (long long)B, now_ms() - t_start);
+    if (h->adaptive && !h->adaptive_seeded) {
+        // A rank with a handful of planning threads (8 ranks on a 16-CPU quota: 2-4 each) cannot plan a stream like C3 at the rate
+        // its GPU executes it (67 / 133 k queries/s at 2 / 4 threads against 280 k): it starts with the device planner instead of
+        // finding that out over several host-bound calls; the share controller gives the planning back where the host keeps up.
+        h->adaptive_seeded = true;
+        if (h->pool->size() <= 4 && h->order_net_ok && h->emit_net_ok && !h->gpu_emit) { h->gpu_emit = 1; h->auto_emit = true; }
+    }
     if (h->adaptive) {
         // over the calls since the last adjustment: host planning wall time against GPU kernel time (retired launches)
         const double dp = h->total.plan_ms - h->seen_plan_ms, dk = h->total.kernel_ms - h->seen_kernel_ms;
