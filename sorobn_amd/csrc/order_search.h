@@ -72,8 +72,6 @@ struct OrderScratch {
     B2 adj[128];
     double ws[128];
     int32_t miss[128];
-    int32_t hid[128];
-    uint8_t alive[128];
     // candidates
     uint8_t cand[128], best[128];
     int32_t n_cand, n_best;
@@ -163,13 +161,11 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
         b2_each(sc, [&](int v) { adj[v].a |= sc.a; adj[v].b |= sc.b; });
     }
     for (int v = 0; v < n; ++v) adj[v].clr(v);
-    int32_t *hid = S.hid;
-    int n_alive = 0;
-    b2_each(hidden, [&](int v) { hid[n_alive++] = v; });
     double *ws = S.ws;
     int32_t *miss = S.miss;
-    uint8_t *alive = S.alive;
-    for (int v = 0; v < n; ++v) alive[v] = 0;
+    B2 alive = hidden;  // the vertices not yet eliminated - a register pair, scanned in ascending order (the order of the list the
+                        // first version kept in memory: two loads fewer per candidate, the same winner)
+    int n_alive = __builtin_popcountll(hidden.a) + __builtin_popcountll(hidden.b);
     auto full = [&](int x) {
         const B2 ax = adj[x];
         double w = 0;
@@ -181,30 +177,27 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
         ws[x] = w;
         miss[x] = missing;
     };
-    for (int i = 0; i < n_alive; ++i) { full(hid[i]); alive[hid[i]] = 1; }
+    b2_each(alive, [&](int x) { full(x); });
     S.n_cand = 0;
     const int total = n_alive;
     double created = 0;
     for (int it = 0; it < total; ++it) {
-        int best = -1;
+        int best = -1, dbest = 0;
         double wbest = 0;
-        int k = 0;
-        for (int i = 0; i < n_alive; ++i) {
-            const int x = hid[i];
-            if (!alive[x]) continue;
-            hid[k++] = x;
+        b2_each(alive, [&](int x) {
             const double wx = miss[x] * 64.0 + ws[x];
             const double d = wx - wbest;
-            if (best < 0 || wx < wbest - 1e-12 ||
-                ((d < 0 ? -d : d) <= 1e-12 &&
-                 (net.depth[x] < net.depth[best] || (net.depth[x] == net.depth[best] && x < best)))) {
+            if (best < 0 || wx < wbest - 1e-12) {
                 best = x;
                 wbest = wx;
+                dbest = net.depth[x];
+            } else if ((d < 0 ? -d : d) <= 1e-12) {
+                const int dx = net.depth[x];
+                if (dx < dbest || (dx == dbest && x < best)) { best = x; wbest = wx; dbest = dx; }
             }
-        }
-        n_alive = k;
+        });
         S.cand[S.n_cand++] = (uint8_t)best;
-        alive[best] = 0;
+        alive.clr(best);
         created += order_exp2(ws[best]);  // cells of the factor this elimination creates (its scope = the neighbours)
         if (16.0 * net.chain_weight * created > abort_above) return false;
         const B2 nb = adj[best];
@@ -228,7 +221,7 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
             adj[y].clr(best);
             adj[y].clr(y);
         });
-        b2_each(nb, [&](int y) { if (alive[y]) full(y); });
+        b2_each(nb, [&](int y) { if (alive.test(y)) full(y); });
     }
     return true;
 }
