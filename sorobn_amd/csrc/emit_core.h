@@ -1207,7 +1207,7 @@ template <class OrderT>
 MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, EmitStats &st, void *rec, int nq, const int32_t *qvars,
                             int64_t out_off, const OrderT *best, int n_best MIBN_PROF_ARG) {
     PF *pool = S.pool;
-    for (int v = 0; v < net.n_vars; ++v) { S.key[v] = 0.0; S.pos[v] = -1; }
+    S.rel.for_each([&](int v) { S.key[v] = 0.0; S.pos[v] = -1; });  // (only relevant variables are axes of anything)
     Emitter em{net, prog, st, Arena{}, S.key, S.pos, 0, rec};
     for (int i = 0; i < n_best; ++i) S.key[best[i]] = (double)i;
     for (int i = 0; i < nq; ++i) S.key[qvars[i]] = 1e9 + i;
@@ -1255,7 +1255,8 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
     MIBN_TICK(1)  // key / pos / slot sets
     // factors alive whose scope contains a (or b, if b >= 0), in slot order; f(idx) returns false to stop early
     auto each_with = [&](int a, int b, auto f) {
-        for (int k = 0; k < sw; ++k) {
+        const int kw = (S.n_pool + 63) >> 6;  // (slots handed out so far: the words beyond are all zero)
+        for (int k = 0; k < kw; ++k) {
             uint64_t m = (mem[(size_t)a * sw + k] | (b >= 0 ? mem[(size_t)b * sw + k] : 0ull)) & alive[k];
             for (; m; m &= m - 1)
                 if (!f(k * 64 + __builtin_ctzll(m))) return;
@@ -1424,7 +1425,7 @@ MIBN_HD inline int emit_run(const EmitNet &net, EmitScratch &S, EmitBuf &prog, E
     st.out_cells = 1;
     for (int i = 0; i < nq; ++i) st.out_cells *= net.card[qvars[i]];
     int n_in = 0;
-    for (int k = 0; k < sw; ++k)
+    for (int k = 0; k < ((S.n_pool + 63) >> 6); ++k)
         for (uint64_t m = alive[k]; m; m &= m - 1) ins[n_in++] = &pool[k * 64 + __builtin_ctzll(m)];
     emit_limited(n_in, -1, true, out_off);
     if (em.err) return em.err;

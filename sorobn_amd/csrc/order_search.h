@@ -95,11 +95,13 @@ MIBN_HD inline double order_cells(const OrderNet &net, const B2 &u) {
 // slots whose scope contains it, so an elimination touches only the factors it consumes.
 MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const uint8_t *order, int n_order, double abort_above) {
     const int nv = net.n_vars;
+    int nf = S.n_f0;
+    // slot words in use: the request's factors + one per elimination (the rest of a row is neither written nor read)
+    const int kw = (nf + n_order + 64) / 64 < kOrderSlotWords ? (nf + n_order + 64) / 64 : kOrderSlotWords;
     for (int v = 0; v < nv; ++v)
-        for (int k = 0; k < kOrderSlotWords; ++k) S.mem[v][k] = 0;
+        for (int k = 0; k < kw; ++k) S.mem[v][k] = 0;
     uint64_t alive[kOrderSlotWords];
     for (int k = 0; k < kOrderSlotWords; ++k) alive[k] = 0;
-    int nf = S.n_f0;
     for (int i = 0; i < nf; ++i) {
         S.f[i] = S.f0[i];
         S.fc[i] = S.f0c[i];
@@ -112,7 +114,7 @@ MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const
         B2 u;
         double in = 0;
         int nbig = 0;
-        for (int k = 0; k < kOrderSlotWords; ++k) {
+        for (int k = 0; k < kw; ++k) {
             uint64_t m = S.mem[x][k] & alive[k];
             alive[k] &= ~m;
             for (; m; m &= m - 1) {
@@ -135,7 +137,7 @@ MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const
     }
     B2 u;
     double in = 0;
-    for (int k = 0; k < kOrderSlotWords; ++k)
+    for (int k = 0; k < kw; ++k)
         for (uint64_t m = alive[k]; m; m &= m - 1) {
             const int i = k * 64 + __builtin_ctzll(m);
             u.a |= S.f[i].a;
