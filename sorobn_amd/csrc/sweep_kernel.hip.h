@@ -238,7 +238,6 @@ __device__ __forceinline__ void sweep_tiles_any(double *__restrict__ L, const do
     sweep_build_tables(tb, tid);
     const int Rt = 1 << rb;
     const int ocells = Rt << (2 * kout);
-    const int p_tid = sweep_perm(tid, kout, rb, surv);
     const int rp = tid & ((Rt >> 1) - 1);
     const long g_tid = (long)(tid >> (rb - 1)) * Rcells + 2 * rp;
     const long g_step = (long)(kSweepWG >> (rb - 1)) * Rcells;
@@ -743,7 +742,6 @@ __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_kernel(const LevelArgs A
     for (int i = tid; i < words; i += kSweepWG) sh_step[i] = p[i];
     __syncthreads();
     const int k = uni((int)((sh_step[0] >> 16) & 0xff)), rb = uni((int)((sh_step[0] >> 24) & 0xff));
-    const int Rt = 1 << rb;
     const int tiles = uni((int)sh_step[3]);
     const int kout = uni((int)(sh_step[7] & 0xffff)), t_total = uni((int)(sh_step[7] >> 16));
     const uint32_t surv = (uint32_t)uni((int)sh_step[8]);
