@@ -540,6 +540,29 @@ def test_device_planner_writes_the_host_programs(amd):
             _check_requests(b, requests, net_spec["name"] + " gpu_emit")
 
 
+def test_adaptive_policy_starts_a_starved_rank_on_the_device_planner(amd):
+    """Option adaptive (bench.py switches it on): an engine with at most four planning threads - a rank of an 8-GPU node with a
+    16-CPU quota - plans on the device from its first call (engine.hip, run_batch); the answers are the host-planned ones bit for
+    bit, and switching the policy off gives the planning back."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    q, ev, ec = netspec.c3_requests(100, 4, 4096, 4, seed=1)
+    ref_bn = netspec.build(spec, amd.BayesNet)
+    to_var = np.array([ref_bn.backend.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    host = ref_bn.backend.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert "order_kernel+emit_kernel" not in [k["name"] for k in ref_bn.backend.engine.kernel_stats()]
+    bn = netspec.build(spec, amd.BayesNet)
+    eng = bn.backend.engine
+    eng.set_option("threads", 2)
+    eng.set_option("adaptive", 1)
+    for _ in range(2):
+        assert np.array_equal(eng.query_fixed(to_var[q][:, None], to_var[ev], ec), host)
+        planned = [k for k in eng.kernel_stats() if k["name"] == "order_kernel+emit_kernel"]
+        assert planned and planned[0]["items"] > 0
+    eng.set_option("adaptive", 0)
+    assert np.array_equal(eng.query_fixed(to_var[q][:, None], to_var[ev], ec), host)
+    assert "order_kernel+emit_kernel" not in [k["name"] for k in eng.kernel_stats()]
+
+
 def test_device_order_search_reproduces_the_host_search(amd):
     """Option gpu_search: the elimination-order search runs as a kernel (order_kernel: one request per lane, the very
     code of csrc/order_search.h that the host runs).  Same orders => same programs => the same posteriors bit for bit
