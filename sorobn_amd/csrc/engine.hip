@@ -55,7 +55,13 @@ struct OrderArgs {
 // (Workgroups of up to 16 waves - no cooperation between them, only placement: the waves of a workgroup share a CU, so the 512
 // waves of a chunk take 32 CUs whole instead of one workgroup's worth of registers on every CU - beside the level and sweep
 // kernels, whose workgroups fill a CU's register file exactly, that is an eighth of the chip instead of a third to a half.)
-__global__ __launch_bounds__(1024) void order_kernel(const OrderArgs A) {
+#ifndef MIBN_ORDER_WAVES_PER_EU
+#define MIBN_ORDER_WAVES_PER_EU 4  // build-time experiment hooks: the register budget of the planner's kernels (waves per SIMD)
+#endif
+#ifndef MIBN_EMIT_WAVES_PER_EU
+#define MIBN_EMIT_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(1024, MIBN_ORDER_WAVES_PER_EU) void order_kernel(const OrderArgs A) {
     if (A.zero && blockIdx.x == 0 && threadIdx.x == 0) *A.zero = 0;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
     if (lane >= A.lanes) return;
@@ -104,7 +110,7 @@ struct EmitArgs {
 __device__ unsigned long long g_emit_prof[12];  // 100 MHz ticks per phase, summed over the lanes (see MIBN_TICK in emit_core.h)
 #endif
 
-__global__ __launch_bounds__(1024) void emit_kernel(const EmitArgs A) {
+__global__ __launch_bounds__(1024, MIBN_EMIT_WAVES_PER_EU) void emit_kernel(const EmitArgs A) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
     if (lane >= A.lanes) return;
     const int64_t b = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
