@@ -538,6 +538,18 @@ def test_device_planner_writes_the_host_programs(amd):
             for a, w in zip(got, want):
                 assert a.index.equals(w.index) and np.array_equal(a.to_numpy(), w.to_numpy())
             _check_requests(b, requests, net_spec["name"] + " gpu_emit")
+    # the four example networks and friends (no tiny kernel: step programs), and networks of more than 128 variables - which the
+    # device planner does not cover: the option is accepted and the host plans
+    for net in gu.load("examples.json"):
+        b = netspec.build(net["spec"], amd.BayesNet)
+        b.backend.engine.set_option("tiny", 0)
+        b.backend.engine.set_option("gpu_emit", 2)
+        _check_requests(b, net["requests"], net["spec"]["name"] + " gpu_emit")
+    for net in gu.load("many_nodes.json"):
+        b = netspec.build(net["spec"], amd.BayesNet)
+        b.backend.engine.set_option("gpu_emit", 2)
+        _check_requests(b, net["requests"], net["spec"]["name"] + " gpu_emit (host)")
+        assert "order_kernel+emit_kernel" not in [k["name"] for k in b.backend.engine.kernel_stats()]
 
 
 def test_adaptive_policy_starts_a_starved_rank_on_the_device_planner(amd):
