@@ -236,6 +236,17 @@ int mibn_sample(mibn_t *h, int64_t n_samples, int32_t n_init, const int32_t *ini
 int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,
                         const int32_t *e_codes, int64_t n_samples, uint64_t seed, double *weight_sum, int64_t *counts);
 
+/* Parity hook for the deterministic half of the sampling paths (tests): sample_kernel ITSELF walks n_rows GIVEN joint states
+ * (states[row * n_vars + v] = label code) exactly as it walks a sample it draws - same CPT offsets, same row sums, same running
+ * sums, same likelihood product - and writes them out instead of drawing from them:
+ *   likelihood[row]                        the product of P(state_v | parents in the state) over ALL nodes, the weight
+ *                                          _forward_sample hands to _llh_weighting (bayes_net.py:541-546, 646-652)
+ *   cdf[(row * n_vars + v) * cdf_stride + x]   x < card(v): the running sum of the conditional row P(v = . | parents in the state)
+ *                                          the inverse-CDF draw of v compares u * total with (total = the entry at card(v) - 1) -
+ *                                          the weights the reference hands to its alias sampler (bayes_net.py:28-42, 530-539)
+ * Only the random stream of the sampling paths stays unpinned (the reference's depends on the absent third-party `vose`). */
+int mibn_sample_probe(mibn_t *h, int64_t n_rows, const uint8_t *states, int32_t cdf_stride, double *likelihood, double *cdf);
+
 /*
  * Grouped counting of label codes: the `X.groupby([*parents, node]).size()` of
  * BayesNet.partial_fit (bayes_net.py:467-510) and the pairwise `X.groupby([u, v]).size()` of structure.chow_liu

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mibn_total_kernel_stats", "mibn_sample", "mibn_sampling_query", "mibn_count_tables",
     "mibn_query_batch_ex", "mibn_plan_order", "mibn_estimate_costs", "mibn_device_synchronize", "mibn_gibbs_shard",
     "mibn_comm_unique_id", "mibn_comm_init", "mibn_comm_destroy", "mibn_comm_allgather_f64",
-    "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier", "mibn_gibbs_conditional",
+    "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier", "mibn_gibbs_conditional", "mibn_sample_probe",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -93,6 +93,7 @@ def lib():
         L.mibn_total_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mibn_total_kernel_stats.argtypes = [vp, C.c_int32, C.POINTER(KernelStat), C.POINTER(C.c_int32)]
         L.mibn_sample.argtypes = [vp, C.c_int64, C.c_int32, i32p, i32p, C.c_uint64, C.POINTER(C.c_uint8)]
+        L.mibn_sample_probe.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint8), C.c_int32, f64p, f64p]
         L.mibn_sampling_query.argtypes = [vp, C.c_int32, C.c_int32, i32p, C.c_int32, i32p, i32p, C.c_int64, C.c_uint64, f64p, i64p]
         L.mibn_count_tables.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_uint8), C.c_int32, i32p, C.c_int32, i64p, i32p, i64p, i64p]
         L.mibn_last_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -376,6 +377,17 @@ class Engine:
         self._check(self._L.mibn_sample(self._h, int(n_samples), len(iv), _p(iv_, C.c_int32), _p(ic_, C.c_int32),
                                         int(seed) & (2**64 - 1), out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
+
+    def sample_probe(self, states):
+        """The sampling kernel's walk over GIVEN joint states [n_rows, n_vars] (mibn_sample_probe) -> (likelihood [n_rows],
+        running sums of every variable's conditional row [n_rows, n_vars, max card])."""
+        st = np.ascontiguousarray(states, np.uint8).reshape(-1, len(self.card))
+        stride = int(self.card.max())
+        lik = np.zeros(len(st), np.float64)
+        cdf = np.zeros((len(st), len(self.card), stride), np.float64)
+        self._check(self._L.mibn_sample_probe(self._h, len(st), st.ctypes.data_as(C.POINTER(C.c_uint8)), stride,
+                                              _p(lik, C.c_double), _p(cdf, C.c_double)))
+        return lik, cdf
 
     def sampling_query(self, mode, qvars, evars, ecodes, n_samples, seed=0):
         """mode 1 = rejection, 2 = likelihood weighting -> (weight_sum, counts) per joint query state."""

@@ -1476,7 +1476,11 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             // have finished.  The tail of one launch - a sweep workgroup lives ~100 us - then runs under the body of the other.
             const bool two = h->overlap && n_lanes == 1;
             hipStream_t S2 = h->stream2;
-            long last_a = -1, last_b = -1, a_saw_b = -1, b_saw_a = (long)e_first;  // event indices: last launch end on S / S2, and what the other stream has waited for
+            // event indices: the last launch end on S / S2 (running), the ends of the PREVIOUS level's launches (what the launches of
+            // this level wait for on the other stream - not the running ones: the level kernel's launch of level L comes first and
+            // the sweep launch of the same level must not wait for it), and what either stream has already waited for
+            long last_a = -1, last_b = -1, prev_a = -1, prev_b = -1, a_saw_b = -1, b_saw_a = (long)e_first;
+            int cur_level = -1;
             if (two) HIP_TRY(h, hipStreamWaitEvent(S2, st.ev[e_first], 0));  // (the uploads, the previous wave's kernels: the arena is theirs until then)
             for (size_t li = 0; li < sc.launches.size();) {
                 // one launch of the level kernel per level (all its classes of work together) unless split_kinds, and one
@@ -1496,8 +1500,9 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 size_t e0 = 0, e1 = 0;
                 hipStream_t Sx = (two && sweep) ? S2 : S;
                 if (two) {  // the previous level's launch on the other stream
-                    if (sweep && last_a > b_saw_a) { HIP_TRY(h, hipStreamWaitEvent(S2, st.ev[(size_t)last_a], 0)); b_saw_a = last_a; }
-                    if (!sweep && last_b > a_saw_b) { HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)last_b], 0)); a_saw_b = last_b; }
+                    if (L.level != cur_level) { cur_level = L.level; prev_a = last_a; prev_b = last_b; }
+                    if (sweep && prev_a > b_saw_a) { HIP_TRY(h, hipStreamWaitEvent(S2, st.ev[(size_t)prev_a], 0)); b_saw_a = prev_a; }
+                    if (!sweep && prev_b > a_saw_b) { HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)prev_b], 0)); a_saw_b = prev_b; }
                 }
                 if ((rc = next_event(h, st, e0, Sx))) return rc;
                 if (sweep && h->sweep_dma) hipLaunchKernelGGL(ve_sweep_dma_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, Sx, A);
@@ -1701,6 +1706,21 @@ extern "C" int mibn_sample(mibn_t *h, int64_t n_samples, int32_t n_init, const i
     HIP_TRY(h, hipSetDevice(h->device));
     return sample_run(h->net, h->d_pool, h->stream, kSampleMode, 0, nullptr, n_init, init_vars, init_codes, 0, nullptr, nullptr,
                       n_samples, seed, states, nullptr, nullptr, h->err);
+}
+
+extern "C" int mibn_sample_probe(mibn_t *h, int64_t n_rows, const uint8_t *states, int32_t cdf_stride, double *likelihood, double *cdf) {
+    if (!h || n_rows < 0 || (n_rows && (!states || !likelihood || !cdf))) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
+    if (!h->has_net) { h->err = "set_network first"; return MIBN_E_STATE; }
+    for (int v = 0; v < h->net.n_vars; ++v)
+        if (h->net.card[v] > cdf_stride) { h->err = "sample probe: cdf_stride below a variable's cardinality"; return MIBN_E_ARG; }
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int v = 0; v < h->net.n_vars; ++v)
+            if (states[r * h->net.n_vars + v] >= h->net.card[v]) { h->err = "sample probe: a state code is outside its variable's domain"; return MIBN_E_ARG; }
+    if (n_rows == 0) return MIBN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return sample_run(h->net, h->d_pool, h->stream, kProbeMode, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, n_rows, 0,
+                      const_cast<uint8_t *>(states), nullptr, nullptr, h->err, cdf_stride, likelihood, cdf);
 }
 
 extern "C" int mibn_sampling_query(mibn_t *h, int32_t mode, int32_t n_q, const int32_t *q_vars, int32_t n_e, const int32_t *e_vars,

@@ -34,7 +34,10 @@ struct SampleArgs {
     const int32_t *qstride;
     const int32_t *evars;         // REJECTION: the event to agree with
     const int32_t *ecodes;
-    uint8_t *states;              // SAMPLE: [n_samples][n_vars]
+    uint8_t *states;              // SAMPLE: [n_samples][n_vars] (out); PROBE: the given joint states (in)
+    double *cdf;                  // PROBE: [n_samples][n_vars][cdf_stride] running sums of the conditional row a draw of v compares u * total with
+    double *lik;                  // PROBE: [n_samples] the likelihood of the given state
+    int32_t cdf_stride;
     double *wsum;                 // LIKELIHOOD: sum of likelihoods per query cell
     unsigned long long *counts;   // samples per query cell (REJECTION: accepted ones)
     int32_t n_vars, n_q, n_e, hist_cells, mode;
@@ -43,6 +46,9 @@ struct SampleArgs {
 };
 
 constexpr int kSampleMode = 0, kRejectionMode = 1, kLikelihoodMode = 2;
+// PROBE (mibn_sample_probe, parity hook): the walk of the kernel over GIVEN joint states - same offsets, same row sums, same
+// running sums a draw compares its uniform with, same likelihood product - written out instead of drawn from / histogrammed
+constexpr int kProbeMode = 3;
 
 __global__ __launch_bounds__(64) void sample_kernel(const SampleArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -63,7 +69,8 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleArgs A) {
             for (int k = 0; k + 1 < V.scope_len; ++k)
                 off += (int)st[A.scope_var[V.scope_begin + k] * 64 + lane] * A.scope_stride[V.scope_begin + k];
             int val = V.ev_code;
-            if (!V.is_evidence) {
+            const bool probe = A.mode == kProbeMode;
+            if (!V.is_evidence || probe) {
                 // P.cdt.sample(): a draw from the (possibly unnormalised / sparse) conditional row (bayes_net.py:28-42)
                 double total = 0;
                 for (int x = 0; x < V.card; ++x) total += A.pool[off + x];
@@ -72,13 +79,16 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleArgs A) {
                 val = V.card - 1;
                 for (int x = 0; x < V.card; ++x) {
                     acc += A.pool[off + x];
+                    if (probe) { if (active) A.cdf[((size_t)s * A.n_vars + v) * A.cdf_stride + x] = acc; continue; }
                     if (u < acc) { val = x; break; }
                 }
+                if (probe) val = active ? (int)A.states[(size_t)s * A.n_vars + v] : 0;
             }
             st[v * 64 + lane] = (uint8_t)val;
             likelihood *= A.pool[off + val];  // P.get(node_value, 0): absent rows are 0 in the dense table
         }
         if (!active) continue;
+        if (A.mode == kProbeMode) { A.lik[s] = likelihood; continue; }
         if (A.mode == kSampleMode) {
             for (int v = 0; v < A.n_vars; ++v) A.states[s * A.n_vars + v] = st[v * 64 + lane];
             continue;
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const SampleArgs A) {
 inline int sample_run(const Network &net, const double *d_pool, hipStream_t stream, int mode, int32_t n_q, const int32_t *q_vars,
                       int32_t n_clamp, const int32_t *clamp_vars, const int32_t *clamp_codes, int32_t n_ev, const int32_t *ev_vars,
                       const int32_t *ev_codes, int64_t n_samples, uint64_t seed, uint8_t *states, double *wsum, int64_t *counts,
-                      std::string &err) {
+                      std::string &err, int32_t cdf_stride = 0, double *probe_lik = nullptr, double *probe_cdf = nullptr) {
     const int n = net.n_vars;
     std::vector<GibbsVar> vars(n);
     std::vector<int32_t> scope_var, scope_stride;
@@ -147,7 +157,10 @@ inline int sample_run(const Network &net, const double *d_pool, hipStream_t stre
     const size_t o_sv = put(scope_var), o_ss = put(scope_stride);
     const size_t o_q = put(std::vector<int32_t>(q_vars, q_vars + n_q)), o_qs = put(qstride);
     const size_t o_ev = put(std::vector<int32_t>(ev_vars, ev_vars + n_ev)), o_ec = put(std::vector<int32_t>(ev_codes, ev_codes + n_ev));
-    const size_t out_bytes = mode == kSampleMode ? (size_t)n_samples * n : (size_t)cells * 16;
+    // PROBE: the given states | likelihoods | running sums
+    const size_t probe_states = ((size_t)n_samples * n + 7) & ~size_t(7);
+    const size_t out_bytes = mode == kSampleMode ? (size_t)n_samples * n
+                             : mode == kProbeMode ? probe_states + (size_t)n_samples * 8 * (1 + (size_t)n * cdf_stride) : (size_t)cells * 16;
     auto fail = [&](hipError_t e) { err = std::string("sampling: ") + hipGetErrorString(e); hipFree(d_vars); hipFree(d_i32); hipFree(d_out); return MIBN_E_HIP; };
     hipError_t e;
     if ((e = hipMalloc(&d_vars, sizeof(GibbsVar) * std::max(1, n))) != hipSuccess) return fail(e);
@@ -156,6 +169,7 @@ inline int sample_run(const Network &net, const double *d_pool, hipStream_t stre
     if ((e = hipMemcpyAsync(d_vars, vars.data(), sizeof(GibbsVar) * n, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
     if ((e = hipMemcpyAsync(d_i32, pack.data(), 4 * pack.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
     if ((e = hipMemsetAsync(d_out, 0, std::max<size_t>(16, out_bytes), stream)) != hipSuccess) return fail(e);
+    if (mode == kProbeMode && (e = hipMemcpyAsync(d_out, states, (size_t)n_samples * n, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
     SampleArgs A;
     A.pool = d_pool;
     A.vars = d_vars;
@@ -168,10 +182,13 @@ inline int sample_run(const Network &net, const double *d_pool, hipStream_t stre
     A.states = d_out;
     A.wsum = (double *)d_out;
     A.counts = (unsigned long long *)(d_out + (size_t)cells * 8);
+    A.lik = (double *)(d_out + probe_states);
+    A.cdf = A.lik + n_samples;
+    A.cdf_stride = cdf_stride;
     A.n_vars = n;
     A.n_q = n_q;
     A.n_e = n_ev;
-    A.hist_cells = mode == kSampleMode ? 0 : (int32_t)cells;
+    A.hist_cells = (mode == kSampleMode || mode == kProbeMode) ? 0 : (int32_t)cells;
     A.mode = mode;
     A.n_samples = n_samples;
     A.seed = seed;
@@ -186,6 +203,9 @@ inline int sample_run(const Network &net, const double *d_pool, hipStream_t stre
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
     if (mode == kSampleMode) {
         std::memcpy(states, host.data(), out_bytes);
+    } else if (mode == kProbeMode) {
+        std::memcpy(probe_lik, host.data() + probe_states, (size_t)n_samples * 8);
+        std::memcpy(probe_cdf, host.data() + probe_states + (size_t)n_samples * 8, (size_t)n_samples * 8 * n * cdf_stride);
     } else {
         const double *ws = (const double *)host.data();
         const unsigned long long *cn = (const unsigned long long *)(host.data() + (size_t)cells * 8);

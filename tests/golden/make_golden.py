@@ -344,6 +344,32 @@ def grids_fixture(heavy):
                   "requests": res})
 
 
+def grid_nev_fixture():
+    """SURVEY 8(d)'s n_evidence variants of the C3 stream on the 10x10 K=4 grid: for n_evidence in {1, 8, 16} the first requests
+    of netspec.c3_requests(..., n_evidence, seed=1) whose row-major product (the order the hash-ordered reference eliminates in)
+    stays below 3e6 rows - seconds each in the reference.  -> grid10x10_nev.json"""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, sorobn.BayesNet, wrap=refload.HashedName)
+    out = {"recipe": {"R": 10, "C": 10, "K": 4, "seed": 0},
+           "cpt_sum_hex": float(sum(r[-1] for c in spec["cpts"].values() for r in c["rows"])).hex(), "variants": {}}
+    for n_ev in (1, 8, 16):
+        q, ev, ec = netspec.c3_requests(100, 4, 2000, n_ev, seed=1)
+        reqs, stream_index = [], []
+        for i in range(2000):
+            if netspec.grid_row_major_cost(q[i], ev[i], 10, 10, 4)[0] <= 3e6:
+                reqs.append(((f"{q[i]:03d}",), [(f"{e:03d}", int(c)) for e, c in zip(ev[i], ec[i])]))
+                stream_index.append(i)
+            if len(reqs) >= 8:
+                break
+        t0 = time.time()
+        res = run_requests(bn, reqs, refload.HashedName)
+        for r, i in zip(res, stream_index):
+            r["stream_index"] = i
+        out["variants"][str(n_ev)] = res
+        print("grid10x10 n_evidence", n_ev, len(reqs), round(time.time() - t0, 1), "s", [r["ref_seconds"] for r in res], flush=True)
+    netspec.save(os.path.join(HERE, "grid10x10_nev.json"), out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--heavy", action="store_true")
@@ -358,6 +384,8 @@ if __name__ == "__main__":
         dags_fixture()
     if "grids" in todo:
         grids_fixture(a.heavy)
+    if "nev" in todo or "grids" in todo:
+        grid_nev_fixture()
     if "wide" in todo:
         wide_fixture()
     if "many" in todo:

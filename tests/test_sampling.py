@@ -119,3 +119,53 @@ def test_likelihood_weighting_matches_the_reference_estimator():
             key = key if isinstance(key, tuple) else (key,)
             codes = {n: f.code_of(f.id[n], lab) for n, lab in zip(order, key)}
             assert abs(p - lim[tuple(codes[n] for n in q)]) < 0.005, (name, key)
+
+
+@pytest.mark.gpu
+def test_sampling_walk_vs_the_references_own_arithmetic():
+    """f2's deterministic half (VERDICT r3 missing #4): everything in the sampling paths that is a pure function of the CPTs,
+    computed by sample_kernel ITSELF (mibn_sample_probe: its walk over given joint states) against the reference's arithmetic
+    on live reference objects (oracle/_ref):
+      * the likelihood weight of a sample - `_forward_sample(init=sample)` clamps every node and therefore draws nothing; the
+        generator's second value is the product _llh_weighting averages (bayes_net.py:541-546, 646-652)           <= 1e-12 relative
+      * the conditional row every node is drawn from - `P.cdt[condition]` (44-52, 530-534), the weights the reference hands to
+        its alias sampler (28-42), as cumulative probabilities                                                       <= 1e-12
+    Only the random stream itself stays unpinned (the reference's needs the absent `vose`)."""
+    from oracle import refload
+    if not refload.available():
+        pytest.skip("oracle/_ref was not built (make -C oracle _ref where /root/reference is mounted)")
+    ref_mod = refload.load()
+    n_checked = 0
+    for name in ("alarm", "sprinkler", "asia", "grades"):
+        ref = getattr(ref_mod.examples, name)()
+        bn = netspec.build(_spec(name), sorobn_amd.BayesNet)
+        f = flatten(bn)
+        eng = bn.backend.engine
+        assert list(ref.nodes) == list(f.names)
+        states = eng.sample(96, seed=11)  # states of positive probability: every conditional row exists in the sparse CPTs
+        lik, cdf = eng.sample_probe(states)
+        for r, st in enumerate(states):
+            sample = {f.names[v]: f.domains[v][int(st[v])] for v in range(len(f.names))}
+            got_sample, want_lik = next(ref._forward_sample(init=sample))
+            assert got_sample == sample
+            assert want_lik > 0 and abs(lik[r] - want_lik) <= 1e-12 * want_lik, (name, r, lik[r], want_lik)
+            for v, node in enumerate(f.names):
+                P = ref.P[node]
+                if node in ref.parents:
+                    P = P.cdt[tuple(sample[p] for p in ref.parents[node])]
+                w = np.array([float(P.get(lab, 0)) for lab in f.domains[v]])
+                assert abs(w.sum() - float(P.to_numpy(dtype=float).sum())) <= 1e-15  # (no row outside the flattened domain)
+                k = int(f.card[v])
+                got = cdf[r, v, :k]
+                assert abs(got[-1] - w.sum()) <= 1e-12
+                assert np.max(np.abs(got / got[-1] - np.cumsum(w) / w.sum())) <= 1e-12, (name, node)
+                n_checked += 1
+    assert n_checked >= 96 * (5 + 4 + 8 + 5)
+    # a state of probability zero under a sparse CPT: absent rows are zeros of the dense table, P.get(value, 0) of the reference
+    bn = netspec.build(_spec("asia"), sorobn_amd.BayesNet)
+    f = flatten(bn)
+    st = np.zeros((1, len(f.names)), np.uint8)
+    for v, nme in enumerate(f.names):
+        st[0, v] = f.code_of(v, {"TB or cancer": False, "Tuberculosis": True}.get(nme, False))
+    lik, _ = bn.backend.engine.sample_probe(st)
+    assert lik[0] == 0.0
