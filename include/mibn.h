@@ -268,15 +268,23 @@ int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *
  * only communication is the final gather of the posteriors (exact path) or the sum of the histograms (Gibbs).  These
  * entry points sit directly on RCCL (librccl.so is dlopen'ed by mibn_comm_init - a single-GPU process never loads it) and
  * run on a stream of their own (the gather of batch s must not queue behind the kernels of batch s + 1), over xGMI between the GPUs of a node.  No PyTorch involved.
- *   mibn_comm_unique_id   rank 0 creates the 128-byte RCCL id; the caller hands it to the other ranks out of band
+ *   mibn_comm_probe       loads librccl.so and resolves its entry points, nothing else: what can fail on one rank alone is
+ *                         checked on EVERY rank before anybody enters the collective init
+ *   mibn_comm_unique_id   rank 0 (only) creates the 128-byte RCCL id; the caller hands it to the other ranks out of band
  *                         (sorobn_amd/sharding.py: a file next to the rendezvous port, single node)
- *   mibn_comm_init        collective: every rank calls it with the same id
+ *   mibn_comm_init        collective: every rank calls it with the same id.  Bounded: a rank that has waited
+ *                         MIBN_COMM_INIT_TIMEOUT_S seconds (environment, default 180) for the others returns MIBN_E_COMM with
+ *                         a message naming the likely causes instead of hanging the launch
+ *   mibn_device_info      one text line about this context's device (name, PCI bus id, link type / hops to every other
+ *                         visible device) for the launch log
  *   mibn_comm_allgather_f64   recv[r * n .. (r+1) * n) = rank r's send[0 .. n)   (host buffers, staged through HBM)
  *   mibn_comm_reduce_i64      sum over ranks of buf[0 .. n) -> buf on `root` (other ranks' buf unchanged)
  *   mibn_comm_allreduce_max_f64   element-wise max over ranks, in place (the bench's max-over-ranks step time)
  *   mibn_comm_barrier     all ranks have reached the call and their device work is complete
  */
 #define MIBN_COMM_ID_BYTES 128
+int mibn_comm_probe(mibn_t *h);
+int mibn_device_info(mibn_t *h, char *buf, int32_t cap);
 int mibn_comm_unique_id(mibn_t *h, void *id_out /* MIBN_COMM_ID_BYTES */);
 int mibn_comm_init(mibn_t *h, int32_t rank, int32_t world, const void *id /* MIBN_COMM_ID_BYTES */);
 int mibn_comm_destroy(mibn_t *h);

@@ -21,6 +21,7 @@ SYMBOLS = [
     "mibn_query_batch_ex", "mibn_plan_order", "mibn_estimate_costs", "mibn_device_synchronize", "mibn_gibbs_shard",
     "mibn_comm_unique_id", "mibn_comm_init", "mibn_comm_destroy", "mibn_comm_allgather_f64",
     "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier", "mibn_gibbs_conditional", "mibn_sample_probe",
+    "mibn_comm_probe", "mibn_device_info",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -80,6 +81,8 @@ def lib():
         L.mibn_gibbs_shard.argtypes = [vp, C.c_int32, i32p, C.c_int32, i32p, i32p, i32p, C.c_int64, C.c_int64,
                                        C.c_int64, C.c_uint64, i64p]
         L.mibn_gibbs_conditional.argtypes = [vp, C.c_int32, i32p, i32p, i32p, C.c_int32, C.c_int64, C.POINTER(C.c_uint8), f64p]
+        L.mibn_comm_probe.argtypes = [vp]
+        L.mibn_device_info.argtypes = [vp, C.c_char_p, C.c_int32]
         L.mibn_comm_unique_id.argtypes = [vp, C.c_char_p]
         L.mibn_comm_init.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p]
         L.mibn_comm_destroy.argtypes = [vp]
@@ -336,6 +339,15 @@ class Engine:
 
     def synchronize(self):
         self._check(self._L.mibn_device_synchronize(self._h))
+
+    def comm_probe(self):
+        """librccl.so loads and has the entry points mibn_comm_* needs (no id, no socket, no thread)."""
+        self._check(self._L.mibn_comm_probe(self._h))
+
+    def device_info(self):
+        buf = C.create_string_buffer(1024)
+        self._check(self._L.mibn_device_info(self._h, buf, 1024))
+        return buf.value.decode(errors="replace")
 
     def comm_unique_id(self):
         buf = C.create_string_buffer(COMM_ID_BYTES)

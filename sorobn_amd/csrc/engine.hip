@@ -7,9 +7,12 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -1297,6 +1300,14 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             }
         }
         BatchPlan &ck = st.plan;
+        // every error exit of the device-planner path: the planner's kernels (they read pinned request arrays and write pinned
+        // results) and the chunks this call has already launched are drained before the caller sees the error - ADVICE r3
+        auto bail = [&](int code) {
+            (void)hipStreamSynchronize(h->search_stream);
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamSynchronize(h->stream2);
+            return code;
+        };
         bool on_device = false;
         int64_t nd = 0;          // requests [b0, b0 + nd) planned by the device, the rest by the host's workers meanwhile
         size_t prog_base = 0;    // words of st.d_prog the device has written (the host's programs follow)
@@ -1304,7 +1315,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             nd = h->gpu_emit == 2 ? n : std::min<int64_t>(n, std::max<int64_t>(64, (int64_t)((double)n * std::min(h->emit_share, h->emit_share_opt > 0 ? 1.0 : 0.95) + 0.5)));
             if (n - nd < 256) nd = n;  // (without a pinned share the host keeps at least a twentieth: its rate stays measured)
             const size_t stride = h->emit_words;
-            if ((rc = plan_on_device_launch(h, flags, b0, b0 + nd, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), st, (size_t)n * stride))) return rc;
+            if ((rc = plan_on_device_launch(h, flags, b0, b0 + nd, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), st, (size_t)n * stride))) return bail(rc);
             const double t_launched = now_ms();
             BatchPlan &hp = h->emit_host, &dp = h->emit_dev;
             double host_ms = 0, dev_ms = 0;
@@ -1313,7 +1324,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 plan_batch(h->net, *h->pool, st.bufs, b0 + nd, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), hp,
                            (flags & MIBN_Q_NOPRUNE) != 0, nullptr, nullptr, b0);
                 host_ms = now_ms() - th;
-                if (!hp.err.empty()) { h->err = hp.err; (void)hipStreamSynchronize(h->search_stream); return MIBN_E_LIMIT; }
+                if (!hp.err.empty()) { h->err = hp.err; return bail(MIBN_E_LIMIT); }
             }
             const double tw = now_ms();
             rc = plan_on_device_collect(h, b0, nd, nd < n ? dp : ck, &dev_ms);
@@ -1338,7 +1349,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
 #endif
             if (h->trace) std::fprintf(stderr, "[mibn plan] chunk of %lld: device %lld requests (upload + launch %.2f ms, kernels %.2f ms, wait + collect %.2f ms), host %lld requests %.2f ms\n",
                                        (long long)n, (long long)nd, t_launched - t0, dev_ms, now_ms() - tw, (long long)(n - nd), host_ms);
-            if (rc < 0 || rc > 1) return rc;
+            if (rc < 0 || rc > 1) return bail(rc);
             if (rc == 0 && nd < n && hp.total_words > (size_t)(n - nd) * stride) rc = 1;  // (the host's programs do not fit behind the device's)
             on_device = rc == 0;
             if (on_device && nd < n) {
@@ -1385,7 +1396,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             BatchPlan ref;
             plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ref,
                        (flags & MIBN_Q_NOPRUNE) != 0, nullptr, nullptr);
-            if (!ref.err.empty()) { h->err = ref.err; return MIBN_E_LIMIT; }
+            if (!ref.err.empty()) { h->err = ref.err; return bail(MIBN_E_LIMIT); }
             for (int64_t i = 0; i < n; ++i) {
                 const uint32_t *hw = st.bufs[ref.thread_of[i]].data + ref.local_off[i], *dw = dev.data() + (size_t)i * stride;
                 size_t words = 1;
@@ -1394,14 +1405,14 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                     if (hw[k] != dw[k]) {
                         h->err = "device planner: request " + std::to_string(b0 + i) + " word " + std::to_string(k) + " of " + std::to_string(words) + ": host " +
                                  std::to_string(hw[k]) + " device " + std::to_string(dw[k]);
-                        return MIBN_E_STATE;
+                        return bail(MIBN_E_STATE);
                     }
                 const Tag *ht = ref.tags[ref.thread_of[i]].data() + ref.tag_first[i], *dt = ck.tags[0].data() + ck.tag_first[i];
                 bool same = ref.tag_count[i] == ck.tag_count[i] && ref.arena_need[i] == ck.arena_need[i] && ref.cost[i] == ck.cost[i];
                 for (uint32_t k = 0; same && k < ref.tag_count[i]; ++k)
                     same = ht[k].rel_off == dt[k].rel_off && ht[k].a == dt[k].a && ht[k].wgs == dt[k].wgs && ht[k].level == dt[k].level &&
                            ht[k].kid == dt[k].kid && ht[k].bytes == dt[k].bytes;
-                if (!same) { h->err = "device planner: work items / statistics of request " + std::to_string(b0 + i) + " differ from the host's"; return MIBN_E_STATE; }
+                if (!same) { h->err = "device planner: work items / statistics of request " + std::to_string(b0 + i) + " differ from the host's"; return bail(MIBN_E_STATE); }
             }
         }
         if (!ck.err.empty()) { h->err = ck.err; (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->stream2); return MIBN_E_LIMIT; }
@@ -1853,6 +1864,39 @@ int comm_buf(mibn_ctx *h, void *&ptr, size_t &cap, size_t bytes) {
 
 }  // namespace
 
+// dlopen + symbol resolution only: what can fail on ONE rank of a node, checked before anybody enters the collective init.
+// (ncclGetUniqueId is for rank 0 alone: on any other rank it starts a bootstrap listener thread and a socket that wait for
+// `world` connections which never arrive - ADVICE r3.)
+extern "C" int mibn_comm_probe(mibn_t *h) {
+    if (!h) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound"; return MIBN_E_NODEVICE; }
+    return comm_load(h);
+}
+
+// One line about this context's device for the launch log: name, PCI bus id, and the link (type, hops) to every other visible
+// device - hipExtGetLinkTypeAndHopCount; type 4 = xGMI (HSA_AMD_LINK_INFO_TYPE_XGMI), 2 = PCIe.
+extern "C" int mibn_device_info(mibn_t *h, char *buf, int32_t cap) {
+    if (!h || !buf || cap < 1) return MIBN_E_ARG;
+    if (h->planner_only) { h->err = "planner-only context: no HIP device bound"; return MIBN_E_NODEVICE; }
+    hipDeviceProp_t pr;
+    HIP_TRY(h, hipGetDeviceProperties(&pr, h->device));
+    char bus[64] = "?";
+    (void)hipDeviceGetPCIBusId(bus, sizeof(bus), h->device);
+    std::string out = "device " + std::to_string(h->device) + " " + pr.name + " (" + pr.gcnArchName + ") pci " + bus + " links:";
+    int n = 0;
+    (void)hipGetDeviceCount(&n);
+    for (int d = 0; d < n; ++d) {
+        if (d == h->device) continue;
+        uint32_t type = 0, hops = 0;
+        if (hipExtGetLinkTypeAndHopCount(h->device, d, &type, &hops) == hipSuccess)
+            out += " ->" + std::to_string(d) + ":" + (type == 4 ? "xgmi" : type == 2 ? "pcie" : "type" + std::to_string(type)) + "/" + std::to_string(hops);
+        else { (void)hipGetLastError(); out += " ->" + std::to_string(d) + ":?"; }
+    }
+    if (n <= 1) out += " none (one visible device)";
+    std::snprintf(buf, (size_t)cap, "%s", out.c_str());
+    return MIBN_OK;
+}
+
 extern "C" int mibn_comm_unique_id(mibn_t *h, void *id_out) {
     if (!h || !id_out) return MIBN_E_ARG;
     if (h->planner_only) { h->err = "planner-only context: no HIP device bound"; return MIBN_E_NODEVICE; }
@@ -1875,7 +1919,37 @@ extern "C" int mibn_comm_init(mibn_t *h, int32_t rank, int32_t world, const void
     ncclUniqueId id;
     std::memcpy(&id, id_in, sizeof(id));
     if (!h->comm.stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->comm.stream, hipStreamNonBlocking));
-    NCCL_TRY(h, h->comm.CommInitRank(&h->comm.comm, world, id, rank));
+    // The collective init blocks until every rank of `world` has joined - for ever when one of them died or took another id.
+    // Bounded: the call runs on a helper thread, and a rank that has waited MIBN_COMM_INIT_TIMEOUT_S seconds (default 180) gives
+    // up with an error that names the likely causes instead of hanging the launch (the helper thread is abandoned: the process
+    // is expected to exit on this error).
+    double limit_s = 180.0;
+    if (const char *e = std::getenv("MIBN_COMM_INIT_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) limit_s = v; }
+    struct InitState { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto state = std::make_shared<InitState>();
+    const int device = h->device;
+    auto init_fn = h->comm.CommInitRank;
+    std::thread([state, init_fn, device, world, id, rank]() {
+        (void)hipSetDevice(device);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = init_fn(&c, world, id, rank);
+        std::lock_guard<std::mutex> lk(state->m);
+        state->res = r;
+        state->comm = c;
+        state->done = true;
+        state->cv.notify_all();
+    }).detach();
+    {
+        std::unique_lock<std::mutex> lk(state->m);
+        if (!state->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return state->done; })) {
+            h->err = "ncclCommInitRank: rank " + std::to_string(rank) + " of " + std::to_string(world) + " on device " + std::to_string(device) +
+                     " still waiting after " + std::to_string((int)limit_s) + " s (MIBN_COMM_INIT_TIMEOUT_S) - a rank died before the init, the ranks "
+                     "hold different ids, two ranks share one device, or the GPUs cannot reach each other (check HSA_ENABLE_IPC_MODE_LEGACY=0)";
+            return MIBN_E_COMM;
+        }
+        if (state->res != ncclSuccess) { h->err = std::string("ncclCommInitRank: ") + h->comm.GetErrorString(state->res); return MIBN_E_COMM; }
+        h->comm.comm = state->comm;
+    }
     h->comm.rank = rank;
     h->comm.world = world;
     return MIBN_OK;

@@ -13,6 +13,10 @@ Transports behind one small interface (`rank`, `world`, `allgather`, `reduce_i64
                   128-byte RCCL id travels from rank 0 to the other ranks of the node through a file.
   * `TorchComm` - a test hook: the same calls on a torch.distributed process group ("gloo" on CPU: the world-size-2
                   tests of the N > 1 logic in the GPU-less build container).
+  * `FileComm`  - the dry run (`MIBN_BENCH_BACKEND=files`): N ranks on FEWER GPUs than ranks (RCCL refuses two ranks on one
+                  device) run everything of the N > 1 path - the launch, the librccl probe on every rank, the vote, rank 0's
+                  ncclGetUniqueId and the id exchange, the shards, the gather's packing - except ncclCommInitRank and the
+                  collectives themselves, which go through files of the launch's private directory.  No PyTorch.
   * `SoloComm`  - world size 1.
 """
 import os
@@ -149,11 +153,22 @@ def exchange_id(rank, world, make_id, path=None, timeout_s=120.0):
         time.sleep(0.01)
 
 
+_attempt = {}  # per process: how many times a vote / an id exchange of a given name has run (every rank constructs its
+                # communicators in the same order, so the counters agree across the ranks of a launch)
+
+
+def _next_attempt(what):
+    _attempt[what] = _attempt.get(what, 0) + 1
+    return _attempt[what]
+
+
 def all_agree(rank, world, ok, what, timeout_s=120.0):
     """A collective boolean AND over the ranks of a node without a communicator (it decides whether one can be built): every
-    rank leaves a marker file of this launch, then reads everybody's.  Returns True iff every rank reported ok; a rank that
-    does not report within the timeout counts as a failure."""
-    base = os.path.join(_comm_dir(), f"mibn_vote_{_launch_tag()}_{what}")
+    rank leaves a marker file of this launch AND of this attempt (a second communicator built in the same launch must not read
+    the first one's votes - ADVICE r3), then reads everybody's.  Returns (verdict, my file): True iff every rank reported ok; a
+    rank that does not report within the timeout counts as a failure.  The caller unlinks its own file once every rank has read
+    it (after the barrier that follows the init), see `RcclComm`."""
+    base = os.path.join(_comm_dir(), f"mibn_vote_{_launch_tag()}_{what}_a{_next_attempt('vote_' + what)}")
     mine = f"{base}.{rank}"
     tmp = f"{mine}.{os.getpid()}.tmp"
     with open(tmp, "w") as f:
@@ -175,7 +190,36 @@ def all_agree(rank, world, ok, what, timeout_s=120.0):
                 verdict = False
                 break
             time.sleep(0.01)
-    return verdict
+    return verdict, mine
+
+
+def _unlink(path):
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+
+
+def _probe_and_vote(engine, rank, world):
+    """Every rank checks that librccl.so loads (mibn_comm_probe: dlopen + symbols - no id, no listener thread, no socket on the
+    ranks that are not rank 0), the ranks agree on the outcome, and every rank echoes its device and links once.
+    -> this rank's vote file (to unlink after the first barrier)."""
+    try:
+        engine.comm_probe()
+        err = None
+    except Exception as e:  # noqa: BLE001
+        err = e
+    try:
+        info = engine.device_info()
+    except Exception as e:  # noqa: BLE001
+        info = f"device info unavailable ({e!r})"
+    import sys
+    print(f"[mibn comm] rank {rank}/{world} pid {os.getpid()} {info}", file=sys.stderr, flush=True)
+    ok, vote = all_agree(rank, world, err is None, "rccl_load")
+    if not ok:
+        _unlink(vote)
+        raise RuntimeError(f"mibn_comm_* unavailable on at least one rank of the node (this rank: {err!r})")
+    return vote
 
 
 class RcclComm:
@@ -187,22 +231,18 @@ class RcclComm:
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         # What can fail on one rank only - loading librccl.so - happens BEFORE anybody enters the collective
         # ncclCommInitRank, and the ranks agree on the outcome: either all of them build the communicator or all of them
-        # raise (and the caller falls back as a whole); a rank that failed alone would leave the others hanging in the init.
+        # raise (and the caller falls back as a whole); a rank that failed alone would leave the others hanging in the init
+        # (which is bounded besides: mibn_comm_init gives up after MIBN_COMM_INIT_TIMEOUT_S seconds).
+        vote = _probe_and_vote(engine, self.rank, self.world)
+        uid, path = exchange_id(self.rank, self.world, engine.comm_unique_id,  # (ncclGetUniqueId on rank 0 only)
+                                path=f"{_id_file()}.a{_next_attempt('id')}")
         try:
-            probe = engine.comm_unique_id()  # (dlopen + ncclGetUniqueId; only rank 0's id is used)
-            err = None
-        except Exception as e:  # noqa: BLE001
-            probe, err = None, e
-        if not all_agree(self.rank, self.world, err is None, "rccl_load"):
-            raise RuntimeError(f"mibn_comm_* unavailable on at least one rank of the node (this rank: {err!r})")
-        uid, path = exchange_id(self.rank, self.world, lambda: probe)
-        engine.comm_init(self.rank, self.world, uid)
-        engine.comm_barrier()  # every rank has read the id
-        if self.rank == 0:
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+            engine.comm_init(self.rank, self.world, uid)
+            engine.comm_barrier()  # every rank has read the id and everybody's vote
+        finally:
+            _unlink(vote)
+            if self.rank == 0:
+                _unlink(path)
 
     def allgather(self, rows):
         rows = np.ascontiguousarray(rows, np.float64)
@@ -219,6 +259,78 @@ class RcclComm:
 
     def close(self):
         self.engine.comm_destroy()
+
+
+class FileComm:
+    """The dry run of the N > 1 path on a box with fewer GPUs than ranks (`MIBN_BENCH_BACKEND=files`; tests/test_dist.py): the
+    same launch, probe, vote and id exchange as `RcclComm` - rank 0 really calls ncclGetUniqueId - but no ncclCommInitRank (RCCL
+    refuses two ranks on one device) and collectives through files of the launch's private directory (MIBN_COMM_DIR).  Slow and
+    single-node by construction: a check of the plumbing, never a measurement."""
+
+    def __init__(self, engine, rank=None, world=None, timeout_s=300.0):
+        self.engine = engine
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self.timeout_s = timeout_s
+        self._seq = 0
+        self._mine = []
+        self._base = os.path.join(_comm_dir(), f"mibn_filecomm_{_launch_tag()}_a{_next_attempt('filecomm')}")
+        if engine is not None and not getattr(engine, "planner_only", False):
+            vote = _probe_and_vote(engine, self.rank, self.world)
+            uid, path = exchange_id(self.rank, self.world, engine.comm_unique_id, path=f"{_id_file()}.a{_next_attempt('id')}")
+            assert len(uid) == 128
+            self.barrier()
+            _unlink(vote)
+            if self.rank == 0:
+                _unlink(path)
+
+    def _exchange(self, arr):
+        """Every rank publishes `arr` for this sequence number and reads everybody's.  -> list of arrays by rank."""
+        self._seq += 1
+        mine = f"{self._base}.{self._seq}.{self.rank}.npy"
+        tmp = f"{mine}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            np.save(f, np.ascontiguousarray(arr))
+        os.replace(tmp, mine)
+        self._mine.append(mine)
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            p = f"{self._base}.{self._seq}.{r}.npy"
+            while True:
+                try:
+                    out.append(np.load(p))
+                    break
+                except (OSError, ValueError, EOFError):
+                    if time.time() - t0 > self.timeout_s:
+                        raise TimeoutError(f"rank {self.rank}: rank {r} did not reach collective {self._seq} within {self.timeout_s:.0f} s")
+                    time.sleep(0.002)
+        # a file is read by every rank before any rank can publish sequence number + 2 (it has to pass + 1 first): drop old ones
+        while len(self._mine) > 2:
+            _unlink(self._mine.pop(0))
+        return out
+
+    def allgather(self, rows):
+        rows = np.ascontiguousarray(rows, np.float64)
+        return np.stack(self._exchange(rows))
+
+    def reduce_i64(self, arr, root=0):
+        parts = self._exchange(np.ascontiguousarray(arr, np.int64))
+        return np.sum(parts, axis=0).astype(np.int64) if self.rank == root else np.ascontiguousarray(arr, np.int64).copy()
+
+    def allreduce_max(self, values):
+        return np.max(np.stack(self._exchange(np.ascontiguousarray(values, np.float64).reshape(-1))), axis=0)
+
+    def barrier(self):
+        self._exchange(np.zeros(1))
+
+    def close(self):
+        # two barriers: whoever completes the second knows that every rank has read all files of the first (and older ones), which
+        # can go; a rank's file of the LAST barrier may still be being read - it stays for the launcher's clean-up of the directory
+        self.barrier()
+        self.barrier()
+        for p in self._mine[:-1]:
+            _unlink(p)
+        self._mine = []
 
 
 class TorchComm:
@@ -277,6 +389,88 @@ def gather_posteriors(local: np.ndarray, n_total: int, comm=None, ranges=None, g
         buf[:len(local)] = local.reshape(len(local), cells)
     out = comm.allgather(buf)
     return np.concatenate([out[r, :hi - lo] for r, (lo, hi) in enumerate(ranges)], axis=0)
+
+
+class ShardedStream:
+    """The exact path over a request stream on N ranks (BASELINE configs 3 and 4): the stream is cut into STEPS of `global_batch`
+    requests; a step's requests are split into contiguous shards, one per rank (equal counts, or equal planner cost estimates
+    with balance="cost"); a rank works through its shard in sub-batches of `sub_batch` requests, two calls in flight
+    (mibn_submit_batch / mibn_wait: the host plans sub-batch k + 1 while the GPU runs k - across step boundaries too); a step
+    ends with ONE all-gather of the dense posteriors (`gather_posteriors`), after which every rank holds the step's
+    [global_batch x cells] answers.  No other communication.  `global_batch` fixed while N grows = strong scaling (config 4: the
+    same requests on 2 / 4 / 8 GPUs); `global_batch` = N x per-rank batch = weak scaling.
+
+    engine: `_capi.Engine` (or anything with query_fixed; submit_fixed / wait are used when present).  qvars [n, nq], evars
+    [n, ne], ecodes [n, ne]: the stream, variable ids of the engine's network."""
+
+    def __init__(self, engine, comm, qvars, evars, ecodes, global_batch, sub_batch=32768, balance="count", pipelined=True):
+        self.engine, self.comm = engine, comm
+        self.q, self.ev, self.ec = qvars, evars, ecodes
+        self.G, self.sub = int(global_batch), max(1, int(sub_batch))
+        self.balance = balance
+        self.pipelined = pipelined and hasattr(engine, "submit_fixed")
+        self.shard_requests = np.zeros(comm.world, np.int64)  # requests every rank has processed so far
+        self.cells = None
+
+    def ranges(self, step):
+        """The shard of every rank inside step `step` (same on every rank: the estimates are deterministic)."""
+        world = self.comm.world
+        lo = step * self.G
+        n = min(self.G, len(self.q) - lo)
+        if self.balance == "cost" and world > 1:
+            cost = self.engine.estimate_costs(self.q[lo:lo + n], self.ev[lo:lo + n])
+            return cost_balanced_ranges(cost, world)
+        return [shard_range(n, world, r) for r in range(world)]
+
+    def run(self, steps, keep=False):
+        """-> {"first": gathered posteriors of the first step run, "first_step", "requests", "mass" (sum of all gathered posteriors: =
+        requests when every answer is a distribution), "gathered" (per step, only if keep)}."""
+        comm, eng = self.comm, self.engine
+        jobs = []  # (step, lo, hi, is_last_of_step, ranges)
+        for st in steps:
+            rg = self.ranges(st)
+            lo, hi = st * self.G + rg[comm.rank][0], st * self.G + rg[comm.rank][1]
+            cuts = list(range(lo, hi, self.sub)) or [lo]
+            for k, a in enumerate(cuts):
+                jobs.append((st, a, min(hi, a + self.sub), k == len(cuts) - 1, rg))
+            self.shard_requests += np.array([b - a for a, b in rg], np.int64)
+        out = {"first": None, "first_step": None, "requests": 0, "mass": 0.0, "gathered": {} if keep else None}
+        parts = []
+
+        def finish(job, handle):
+            st, a, b, last, rg = job
+            if b > a:
+                post = eng.wait(handle) if self.pipelined else handle
+                parts.append(np.asarray(post, np.float64).reshape(b - a, -1))
+            if not last:
+                return
+            n = min(self.G, len(self.q) - st * self.G)
+            if self.cells is None:  # cells per posterior: agreed once (a rank whose shard is empty has no answer to read it from)
+                mine = parts[0].shape[1] if parts else 0
+                self.cells = int(comm.allreduce_max([float(mine)])[0]) if comm.world > 1 else mine
+            local = np.concatenate(parts, axis=0) if parts else np.zeros((0, self.cells))
+            parts.clear()
+            full = gather_posteriors(local, n, comm, ranges=rg) if comm.world > 1 else local
+            out["requests"] += n
+            out["mass"] += float(full.sum())
+            if out["first"] is None:
+                out["first"], out["first_step"] = full, st
+            if keep:
+                out["gathered"][st] = full
+
+        pending = None
+        for job in jobs:
+            st, a, b, last, rg = job
+            if self.pipelined:
+                nxt = eng.submit_fixed(self.q[a:b], self.ev[a:b], self.ec[a:b]) if b > a else None  # (an empty shard: gather only)
+                if pending is not None:
+                    finish(*pending)
+                pending = (job, nxt)
+            else:
+                finish(job, eng.query_fixed(self.q[a:b], self.ev[a:b], self.ec[a:b]) if b > a else None)
+        if pending is not None:
+            finish(*pending)
+        return out
 
 
 def gibbs_sharded(engine, comm, qvars, evars, ecodes, n_chains, n_iterations, seed=0, cycle=None, root=0):

@@ -64,6 +64,22 @@ def main():
     if rank == 0:
         assert np.array_equal(full, ref)
 
+    # 2b. BASELINE config 4 as bench.py runs it (sharding.ShardedStream): the SAME requests whatever the world size, steps of a
+    #     fixed global batch, contiguous shards (count- and cost-balanced), sub-batches per call, ONE gather per step; and the
+    #     whole stream as one step with one gather (bench.py --full-stream)
+    tq, tev = to_var[q][:, None], to_var[ev]
+    for balance, G, sub in (("count", 20, 7), ("cost", 20, 64), ("count", n, 16)):
+        be.engine.estimate_costs = planner.estimate_costs  # (the simulator has no planner of its own: same network, same ids)
+        stream = sharding.ShardedStream(be.engine, comm, tq, tev, ec, G, sub_batch=sub, balance=balance)
+        steps = range((n + G - 1) // G)
+        res = stream.run(steps, keep=True)
+        assert res["requests"] == n and abs(res["mass"] - n) < 1e-9 and int(stream.shard_requests.sum()) == n
+        full = np.concatenate([res["gathered"][st] for st in steps], axis=0)
+        if rank == 0:
+            assert np.array_equal(full, ref), balance
+        if G == n:  # one step: one gather; every rank holds every answer
+            assert len(res["gathered"]) == 1 and res["first"].shape == (n, 4)
+
     # 3. Gibbs: chain shards of one stream, int64 histogram reduce onto rank 0 (bayes_net.py:736-737 on N GPUs)
     fake = FakeGibbsEngine()
     hist = sharding.gibbs_sharded(fake, comm, [0], [], [], 37, 1000, seed=4)

@@ -85,16 +85,17 @@ def test_bench_two_ranks_launch_path():
     env = dict(os.environ, MIBN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "4096"]
+           "--batch", "4096", "--scaling", "weak"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
-    assert out["config"]["requests_per_step_per_gpu"] == 4096
+    assert out["config"]["requests_per_step_per_gpu"] == 4096 and out["config"]["requests_per_step"] == 8192
     assert abs(out["value"] - 2 * 2 * 4096 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    assert out["per_rank"]["requests_per_step"] == [4096.0, 4096.0]
 
 
 @pytest.mark.gpu
@@ -104,14 +105,39 @@ def test_bench_spawns_its_own_ranks():
     env = dict(os.environ, MIBN_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
+           "--global-batch", "10000"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2
-    assert abs(out["value"] - 2 * 2 * 4096 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong"  # (the default: BASELINE config 4)
+    assert out["config"]["requests_per_step"] == 10000 and out["per_rank"]["requests_per_step"] == [5000.0, 5000.0]
+    assert abs(out["value"] - 2 * 10000 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+
+
+@pytest.mark.gpu
+def test_bench_dry_run_of_config_4():
+    """BASELINE config 4 as written, as a DRY RUN on however many GPUs the box has (MIBN_BENCH_BACKEND=files, sharding.FileComm):
+    `python bench.py --gpus 2 --full-stream` - bench.py spawns the ranks, every rank probes librccl (mibn_comm_probe), they vote,
+    rank 0 creates a real RCCL id (ncclGetUniqueId) and the others read it, the first 1 M requests of the stream are split into
+    contiguous shards, and ONE gather ends the pass - everything of the N > 1 path except ncclCommInitRank and the collective itself
+    (RCCL refuses two ranks on one device).  No PyTorch in the ranks."""
+    env = dict(os.environ, MIBN_BENCH_BACKEND="files")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--global-batch", "20000",
+           "--full-stream"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(next(l for l in r.stdout.splitlines() if l.startswith('{"metric"')))
+    fs = out["full_stream"]
+    assert fs["requests"] == 1_000_000 and fs["n_gpus"] == 2 and fs["scaling"] == "strong" and fs["gathers"] == 1
+    assert fs["per_rank_requests"] == [500000.0, 500000.0] and abs(fs["posterior_mass"] - 1e6) < 1e-3
+    assert fs["imbalance_alg_bytes_max_over_mean"] < 1.05
+    echo = [l for l in r.stderr.splitlines() if l.startswith("[mibn comm] rank ")]
+    assert len(echo) >= 2 and all("device" in l and "pci" in l for l in echo), r.stderr[-2000:]  # rank / device / links, once per rank
 
 
 def test_collective_vote_without_a_communicator(tmp_path):
@@ -121,14 +147,42 @@ def test_collective_vote_without_a_communicator(tmp_path):
     code = ("import sys, os; sys.path.insert(0, %r)\n"
             "from sorobn_amd.sharding import all_agree\n"
             "r = int(sys.argv[1])\n"
-            "a = all_agree(r, 2, True, 'first', timeout_s=30)\n"
-            "b = all_agree(r, 2, r == 0, 'second', timeout_s=30)\n"
-            "sys.stdout.write('%%d %%d' %% (a, b))") % ROOT
+            "a, fa = all_agree(r, 2, True, 'first', timeout_s=30)\n"
+            "b, fb = all_agree(r, 2, r == 0, 'second', timeout_s=30)\n"
+            # a second vote of the same name in the same launch (a second communicator): its own attempt, not the first one's files
+            "c, fc = all_agree(r, 2, r == 1, 'first', timeout_s=30)\n"
+            "assert fa != fc and os.path.basename(fa).startswith('mibn_vote_t1_first_a1') and '_a2' in os.path.basename(fc)\n"
+            "sys.stdout.write('%%d %%d %%d' %% (a, b, c))") % ROOT
     env = dict(os.environ, MIBN_COMM_DIR=str(tmp_path), MIBN_LAUNCH_NONCE="t1")
-    stale = tmp_path / "mibn_vote_t1_first.1"
+    stale = tmp_path / "mibn_vote_t1_first_a1.1"
     stale.write_text("0")
     os.utime(stale, (1.0, 1.0))  # 1970: older than any launcher
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, text=True) for r in (0, 1)]
     outs = [p.communicate(timeout=60)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs)
-    assert outs == ["1 0", "1 0"], outs
+    assert outs == ["1 0 0", "1 0 0"], outs
+
+
+def test_file_comm_collectives(tmp_path):
+    """sharding.FileComm (the transport of the N > 1 dry run): all-gather, int64 reduce, max and barrier between two processes."""
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from sorobn_amd.sharding import FileComm, gather_posteriors\n"
+            "r = int(sys.argv[1])\n"
+            "c = FileComm(None, r, 2, timeout_s=60)\n"
+            "g = c.allgather(np.full((3, 2), float(r)))\n"
+            "assert g.shape == (2, 3, 2) and g[0].max() == 0 and g[1].min() == 1\n"
+            "full = gather_posteriors(np.arange(4.0 * (2 + r)).reshape(2 + r, 4) + 100 * r, 5, c, ranges=[(0, 2), (2, 5)])\n"
+            "assert full.shape == (5, 4) and full[1, 3] == 7 and full[2, 0] == 100 and full[4, 3] == 111\n"
+            "h = c.reduce_i64(np.array([1, 2 + r], np.int64))\n"
+            "assert h.tolist() == ([2, 5] if r == 0 else [1, 3])\n"
+            "assert c.allreduce_max([float(r), 5.0 - r]).tolist() == [1.0, 5.0]\n"
+            "for _ in range(5): c.barrier()\n"
+            "c.close()\n"
+            "sys.stdout.write('ok')") % ROOT
+    env = dict(os.environ, MIBN_COMM_DIR=str(tmp_path), MIBN_LAUNCH_NONCE="t2")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert [o[0] for o in outs] == ["ok", "ok"]
+    assert len([f for f in os.listdir(tmp_path) if f.startswith("mibn_filecomm")]) <= 2, os.listdir(tmp_path)  # (the last barrier's)

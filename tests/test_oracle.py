@@ -141,6 +141,18 @@ def test_oracle_reproduces_reference_grid10x10():
     assert n >= 10
 
 
+def test_oracle_reproduces_reference_grid10x10_n_evidence_variants():
+    """SURVEY 8(d)'s n_evidence in {1, 8, 16} variants of the C3 stream: the C oracle against the reference's own answers
+    (tests/golden/grid10x10_nev.json, make_golden.py grid_nev_fixture) - the evidence filtering of bayes_net.py:768-776 with 1, 8
+    and 16 collapsed axes."""
+    entry = gu.load("grid10x10_nev.json")
+    spec = gu.grid_spec_from_recipe(entry)
+    for n_ev in ("1", "8", "16"):
+        reqs = entry["variants"][n_ev]
+        assert len(reqs) >= 5 and all(len(r["event"]) == int(n_ev) for r in reqs)
+        assert _check_net(spec, reqs, max_ref_seconds=3.0) >= 5
+
+
 def test_oracle_reproduces_the_reference_on_the_c2_stream():
     """BASELINE config 2 (the Asia stream of bench.py / netspec.asia_requests): the C oracle against the unmodified reference
     on the first 400 requests - same rows (zero rows absent, empty answers for zero-probability evidence) and values."""
