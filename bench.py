@@ -574,6 +574,30 @@ def main():
             out["roofline"]["per_kernel"][n] = {"achieved": gbps, "frac": gbps / HBM_PEAK_GBS, "alg_bytes_per_launch": d["alg_bytes"] / la,
                                                 "ms_per_launch": d["ms"] / la, "launches": la, "traffic": None, "traffic_over_alg": pmc_ratio(n)[0],
                                                 "share_of_kernel_time": d["ms"] / agg["kernel_ms"]}
+        if "||" in dom:
+            out["roofline"]["note"] = ("option overlap (default): the launches of a level - one of ve_level_kernel, one of ve_sweep_dma_kernel, items of different "
+                                       "requests - run CONCURRENTLY on two streams; the unit whose duration means anything is the pair (from the earlier start to the "
+                                       "later end, HIP events): `kernel` names it, `launches` = levels.  The two kernels' own event durations (per_kernel) then include "
+                                       "each other's share of the chip; per_kernel_serialised = the same kernels right after the timed region with the launches "
+                                       "serialised (overlap=0), for comparison with earlier rounds.")
+        if world == 1 and not a.no_configs and "||" in dom:
+            # the two kernels by themselves: a few calls with the launches of a level one after the other (option overlap = 0)
+            try:
+                eng.set_option("overlap", 0)
+                k0 = eng.total_kernel_stats()
+                stream.run(range(1))
+                eng.drain()
+                k1 = eng.total_kernel_stats()
+                eng.set_option("overlap", 1)
+                ser = {}
+                for n in k1:
+                    d = {f: k1[n][f] - k0.get(n, {}).get(f, 0.0) for f in k1[n]}
+                    if d["launches"] > 0 and d["alg_bytes"] > 0:
+                        ser[n] = {"achieved": d["alg_bytes"] / max(d["ms"], 1e-9) / 1e6, "frac": d["alg_bytes"] / max(d["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS,
+                                  "launches": d["launches"], "ms_per_launch": d["ms"] / d["launches"], "alg_bytes_per_launch": d["alg_bytes"] / d["launches"]}
+                out["roofline"]["per_kernel_serialised"] = ser
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["per_kernel_serialised"] = {"error": repr(e)}
         if full is not None:
             out["full_stream"] = full
         if world > 1:

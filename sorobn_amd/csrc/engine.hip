@@ -217,7 +217,12 @@ struct mibn_ctx {
         size_t items_cap = 0;
         hipEvent_t uploaded = nullptr;       // the copy stream has delivered this set's programs and schedule
         std::vector<hipEvent_t> ev;          // launch boundaries of the waves in flight
-        struct Timed { int kid; size_t e0, e1; double bytes, items; uint64_t call; };  // kid < 0: the wall time of a wave (kernel_ms); else one launch
+        struct Timed {  // kid >= 0: one launch; -1: the wall time of a wave (kernel_ms); -2: the launches of one level on the two streams of
+                        // option overlap, as ONE concurrent launch pair - events (e0, e1) of the level kernel's launch, (e2, e3) of the sweep
+                        // kernel's (kNone: the level has no such launch); its duration is the span from the earlier start to the later end
+            int kid; size_t e0, e1; double bytes, items; uint64_t call; size_t e2 = kNone, e3 = kNone, e4 = kNone, e5 = kNone;  // (e4, e5: the segment kernel's)
+            static constexpr size_t kNone = ~size_t(0);
+        };
         std::vector<Timed> timed;
         size_t ev_used = 0;
         bool busy = false;
@@ -304,11 +309,14 @@ struct mibn_ctx {
     } comm;
     std::string err;
     mibn_stats stats{}, total{};               // last call / since creation
-    mibn_kernel_stat kstats[kNumKernels + 4];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
-    mibn_kernel_stat ktotal[kNumKernels + 4];  // + the device planner's pair of kernels
+    mibn_kernel_stat kstats[kNumKernels + 6];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
+    mibn_kernel_stat ktotal[kNumKernels + 6];  // + the device planner's pair of kernels + the concurrent launch pair of a level (option overlap)
     // options
     double arena_gb = 200.0;  // scratch budget of all lanes together (of the 288 GB)
     hipStream_t stream2 = nullptr;  // lane 1 (lane 0 = stream)
+    hipStream_t aux[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // option overlap, per lane: the sweep kernel's and the segment kernel's launches
+    int seg_kernel = 1;             // the segments of a level as a launch of ve_segment_kernel (12 KB of LDS per workgroup) instead of workgroups
+                                    // of ve_level_kernel (40 KB, 168 VGPRs)
     hipEvent_t epoch = nullptr;     // reference of the busy-time bookkeeping (re-recorded when the GPU is idle)
     hipEvent_t lane_ev = nullptr, zero_ev = nullptr;  // end of lane 1's work of a call / results buffer zeroed
     double busy_until = 0;          // ms since epoch up to which GPU time has been booked as kernel_ms
@@ -323,7 +331,8 @@ struct mibn_ctx {
                           // items belong to different requests): the tail of one runs under the body of the other, +1-2 % (profiles/r03_k_overlap.log)
     int sweep_dma = 1;    // the sweep kernel: 1 = ve_sweep_dma_kernel (round 3: LDS-DMA fill, 16-byte LDS accesses, wave-local stage pairs,
                           // wave-owned tail); 0 = round 2's register-staged ve_sweep_kernel (reference for A/B runs and the bit-for-bit test)
-    int gibbs_lds = 1;    // Gibbs: keep the CPTs in LDS when they fit (0: always read them through L2)
+    int gibbs_lds = 1;    // Gibbs: 1 = CPTs in LDS when they fit + the eight-lanes-per-chain form for grids (gibbs_kernel8); 2 = LDS, one chain per
+                          // lane (round 3's kernel); 0 = always read the tables through L2
     int64_t chunk = 32768;  // requests per launch; planning of chunk i+1 overlaps the kernel of chunk i.  Round 3: 32 768 (16 384 before):
                             // half as many, twice as large launches - the tails of the ~150 launches of a chunk cost the same time
                             // whatever their size: 4.13-4.24 -> 4.30-4.38 TB/s over all kernels (profiles/r03_d_chunk.log); the
@@ -444,6 +453,10 @@ int mibn_create(int device, mibn_t **out) {
     h->n_cu = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->aux[0][0], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->aux[0][1], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->aux[1][0], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->aux[1][1], hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
     // the sweep kernel keeps its 64 KiB tile, the T tables and the step descriptor in dynamic LDS (two workgroups per CU)
     ok = ok && hipFuncSetAttribute((const void *)ve_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes) == hipSuccess;
@@ -504,6 +517,9 @@ void mibn_destroy(mibn_t *h) {
             if (sg.p) (void)hipHostFree(sg.p);
         if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
         if (h->stream2) (void)hipStreamDestroy(h->stream2);
+        for (auto &la : h->aux)
+            for (hipStream_t a : la)
+                if (a) (void)hipStreamDestroy(a);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -525,7 +541,8 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "split_kinds") h->split_kinds = value != 0;
     else if (n == "overlap") { if (mibn_drain(h) != MIBN_OK) return MIBN_E_HIP; h->overlap = value != 0; }
     else if (n == "sweep_dma") h->sweep_dma = value != 0;
-    else if (n == "gibbs_lds") h->gibbs_lds = value != 0;
+    else if (n == "seg_kernel") h->seg_kernel = value != 0;
+    else if (n == "gibbs_lds") h->gibbs_lds = std::max(0, std::min(2, (int)value));
     else if (n == "tiny") h->tiny = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
@@ -723,7 +740,7 @@ void ensure_pool(mibn_ctx *h) {
 
 // name of statistics slot k: the classes of work (split_kinds), then the kernels as launched
 const char *stat_name(int k) {
-    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : (k == kNumKernels + 2 ? "ve_sweep_dma_kernel" : "order_kernel+emit_kernel")));
+    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : (k == kNumKernels + 2 ? "ve_sweep_dma_kernel" : (k == kNumKernels + 3 ? "order_kernel+emit_kernel" : (k == kNumKernels + 4 ? "ve_level_kernel||ve_sweep_dma_kernel" : "ve_segment_kernel")))));
 }
 
 // wait for a set's launches and book their HIP-event durations per kernel
@@ -745,6 +762,23 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
             h->busy_until = std::max(h->busy_until, (double)t1);
             if (mine) h->stats.kernel_ms += add;
             h->total.kernel_ms += add;
+            continue;
+        }
+        if (t.kid == -2) {
+            // one level = one concurrent launch pair: from the earlier start to the later end (timestamps against the epoch event)
+            double lo = 1e300, hi = -1e300;
+            for (size_t e : {t.e0, t.e2, t.e4})
+                if (e != mibn_ctx::Set::Timed::kNone) { float x = 0; HIP_TRY(h, hipEventElapsedTime(&x, h->epoch, st.ev[e])); lo = std::min(lo, (double)x); }
+            for (size_t e : {t.e1, t.e3, t.e5})
+                if (e != mibn_ctx::Set::Timed::kNone) { float x = 0; HIP_TRY(h, hipEventElapsedTime(&x, h->epoch, st.ev[e])); hi = std::max(hi, (double)x); }
+            for (mibn_kernel_stat *ks : {&h->kstats[kNumKernels + 4], &h->ktotal[kNumKernels + 4]}) {
+                if (ks == &h->kstats[kNumKernels + 4] && !mine) continue;
+                if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", stat_name(kNumKernels + 4));
+                ks->launches += 1;
+                ks->ms += std::max(0.0, hi - lo);
+                ks->alg_bytes += t.bytes;
+                ks->items += t.items;
+            }
             continue;
         }
         if (mine) h->stats.n_launches += 1;
@@ -909,7 +943,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         HIP_TRY(h, hipMalloc(&h->d_emit_scratch, want));
         h->emit_scratch_cap = want;
     }
-    if ((rc = ensure(h, st.d_prog, st.prog_cap, std::max(prog_words, (size_t)n * stride)))) return rc;  // (+ room for the host's share of the chunk)
+    if ((rc = ensure(h, st.d_prog, st.prog_cap, std::max(prog_words, (size_t)n * stride) + kMaxStepWords))) return rc;  // (slack: segment_wave prefetches whole descriptor slots)  // (+ room for the host's share of the chunk)
     if (!h->emit_ev[0]) { HIP_TRY(h, hipEventCreate(&h->emit_ev[0])); HIP_TRY(h, hipEventCreate(&h->emit_ev[1])); }
     // the request arrays of the chunk in one pinned buffer: [q_off | e_off | out_off | q_vars | e_vars | e_codes | skip]
     char *pin = h->emit_in.p;
@@ -1154,7 +1188,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     h->search_ms = 0;
     h->emit_ms = 0;
     h->stats = mibn_stats{};
-    for (int k = 0; k <= kNumKernels + 3; ++k) {
+    for (int k = 0; k <= kNumKernels + 5; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
         std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", stat_name(k));
     }
@@ -1306,6 +1340,8 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             (void)hipStreamSynchronize(h->search_stream);
             (void)hipStreamSynchronize(h->stream);
             (void)hipStreamSynchronize(h->stream2);
+            for (auto &la : h->aux)
+                for (hipStream_t a : la) (void)hipStreamSynchronize(a);
             return code;
         };
         bool on_device = false;
@@ -1419,7 +1455,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         for (auto &b : st.bufs)
             if (b.cap && !b.data) { h->err = "pinned host allocation failed"; return MIBN_E_HIP; }
         h->stats.plan_ms += now_ms() - t0;
-        if (!on_device && (rc = ensure(h, st.d_prog, st.prog_cap, ck.total_words))) return rc;
+        if (!on_device && (rc = ensure(h, st.d_prog, st.prog_cap, ck.total_words + kMaxStepWords))) return rc;  // (slack: segment_wave prefetches whole descriptor slots)
         if ((rc = ensure(h, st.d_prog_off, st.prog_off_cap, (size_t)n))) return rc;
         if ((rc = ensure(h, st.d_arena_off, st.arena_off_cap, (size_t)n))) return rc;
         t0 = now_ms();
@@ -1485,22 +1521,34 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             // option overlap: the sweep launch of a level goes to a second stream, next to the level kernel's launch of the same
             // level (their items belong to different requests); level L + 1 starts on either stream when BOTH launches of level L
             // have finished.  The tail of one launch - a sweep workgroup lives ~100 us - then runs under the body of the other.
-            const bool two = h->overlap && n_lanes == 1;
-            hipStream_t S2 = h->stream2;
-            // event indices: the last launch end on S / S2 (running), the ends of the PREVIOUS level's launches (what the launches of
-            // this level wait for on the other stream - not the running ones: the level kernel's launch of level L comes first and
-            // the sweep launch of the same level must not wait for it), and what either stream has already waited for
-            long last_a = -1, last_b = -1, prev_a = -1, prev_b = -1, a_saw_b = -1, b_saw_a = (long)e_first;
+            const bool two = h->overlap != 0;
+            // streams of a wave: 0 = S (the level kernel), 1 = S2 (the sweep kernel), 2 = S3 (the segment kernel, option seg_kernel).  The
+            // launches of level L run side by side; a launch of level L + 1 waits for ALL launches of level L: the one on its own
+            // stream by stream order, the others through their end events (`prev`: the ends of the previous level - not the running
+            // `last`, or the launches of one level would serialise: ADVICE r3).
+            hipStream_t SS[3] = {S, h->aux[lane][0], h->aux[lane][1]};
+            constexpr size_t kNone = mibn_ctx::Set::Timed::kNone;
+            long last[3] = {-1, -1, -1}, prev[3] = {-1, -1, -1}, saw[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
             int cur_level = -1;
-            if (two) HIP_TRY(h, hipStreamWaitEvent(S2, st.ev[e_first], 0));  // (the uploads, the previous wave's kernels: the arena is theirs until then)
+            mibn_ctx::Set::Timed pair{-2, kNone, kNone, 0.0, 0.0, h->call_id};  // the level in progress, as one concurrent launch group
+            auto close_pair = [&]() {
+                if (pair.e0 != kNone || pair.e2 != kNone || pair.e4 != kNone) st.timed.push_back(pair);
+                pair = mibn_ctx::Set::Timed{-2, kNone, kNone, 0.0, 0.0, h->call_id};
+            };
+            if (two) {  // (the uploads, the previous wave's kernels: the arena is theirs until then)
+                HIP_TRY(h, hipStreamWaitEvent(SS[1], st.ev[e_first], 0));
+                HIP_TRY(h, hipStreamWaitEvent(SS[2], st.ev[e_first], 0));
+            }
             for (size_t li = 0; li < sc.launches.size();) {
-                // one launch of the level kernel per level (all its classes of work together) unless split_kinds, and one
-                // of the sweep kernel for the level's SWEEP items (the last class of a level: its own LDS budget)
+                // one launch of the level kernel per level (all its classes of work together) unless split_kinds, one of the
+                // segment kernel for the level's segments (the first class of a level; option seg_kernel) and one of the sweep kernel
+                // for its SWEEP items (the last class: its own LDS budget)
                 size_t lj = li + 1;
                 const bool sweep = sc.launches[li].kid == kKidSweep;
+                const bool seg = h->seg_kernel && !h->split_kinds && sc.launches[li].kid == kKidSeg;
                 double bytes = sc.launches[li].alg_bytes;
                 size_t grid = sc.launches[li].grid;
-                if (!h->split_kinds && !sweep)
+                if (!h->split_kinds && !sweep && !seg)
                     for (; lj < sc.launches.size() && sc.launches[lj].level == sc.launches[li].level && sc.launches[lj].kid != kKidSweep; ++lj) {
                         bytes += sc.launches[lj].alg_bytes;
                         grid += sc.launches[lj].grid;
@@ -1509,24 +1557,37 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 A.wg_item = st.d_wg_item + L.wg_level;
                 A.wg_base = (uint32_t)(L.wg_first - L.wg_level);
                 size_t e0 = 0, e1 = 0;
-                hipStream_t Sx = (two && sweep) ? S2 : S;
-                if (two) {  // the previous level's launch on the other stream
-                    if (L.level != cur_level) { cur_level = L.level; prev_a = last_a; prev_b = last_b; }
-                    if (sweep && prev_a > b_saw_a) { HIP_TRY(h, hipStreamWaitEvent(S2, st.ev[(size_t)prev_a], 0)); b_saw_a = prev_a; }
-                    if (!sweep && prev_b > a_saw_b) { HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)prev_b], 0)); a_saw_b = prev_b; }
+                const int si = two ? (sweep ? 1 : (seg ? 2 : 0)) : 0;
+                hipStream_t Sx = SS[si];
+                if (two) {
+                    if (L.level != cur_level) { cur_level = L.level; for (int j = 0; j < 3; ++j) prev[j] = last[j]; close_pair(); }
+                    for (int j = 0; j < 3; ++j)
+                        if (j != si && prev[j] > saw[si][j]) { HIP_TRY(h, hipStreamWaitEvent(Sx, st.ev[(size_t)prev[j]], 0)); saw[si][j] = prev[j]; }
                 }
                 if ((rc = next_event(h, st, e0, Sx))) return rc;
                 if (sweep && h->sweep_dma) hipLaunchKernelGGL(ve_sweep_dma_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, Sx, A);
                 else if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, Sx, A);
+                else if (seg) hipLaunchKernelGGL(ve_segment_kernel, dim3((unsigned)grid), dim3(kWG), 0, Sx, A);
                 else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, Sx, A);
                 if ((rc = next_event(h, st, e1, Sx))) return rc;
-                if (two) (sweep ? last_b : last_a) = (long)e1;
-                st.timed.push_back({sweep ? (h->sweep_dma ? kNumKernels + 2 : kKidSweep) : (h->split_kinds ? L.kid : kNumKernels), e0, e1, bytes, (double)grid, h->call_id});
+                if (two) {
+                    last[si] = (long)e1;
+                    if (!h->split_kinds) {
+                        if (si == 1) { pair.e2 = e0; pair.e3 = e1; } else if (si == 2) { pair.e4 = e0; pair.e5 = e1; } else { pair.e0 = e0; pair.e1 = e1; }
+                        pair.bytes += bytes;
+                        pair.items += (double)grid;
+                    }
+                }
+                st.timed.push_back({sweep ? (h->sweep_dma ? kNumKernels + 2 : kKidSweep) : (seg ? kNumKernels + 5 : (h->split_kinds ? L.kid : kNumKernels)), e0, e1, bytes, (double)grid, h->call_id});
                 n_wg += (double)grid;
                 li = lj;
             }
             {
-                if (two && last_b > a_saw_b) HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)last_b], 0));  // the wave ends on S
+                if (two) {
+                    close_pair();
+                    for (int j = 1; j < 3; ++j)  // the wave ends on S
+                        if (last[j] > saw[0][j]) HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)last[j]], 0));
+                }
                 size_t e_last = 0;
                 if ((rc = next_event(h, st, e_last, S))) return rc;
                 st.timed.push_back({-1, e_first, e_last, 0.0, 0.0, h->call_id});
@@ -1649,7 +1710,7 @@ extern "C" int mibn_total_stats(const mibn_t *h, mibn_stats *out) {
 extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 3 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 5 && k < cap; ++i)
         if (h->ktotal[i].launches > 0) out[k++] = h->ktotal[i];
     *n = k;
     return MIBN_OK;
@@ -1658,7 +1719,7 @@ extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel
 extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 3 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 5 && k < cap; ++i)
         if (h->kstats[i].launches > 0) out[k++] = h->kstats[i];
     *n = k;
     return MIBN_OK;
@@ -1687,7 +1748,7 @@ extern "C" int mibn_gibbs_shard(mibn_t *h, int32_t n_q, const int32_t *q_vars, i
         return MIBN_OK;
     }
     HIP_TRY(h, hipSetDevice(h->device));
-    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds != 0, n_q, q_vars, n_e, e_vars, e_codes, cycle, chain_first, n_chains,
+    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds, n_q, q_vars, n_e, e_vars, e_codes, cycle, chain_first, n_chains,
                      n_iterations, seed, counts, h->err, h->stats.kernel_ms);
 }
 
@@ -1704,7 +1765,7 @@ extern "C" int mibn_gibbs_conditional(mibn_t *h, int32_t n_e, const int32_t *e_v
     HIP_TRY(h, hipSetDevice(h->device));
     const int32_t q0 = var;  // (the histogram of the ordinary launch: one variable, unused)
     double ms = 0;
-    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds != 0, 1, &q0, n_e, e_vars, e_codes, cycle, 0, n_rows, 1, 0, nullptr, h->err, ms,
+    return gibbs_run(h->net, h->d_pool, h->stream, h->gibbs_lds, 1, &q0, n_e, e_vars, e_codes, cycle, 0, n_rows, 1, 0, nullptr, h->err, ms,
                      var, states, out);
 }
 

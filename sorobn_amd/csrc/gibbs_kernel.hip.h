@@ -334,13 +334,164 @@ __global__ __launch_bounds__(64 * kGibbsWaves) void gibbs_kernel(const GibbsArgs
         if (hist[i]) atomicAdd(&A.counts[i], (unsigned long long)hist[i]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 4: gibbs_kernel8 - the FAST form with EIGHT LANES PER CHAIN (lane = chain g of the wave x candidate state x).
+//
+// One chain per lane made the update a serial program of ~450 vector instructions on a wave that has its SIMD to itself
+// (config 5: 2 waves per GPU): 32 table reads and 24 fp64 multiplies for the 8 weights, an 8-long accumulate-and-select
+// loop, and - a third of the 2 800 cycles - Philox4x32-10 (40 quarter-rate 32-bit multiplies) in every lane.  Here a chain
+// is spread over 8 lanes: lane x reads the 4 table values of candidate state x and multiplies them (same order), the
+// running sum is a 7-step DPP scan ALONG the lanes in the sequential order of the loop it replaces (acc_x = acc_(x-1) + w_x:
+// bit for bit the same sums, so the same draws), the draw is one ballot + find-first, and lane x computes the Philox
+// uniform of iteration it0 + x once per eight iterations (same counter, same key => the same stream).  Eight chains per
+// wave, so config 5's 128 chains per GPU are 16 workgroups on 16 CUs instead of 2.  Histograms bit for bit those of
+// gibbs_kernel (tests: the gibbs_lds=0 / gibbs_fast8=0 comparisons), COND as there.
+__device__ __forceinline__ double dpp_f64(const double v, const int ctrl_is_shr1_mirror_q3) {
+    // 0: row_shr:1 (lane i <- lane i - 1), 1: row_half_mirror (lane x <- lane 7 - x of its 8), 2: quad_perm [3, 3, 3, 3]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ctrl_is_shr1_mirror_q3 == 0) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false);
+    } else if (ctrl_is_shr1_mirror_q3 == 1) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xff, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xff, 0xf, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+template <bool COND>
+__global__ __launch_bounds__(64) void gibbs_kernel8(const GibbsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, g = lane >> 3, x = lane & 7;
+    uint8_t *st = smem;                                        // state[var * 8 + chain of the wave] (room for n_vars * 64 as in gibbs_kernel)
+    unsigned int *hist = (unsigned int *)(smem + ((A.n_vars * 64 + 15) & ~15));
+    double *lds_pool = (double *)(smem + ((((A.n_vars * 64 + 15) & ~15) + A.hist_cells * 4 + 15) & ~15));
+    for (int i = threadIdx.x; i < A.pool_cells; i += blockDim.x) lds_pool[i] = A.pool[i];
+    if (threadIdx.x == 0) lds_pool[A.pool_cells] = 1.0;  // the table of an unused factor slot
+    int32_t *lds_prog = (int32_t *)((unsigned char *)lds_pool + (((size_t)(A.pool_cells + 1) * 8 + 15) & ~size_t(15)));
+    for (int i = threadIdx.x; i < A.uprog_words; i += blockDim.x) lds_prog[i] = A.uprog[i];
+    const int64_t local = (int64_t)blockIdx.x * 8 + g;
+    const int64_t chain = A.chain_first + local;
+    const bool active = local < A.n_chains;
+    for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x) hist[i] = 0;
+    const uint32_t k0 = (uint32_t)A.seed ^ (uint32_t)chain * 0x9E3779B1u;
+    const uint32_t k1 = (uint32_t)(A.seed >> 32) ^ (uint32_t)(chain >> 32) ^ 0x85EBCA6Bu;
+    // forward (ancestral) sample with the evidence clamped (bayes_net.py:715): the eight lanes of a chain compute the same values
+    for (int v = 0; v < A.n_vars; ++v) {
+        const GibbsVar V = A.vars[v];
+        int val = V.ev_code;
+        if (COND) {
+            if (!V.is_evidence) val = active ? (int)A.cond_states[local * A.n_vars + v] : 0;
+        } else if (!V.is_evidence) {
+            int off = V.table_off;
+            for (int k = 0; k + 1 < V.scope_len; ++k)
+                off += (int)st[A.scope_var[V.scope_begin + k] * 8 + g] * A.scope_stride[V.scope_begin + k];
+            double total = 0;
+            for (int c = 0; c < V.card; ++c) total += A.pool[off + c];
+            const double u = philox_uniform((uint64_t)v, 1u, k0, k1) * total;
+            double acc = 0;
+            val = V.card - 1;
+            for (int c = 0; c < V.card; ++c) {
+                acc += A.pool[off + c];
+                if (u < acc) { val = c; break; }
+            }
+        }
+        st[v * 8 + g] = (uint8_t)val;
+    }
+    __syncthreads();
+    int qv4[4] = {0, 0, 0, 0}, qs4[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 4 && q < A.n_q; ++q) { qv4[q] = A.qvars[q]; qs4[q] = A.qstride[q]; }
+    auto query_cell = [&]() {
+        int cell = 0;
+        if (A.n_q <= 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cell += (int)st[qv4[q] * 8 + g] * qs4[q];
+        } else {
+            for (int q = 0; q < A.n_q; ++q) cell += (int)st[A.qvars[q] * 8 + g] * A.qstride[q];
+        }
+        return cell;
+    };
+    int cell = query_cell();  // changes only when a query variable is updated (record word 3)
+    int cyc = COND ? A.cond_pos : 0;
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 cur[kFastWords / 4];
+#pragma unroll
+    for (int q = 0; q < kFastWords / 4; ++q) cur[q] = reinterpret_cast<const i32x4 *>(lds_prog + cyc * kFastWords)[q];
+    double my_u = 0.0;
+    for (int64_t it = 0; it < (COND ? 1 : A.n_iterations); ++it) {
+        i32x4 rec[kFastWords / 4];
+#pragma unroll
+        for (int q = 0; q < kFastWords / 4; ++q) rec[q] = cur[q];
+        cyc = cyc + 1 == A.n_cycle ? 0 : cyc + 1;
+#pragma unroll
+        for (int q = 0; q < kFastWords / 4; ++q) cur[q] = reinterpret_cast<const i32x4 *>(lds_prog + cyc * kFastWords)[q];
+        const int v = __builtin_amdgcn_readfirstlane(rec[0][0]);
+        const int card = __builtin_amdgcn_readfirstlane(rec[0][1]);
+        const int is_q = __builtin_amdgcn_readfirstlane(rec[0][3]);
+        // the uniforms of iterations it .. it + 7: lane x draws the one of it + x (same counter and key as one chain per lane)
+        if ((it & 7) == 0) my_u = philox_uniform((uint64_t)(it + x), 0u, k0, k1);
+        const double u01 = __shfl(my_u, (lane & ~7) | (int)(it & 7), 64);
+        int base[4], sv[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int w0 = 4 + 6 * f;
+            auto R = [&](int k) { return rec[(w0 + k) >> 2][(w0 + k) & 3]; };
+            base[f] = R(0) + (int)st[R(2) * 8 + g] * R(3) + (int)st[R(4) * 8 + g] * R(5);
+            sv[f] = R(1);
+        }
+        const bool on = x < card;
+        double p = lds_pool[on ? base[0] + x * sv[0] : A.pool_cells];
+#pragma unroll
+        for (int f = 1; f < 4; ++f) p *= lds_pool[on ? base[f] + x * sv[f] : A.pool_cells];
+        const double w = on ? p : 0.0;
+        // acc_x = acc_(x-1) + w_x, in the order of the serial loop (lanes beyond card add 0.0: their sum is the total)
+        double acc = w;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const double t = dpp_f64(acc, 0);
+            if (x == k) acc = t + w;
+        }
+        // the total = lane 7's sum, to every lane of the chain: quad_perm [3,3,3,3] (lanes 4-7 have it), mirrored into lanes 0-3
+        const double q3 = dpp_f64(acc, 2);
+        const double total = x < 4 ? dpp_f64(q3, 1) : q3;
+        if constexpr (COND) {
+            if (active && on) A.cond_out[local * card + x] = total > 0 ? w / total : 0.0;
+        } else {
+            const double u = u01 * total;
+            const unsigned long long hit = __ballot(on && u < acc), pos = __ballot(on && w > 0);
+            const unsigned hb = (unsigned)(hit >> (8 * g)) & 0xffu, pb = (unsigned)(pos >> (8 * g)) & 0xffu;
+            if (total > 0) {
+                const int val = hb ? __ffs((int)hb) - 1 : (pb ? 31 - __clz((int)pb) : 0);
+                st[v * 8 + g] = (uint8_t)val;  // (the eight lanes write the same byte)
+            }
+            if (is_q) cell = query_cell();
+            if (active && x == 0) atomicAdd(&hist[cell], 1u);  // bayes_net.py:732-733: every iteration, no burn-in
+        }
+        if ((it & 0xffffff) == 0xffffff) {  // flush before a 32-bit LDS counter can overflow
+            __syncthreads();
+            for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x) {
+                if (hist[i]) atomicAdd(&A.counts[i], (unsigned long long)hist[i]);
+                hist[i] = 0;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.hist_cells; i += blockDim.x)
+        if (hist[i]) atomicAdd(&A.counts[i], (unsigned long long)hist[i]);
+}
+
 // host driver; returns MIBN_* code
 // cond_var >= 0 (mibn_gibbs_conditional): n_chains rows of cond_states, the conditional of cond_var into cond_out
-inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t stream, bool allow_lds, int32_t n_q, const int32_t *q_vars,
+inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t stream, int lds_mode /* 0: tables in L2; 1: LDS; 2: LDS, no 8-lane form */, int32_t n_q, const int32_t *q_vars,
                      int32_t n_e, const int32_t *e_vars, const int32_t *e_codes, const int32_t *cycle_in, int64_t chain_first,
                      int64_t n_chains, int64_t n_iterations, uint64_t seed, int64_t *counts, std::string &err, double &kernel_ms,
                      int32_t cond_var = -1, const uint8_t *cond_states = nullptr, double *cond_out = nullptr) {
     const int n = net.n_vars;
+    const bool allow_lds = lds_mode != 0;
     std::vector<GibbsVar> vars(n);
     std::vector<int32_t> scope_var, scope_stride, children, cycle;
     std::vector<std::vector<int32_t>> ch(n);
@@ -418,7 +569,10 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     // tables in LDS too when they fit beside the state and the launch is small enough for one workgroup per CU
     const size_t pool_cells = net.pool.size();
     const size_t lds_with_pool = (lds + 15) / 16 * 16 + pool_cells * 8;
-    const bool pool_lds = allow_lds && lds_with_pool <= 160 * 1024 && (n_chains + 63) / 64 <= 512;
+    // the 8-lane form (gibbs_kernel8) has eight chains per workgroup: it wins while its workgroups - one per CU, the tables fill the
+    // LDS - need at most two rounds over the 256 CUs (~0.4 us per update against 1.16 us for gibbs_kernel's 64 chains per wave)
+    const bool want8 = lds_mode == 1 && (n_chains + 7) / 8 <= 512;
+    const bool pool_lds = allow_lds && lds_with_pool <= 160 * 1024 && (want8 || (n_chains + 63) / 64 <= 512);
     if (pool_lds) lds = lds_with_pool;
     // fixed-size update records (gibbs_kernel<.., FAST>) when every variable of the cycle qualifies and they still fit
     bool fast = pool_lds;
@@ -426,7 +580,9 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     for (size_t ci = 0; ci < cycle.size() && fast; ++ci) {
         const int v = cycle[ci];
         if (net.card[v] > 8 || 1 + ch[v].size() > 4) { fast = false; break; }
-        const int32_t head[4] = {v, net.card[v], 1 + (int32_t)ch[v].size(), 0};
+        int32_t is_query = 0;
+        for (int i = 0; i < n_q; ++i) is_query |= q_vars[i] == v;
+        const int32_t head[4] = {v, net.card[v], 1 + (int32_t)ch[v].size(), is_query};
         fprog.insert(fprog.end(), head, head + 4);
         int slots = 0;
         auto record = [&](int c) {
@@ -513,12 +669,13 @@ inline int gibbs_run(const Network &net, const double *d_pool, hipStream_t strea
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const unsigned blocks = (unsigned)((n_chains + 63) / 64);
-    auto kernel = fast ? gibbs_kernel<true, true, true>
+    const bool fast8 = fast && want8;
+    const unsigned blocks = fast8 ? (unsigned)((n_chains + 7) / 8) : (unsigned)((n_chains + 63) / 64);
+    auto kernel = fast8 ? gibbs_kernel8<false> : fast ? gibbs_kernel<true, true, true>
                        : pool_lds ? (prog_lds ? gibbs_kernel<true, true> : gibbs_kernel<true, false>)
                                   : (prog_lds ? gibbs_kernel<false, true> : gibbs_kernel<false, false>);
     if (cond_var >= 0)  // the same form, writing the weights instead of drawing from them
-        kernel = fast ? gibbs_kernel<true, true, true, true>
+        kernel = fast8 ? gibbs_kernel8<true> : fast ? gibbs_kernel<true, true, true, true>
                       : pool_lds ? (prog_lds ? gibbs_kernel<true, true, false, true> : gibbs_kernel<true, false, false, true>)
                                  : (prog_lds ? gibbs_kernel<false, true, false, true> : gibbs_kernel<false, false, false, true>);
     if (lds > 64 * 1024) {

@@ -911,11 +911,23 @@ __device__ __forceinline__ void segment_wave(const LevelArgs &A, const uint32_t 
     unsigned char *wbase = reinterpret_cast<unsigned char *>(shT) + wave * (kMaxStepWords * 4 + kMaxIn * kTileMax * 4);
     uint32_t *w_step = reinterpret_cast<uint32_t *>(wbase);
     int (*w_hoff)[kTileMax] = reinterpret_cast<int (*)[kTileMax]>(wbase + kMaxStepWords * 4);
+    // The descriptor of step s + 1 is fetched (kMaxStepWords words, whatever its length: the chunk's program buffer ends with that
+    // much slack) while step s runs: a step of a chain is two dependent global round trips - its descriptor, then its inputs -
+    // and this takes the first one off the chain.
+    constexpr int kPre = kMaxStepWords / 64;
+    uint32_t nxt[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) nxt[k] = p[lane + 64 * k];
     for (int s = 0; s < n_steps; ++s) {
-        const int words = (int)p[6];
         lanes_sync<64>();  // the previous step's stores are done and visible to this wave; its descriptor copy is reusable
-        for (int i = lane; i < words; i += 64) w_step[i] = p[i];
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) w_step[lane + 64 * k] = nxt[k];
         lanes_sync<64>();
+        const int words = (int)w_step[6];
+        if (s + 1 < n_steps) {
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) nxt[k] = p[words + lane + 64 * k];
+        }
         generic_dispatch<64>((w_step[0] >> 8) & 0xff, w_step, w_hoff, A.pool, slot, A.results, lane, 0, (int)w_step[3]);
         if ((w_step[1] >> 16) & kFlagFinal) {
             const uint64_t out_off = (uint64_t)w_step[4] | ((uint64_t)w_step[5] << 32);
@@ -1004,5 +1016,18 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
 }
 #undef MIBN_FIBER_CASES
 #undef MIBN_MFMA_CASES
+
+// Round 4: the segments of a level as a kernel of their own (option seg_kernel, launched on a third stream beside the level's
+// other launches).  A segment is a chain of dependent tiny steps - a few global round trips per step, nothing to stream - and
+// inside ve_level_kernel it paid for that kernel's resources: 40 KB of LDS and 168 VGPRs per workgroup = three workgroups =
+// twelve chains per CU.  Here a workgroup needs its four waves' descriptor copies and offset tables (12 KB) and the registers
+// of the GENERIC form alone: the wave slots of a CU, not its LDS, bound the chains in flight.
+__global__ __launch_bounds__(kWG, 4) void ve_segment_kernel(const LevelArgs A) {
+    __shared__ __attribute__((aligned(16))) unsigned char sh_seg[kSegPerWg * (kMaxStepWords * 4 + kMaxIn * kTileMax * 4)];
+    const uint32_t wg = blockIdx.x + A.wg_base;
+    const uint32_t item_idx = (uint32_t)uni((int)A.wg_item[wg]);
+    const int n_valid = uni((int)A.items[item_idx].b);
+    segment_wave(A, item_idx, n_valid, reinterpret_cast<double *>(sh_seg), threadIdx.x);
+}
 
 }  // namespace mibn

@@ -1043,6 +1043,32 @@ def test_gibbs_matches_exact_posterior(amd):
     assert a.equals(d)
 
 
+def test_gibbs_eight_lanes_per_chain_bit_for_bit(amd):
+    """gibbs_kernel8 (round 4: eight lanes per chain - a lane per candidate state, a DPP scan in the serial order, one Philox draw
+    per lane and eight iterations) against round 3's one-chain-per-lane kernel (gibbs_lds=2) and the L2 path (gibbs_lds=0): the same
+    Philox counters, the same products and running sums, so the same histograms bit for bit - 3- and 8-state grids, one and two
+    query variables, chain counts that do not fill the last wave, shards of one stream."""
+    for (R, C, K, q, ev, chains, iters) in ((4, 5, 3, ("012",), {"000": 1, "019": 2, "007": 0}, 61, 700),
+                                            (4, 5, 3, ("009", "010"), {"000": 1}, 130, 300),
+                                            (5, 10, 8, ("025",), {"000": 3, "009": 1, "040": 7, "049": 0, "022": 5}, 128, 2000),
+                                            (3, 3, 8, ("004", "008"), {}, 9, 1500)):
+        bn = netspec.build(netspec.grid_spec(R, C, K, seed=2), amd.BayesNet)
+        be = bn.backend
+        got = {}
+        for mode in (1, 2, 0):
+            be.engine.set_option("gibbs_lds", mode)
+            got[mode] = be.gibbs_sampling(*q, event=ev, n_iterations=iters, n_chains=chains, seed=5)
+        be.engine.set_option("gibbs_lds", 1)
+        assert got[1].equals(got[2]) and got[1].equals(got[0]), (R, C, K, q)
+        assert abs(got[1].sum() - 1.0) < 1e-12
+        # shards of one stream (mibn_gibbs_shard): two halves = the whole
+        qq, evs, codes = be.encode(q, ev)
+        whole = be.engine.gibbs(qq, evs, codes, chains, iters, seed=9)
+        cut = chains // 3
+        parts = be.engine.gibbs(qq, evs, codes, cut, iters, seed=9) + be.engine.gibbs(qq, evs, codes, chains - cut, iters, seed=9, chain_first=cut)
+        assert np.array_equal(whole, parts)
+
+
 def test_gibbs_through_query_api(amd):
     """query(..., algorithm='gibbs', n_iterations=N): one chain like the reference (bayes_net.py:850-853),
     returns value counts / N over the visited joint states."""
