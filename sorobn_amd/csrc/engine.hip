@@ -749,9 +749,9 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
     HIP_TRY(h, hipEventSynchronize(st.ev[st.ev_used - 1]));
     for (auto &t : st.timed) {
         float ms = 0;
-        HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));
+        if (t.kid != -2) HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));  // (-2: a level's launch group - any of its event pairs may be absent)
         const bool mine = t.call == h->call_id;  // (launches of an earlier asynchronous call only count in the totals)
-        if (t.kid < 0) {
+        if (t.kid == -1) {
             // GPU time of a wave, first launch to last.  With two lanes the waves of consecutive chunks overlap: what is
             // booked as kernel_ms is the time the GPU was busy (the union of the intervals, kept as a high-water mark
             // since the epoch event; sets retire in launch order)

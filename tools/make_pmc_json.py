@@ -26,7 +26,8 @@ per = {}
 for name in sorted(set(fetch) & set(write)):
     f, w = fetch[name][1], write[name][1]
     k = bench.get("kernels", {}).get(name)
-    corr = 1.0 if name in ("ve_sweep_kernel", "ve_sweep_dma_kernel") else 2.0  # (see the session's *_pmc_calibration.log)
+    corr = 1.0 if name in ("ve_sweep_kernel", "ve_sweep_dma_kernel") else 2.0  # (see the session's *_pmc_calibration.log; the segment
+    # kernel's scattered 8-byte reads are neither: its ratio is indicative only - 1.5 % of the bytes)
     # The counter passes see EVERY launch of the command (warm-up steps and the short first chunk of the pipeline included), the
     # bench line books the timed steps only: compare totals - traffic of all launches against the algorithmic bytes of all
     # steps (the steps are i.i.d. request batches of one size: algorithmic bytes per step x (steps + warm-up)) - and express
@@ -36,6 +37,16 @@ for name in sorted(set(fetch) & set(write)):
     per[name] = {"launches_under_the_counters": fetch[name][0], "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
                  "fetch_correction": corr, "traffic_bytes_per_launch": corr * f * 1024 + w * 1024,
                  "alg_bytes_per_launch_same_run": alg_per_launch}
+# the concurrent launches of a level as one unit (bench.py's roofline names it when option overlap is on): the counters of its
+# kernels summed (the PMC passes serialise the kernels, so every kernel's bytes are its own)
+grp = [n for n in per if n in ("ve_level_kernel", "ve_sweep_dma_kernel", "ve_segment_kernel") and per[n]["alg_bytes_per_launch_same_run"]]
+if len(grp) >= 2:
+    tot_t = sum(per[n]["traffic_bytes_per_launch"] * per[n]["launches_under_the_counters"] for n in grp)
+    tot_a = sum(per[n]["alg_bytes_per_launch_same_run"] * per[n]["launches_under_the_counters"] for n in grp)
+    levels = max(per[n]["launches_under_the_counters"] for n in grp)
+    per["ve_level_kernel||ve_sweep_dma_kernel"] = {"launches_under_the_counters": levels, "fetch_correction": "per kernel, see its entries",
+                                                   "traffic_bytes_per_launch": tot_t / levels, "alg_bytes_per_launch_same_run": tot_a / levels,
+                                                   "members": grp}
 out = {"source": path + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of the bench command)",
        "note": "gfx950 FETCH_SIZE counts 64 B per 128-B request: doubled for ve_level_kernel; ve_sweep_kernel's 64-byte runs are "
                "counted in full (calibration: profiles/r02_u_pmc_calibration.log); WRITE_SIZE as reported", "per_kernel": per}

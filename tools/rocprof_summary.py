@@ -21,6 +21,29 @@ def kernel_stats(db):
     return out
 
 
+def level_groups(db):
+    """The launches of a level run concurrently on up to three streams (option overlap): their unit of time is the level - from the
+    earliest start to the latest end of its launches.  A launch of level L + 1 starts only after every launch of level L has ended,
+    so the levels are the connected components of the union of the VE kernels' intervals."""
+    cur = sqlite3.connect(db).cursor()
+    iv = sorted((s, e) for n, s, e in cur.execute("select name, start, end from kernels") if any(k in n for k in ("ve_level_kernel", "ve_sweep", "ve_segment_kernel")))
+    if not iv:
+        return []
+    comps, (cs, ce), busy = [], iv[0], 0
+    for s, e in iv[1:]:
+        if s <= ce:
+            ce = max(ce, e)
+        else:
+            comps.append((cs, ce))
+            cs, ce = s, e
+    comps.append((cs, ce))
+    tot = sum(e - s for s, e in comps) / 1e6
+    single = sum(e - s for s, e in iv) / 1e6
+    return [f"levels (connected components of the VE kernels' intervals = ve_level_kernel||ve_sweep_dma_kernel[||ve_segment_kernel]): {len(comps)} "
+            f"groups, total {tot:.3f} ms = GPU busy time of the VE kernels, avg {tot / len(comps):.3f} ms per level; the sum of the individual "
+            f"kernel durations is {single:.3f} ms ({single / tot:.2f} x: concurrent launches share the chip)"]
+
+
 def pmc_stats(db):
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, counter_name, count(*), avg(counter_value), avg(duration)/1e6 from pmc_events "
@@ -34,5 +57,6 @@ def pmc_stats(db):
 
 if __name__ == "__main__":
     print("\n".join(kernel_stats(sys.argv[1])))
+    print("\n".join(level_groups(sys.argv[1])))
     for db in sys.argv[2:]:
         print("\n".join(pmc_stats(db)))
