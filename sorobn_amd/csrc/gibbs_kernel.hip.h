@@ -455,8 +455,11 @@ __global__ __launch_bounds__(64) void gibbs_kernel8(const GibbsArgs A) {
             if (x == k) acc = t + w;
         }
         // the total = lane 7's sum, to every lane of the chain: quad_perm [3,3,3,3] (lanes 4-7 have it), mirrored into lanes 0-3
+        // (both DPP moves with every lane enabled - a `?:` around the second one would run it with lanes 4-7 masked off, and a DPP
+        //  read of a disabled lane leaves the destination unchanged: round 4's first version drew lanes 0-3 against a partial sum)
         const double q3 = dpp_f64(acc, 2);
-        const double total = x < 4 ? dpp_f64(q3, 1) : q3;
+        const double q3m = dpp_f64(q3, 1);
+        const double total = x < 4 ? q3m : q3;
         if constexpr (COND) {
             if (active && on) A.cond_out[local * card + x] = total > 0 ? w / total : 0.0;
         } else {

@@ -302,6 +302,12 @@ __device__ __forceinline__ void sweep_tiles_any(double *__restrict__ L, const do
 // The step encoding and the arithmetic (order of the FMAs per output cell) are those of the kernel above: the two kernels
 // agree bit for bit (tests/test_gpu_parity.py::test_sweep_kernels_agree_bit_for_bit).
 
+#ifndef MIBN_SWEEP_TAIL_LOCAL
+#define MIBN_SWEEP_TAIL_LOCAL 1  // wave-owned tail: no workgroup barrier between stage K - 2 and the last stage (same cells per wave)
+#endif
+#ifndef MIBN_SWEEP_VMCNT
+#define MIBN_SWEEP_VMCNT 8       // wave-owned tail: the wait for the next tile's DMA leaves this many younger stores in flight (0: drain)
+#endif
 #ifndef MIBN_PROF_INIT  // (tools/ubench/sweep_real.hip defines these to time the phases of a tile with wall_clock64)
 #define MIBN_PROF_INIT
 #define MIBN_PROF_TICK(k)
@@ -599,7 +605,11 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
     for (int i = 0; i < n_tiles; ++i) {
         const int tile = t_begin + i;
         MIBN_PROF_TICK(0)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed
+        // this wave's share of the tile has landed.  Wave-owned tail: the DMA was issued BEFORE the eight 16-byte stores of the
+        // last stage (sweep_last_stage_out) and the vector-memory operations of a wave retire in order, so "at most eight
+        // operations outstanding" means the DMA is done - the wave does not sit out the write acknowledgements of its stores
+        if (OWN && MIBN_SWEEP_VMCNT == 8 && i > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MIBN_PROF_TICK(1)
         __syncthreads();  // ... and everybody else's (first tile: T is complete)
         const int rg = tile * Rt + (K ? 2 * rp : (tid & (Rt - 1)));  // this lane's (even) R cell
@@ -633,7 +643,9 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
                 constexpr int SX = kRt << (2 * G.dig), SL = kRt << (2 * G.loop);                                              \
                 if (cout == 4) sweep_fiber_pairs<4, SX, SL>(L, T, bs, toff, loop_ts, par_ts);                                 \
                 else sweep_fiber_pairs<1, SX, SL>(L, T, bs, toff, loop_ts, par_ts);                                           \
-                if constexpr (G.sync_after) __syncthreads();                                                                  \
+                /* (wave-owned tail: stage K - 2 and the last stage give a wave the same cells - sweep_geom - so that hand-over \
+                    is wave-local too: two workgroup barriers per tile, after the landing and after stage 1 / K - 3) */        \
+                if constexpr (G.sync_after && !(MIBN_SWEEP_TAIL_LOCAL && OWN && J == K - 2)) __syncthreads();                 \
                 else {  /* wave-local hand-over: order the wave's own LDS writes before its reads of the next stage */        \
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                    \
                     __builtin_amdgcn_wave_barrier();                                                                          \
