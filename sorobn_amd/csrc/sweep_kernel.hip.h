@@ -305,6 +305,12 @@ __device__ __forceinline__ void sweep_tiles_any(double *__restrict__ L, const do
 #ifndef MIBN_SWEEP_TAIL_LOCAL
 #define MIBN_SWEEP_TAIL_LOCAL 1  // wave-owned tail: no workgroup barrier between stage K - 2 and the last stage (same cells per wave)
 #endif
+#ifndef MIBN_SWEEP_DEAD_TAIL
+#define MIBN_SWEEP_DEAD_TAIL 1   // the wave-owned tail also for five-variable passes in which one digit dies (kout = 4)
+#endif
+#ifndef MIBN_SWEEP_DEAD_SKIP
+#define MIBN_SWEEP_DEAD_SKIP 1   // ... and the stages behind the dying one skip the fibers that carry nothing
+#endif
 #ifndef MIBN_SWEEP_VMCNT
 #define MIBN_SWEEP_VMCNT 8       // wave-owned tail: the wait for the next tile's DMA leaves this many younger stores in flight (0: drain)
 #endif
@@ -351,7 +357,7 @@ constexpr SweepGeom sweep_geom(const int K, const int J) {
             case 0: return {4, 1, {0, 3, 2}, false};
             case 1: return {3, 1, {0, 4, 2}, true};
             case 2: return {2, 4, {0, 1, 3}, false};
-            case 3: return {1, 4, {0, 2, 3}, true};
+            case 3: return {1, 4, {0, 2, 3}, !MIBN_SWEEP_TAIL_LOCAL};  // (stages 2, 3 AND 4 give a wave the same cells: d3, a pair of d4)
             default: return {0, 4, {1, 2, 3}, true};
         }
     }
@@ -393,11 +399,12 @@ __device__ __forceinline__ int sweep_pair_base(const int tid) {
 // cells are then reduced one after the other through the same T registers (a second slice in registers spills at 128 VGPRs).
 template <int COUT, int SX, int SL, bool PAR>
 __device__ __forceinline__ void sweep_fiber_pairs_impl(double *__restrict__ L, const double *__restrict__ T, const int base, const int toff,
-                                                       const int loop_ts, const int par_ts) {
+                                                       const int loop_ts, const int par_ts, const int nl) {
     constexpr int NT = 4 * COUT;
     double t0[NT];
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
+        if (l >= nl) break;  // (nl = 1: the loop digit has died - only its value 0 carries anything.  A constant 2 everywhere else)
         if (PAR || l == 0 || loop_ts) {  // (uniform)
             const double2 *__restrict__ Tp = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts));
 #pragma unroll
@@ -442,11 +449,11 @@ __device__ __forceinline__ void sweep_fiber_pairs_impl(double *__restrict__ L, c
 }
 template <int COUT, int SX, int SL>
 __device__ __forceinline__ void sweep_fiber_pairs(double *__restrict__ L, const double *__restrict__ T, const int base, const int toff,
-                                                  const int loop_ts, const int par_ts) {
+                                                  const int loop_ts, const int par_ts, const int nl = 2) {
     // (uniform.  A straight-line variant for loop_ts = 0 - all sixteen reads of a lane in flight, then the FMAs, then the
     //  writes - was measured: no faster with one workgroup per CU, spills at the 128-VGPR budget of two)
-    if (par_ts) sweep_fiber_pairs_impl<COUT, SX, SL, true>(L, T, base, toff, loop_ts, par_ts);
-    else sweep_fiber_pairs_impl<COUT, SX, SL, false>(L, T, base, toff, loop_ts, 0);
+    if (par_ts) sweep_fiber_pairs_impl<COUT, SX, SL, true>(L, T, base, toff, loop_ts, par_ts, nl);
+    else sweep_fiber_pairs_impl<COUT, SX, SL, false>(L, T, base, toff, loop_ts, 0, nl);
 }
 
 // The last stage of a wave-owned tail (sweep_tiles_dma, OWN): the results go from the registers straight to the output
@@ -535,6 +542,119 @@ __device__ __forceinline__ void sweep_last_stage_out(const double *__restrict__ 
     }
 }
 
+// The wave-owned tail of a five-variable pass in which ONE digit dies (kout = 4: a stage with cout = 1 - the variable of that digit has
+// no successor in the frontier - 11 % of the C3 bytes).  Round 3 sent these steps through the readout path (a last stage that writes
+// LDS, a workgroup barrier, a readout pass, another barrier, then the next tile's DMA with its whole latency exposed: 10.6 us per
+// 80 KiB tile, 3.8 TB/s in isolation - tools/ubench/sweep_real.hip with a dying stage, profiles/r04_e_sweep_dead.log).  Here the last
+// stage has the same geometry, the same refill of the wave's own cells and the same register-to-memory stores as
+// sweep_last_stage_out; what differs is which lanes hold anything (a stage with cout = 1 leaves its result where the digit is 0:
+// only lanes - for digit 3 waves, for digit 4 the first of the two loop values - whose dead digit is 0 store) and where a cell
+// goes: the surviving digits are packed in ascending order, cell = sum of value(d) << pos(d) + (r << 8).  dead = 0: the last stage
+// itself has cout = 1 and a lane stores one value per cell instead of four.  Same FMA order per output cell as every other path.
+template <bool PAR, class DmaNext>
+__device__ __forceinline__ void sweep_last_stage_out_dead(const double *__restrict__ L, const double *__restrict__ T, double *__restrict__ ot,
+                                                          const int tid, const int rg_tile, const uint32_t s1, const uint32_t (&cw)[3],
+                                                          const int nctrl, const int dead, DmaNext dma_next) {
+    constexpr int K = 5, RB = 3, RT = 8;
+    constexpr SweepGeom G = sweep_geom(K, K - 1);  // dig 0, fields (1, 2, 3), loop 4
+    static_assert(G.dig == 0 && G.f[0] == 1 && G.f[1] == 2 && G.f[2] == 3 && G.loop == 4, "last stage of a five-variable pass");
+    const int d1 = tid & 3, rp = (tid >> 2) & 3, d2 = (tid >> 4) & 3, d3 = (tid >> 6) & 3, h = (tid >> 8) & 1;
+    const int base = 2 * rp + (d1 << (RB + 2)) + (d2 << (RB + 4)) + (d3 << (RB + 6)) + ((2 * h) << (RB + 8));
+    // position of digit d in the packed output cell: digits below the dead one keep 2 d, digits above it move down to 2 (d - 1)
+    // (the dead digit's value is 0 wherever a lane stores: its own shift never matters)
+    const int q1 = 1 > dead ? 0 : 2, q2 = 2 > dead ? 2 : 4, q3 = 3 > dead ? 4 : 6, q4 = 4 > dead ? 6 : 8;
+    int toff = (int)(s1 & 0xffff), loop_ts = 0, par_ts = 0;
+    const int rg = rg_tile + 2 * rp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c < nctrl) {
+            const int src = cw[c] & 0xff, ts = (int)(cw[c] >> 8);
+            if (src >= 8) { toff += ((rg >> (src - 8)) & 3) * ts; if (src == 8) par_ts = ts; }
+            else {
+                toff += ((base >> (RB + 2 * src)) & 3) * ts;
+                if (src == G.loop) loop_ts = ts;
+            }
+        }
+    constexpr int SX = RT, SL = RT << (2 * G.loop);
+    const double2 *__restrict__ Lp = reinterpret_cast<const double2 *>(L + base);
+    double2 f[2][4];
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) f[l][x] = Lp[(l * SL + x * SX) / 2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the data is in the registers before the DMA may overwrite the cells)
+    dma_next();
+    const bool lane_on = dead == 1 ? d1 == 0 : (dead == 2 ? d2 == 0 : (dead == 3 ? d3 == 0 : (dead == 4 ? h == 0 : true)));
+    const int c_hi = (d1 << q1) + (d2 << q2) + (d3 << q3) + ((2 * h) << q4) + ((2 * rp) << 8);
+    if (dead != 0) {
+        if (!lane_on) return;  // (after the wave's reads and its DMA: nothing of this lane's cells is an answer)
+        double t0[16];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (dead == 4 && l == 1) break;
+            double s0[4], s1v[4];
+            if (PAR || l == 0 || loop_ts) {
+                const double2 *__restrict__ Tp = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const double2 v = Tp[q]; t0[2 * q] = v.x; t0[2 * q + 1] = v.y; }
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                s0[n] = f[l][0].x * t0[n];
+#pragma unroll
+                for (int x = 1; x < 4; ++x) s0[n] = __builtin_fma(f[l][x].x, t0[n + 4 * x], s0[n]);
+            }
+            if constexpr (PAR) {
+                const double2 *__restrict__ Tq = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts + par_ts));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const double2 v = Tq[q]; t0[2 * q] = v.x; t0[2 * q + 1] = v.y; }
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                s1v[n] = f[l][0].y * t0[n];
+#pragma unroll
+                for (int x = 1; x < 4; ++x) s1v[n] = __builtin_fma(f[l][x].y, t0[n + 4 * x], s1v[n]);
+            }
+            {
+                double *__restrict__ o0 = ot + (c_hi + (l << q4));
+                double *__restrict__ o1 = o0 + (1 << 8);
+                *reinterpret_cast<double2 *>(o0) = make_double2(s0[0], s0[1]);
+                *reinterpret_cast<double2 *>(o0 + 2) = make_double2(s0[2], s0[3]);
+                *reinterpret_cast<double2 *>(o1) = make_double2(s1v[0], s1v[1]);
+                *reinterpret_cast<double2 *>(o1 + 2) = make_double2(s1v[2], s1v[3]);
+            }
+        }
+    } else {
+        // the last stage's own digit dies: T_j[x + 4 ctrl], one value per cell
+        double t0[4];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (PAR || l == 0 || loop_ts) {
+                const double2 *__restrict__ Tp = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const double2 v = Tp[q]; t0[2 * q] = v.x; t0[2 * q + 1] = v.y; }
+            }
+            double s0 = f[l][0].x * t0[0];
+#pragma unroll
+            for (int x = 1; x < 4; ++x) s0 = __builtin_fma(f[l][x].x, t0[x], s0);
+            if constexpr (PAR) {
+                const double2 *__restrict__ Tq = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts + par_ts));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { const double2 v = Tq[q]; t0[2 * q] = v.x; t0[2 * q + 1] = v.y; }
+            }
+            double s1v = f[l][0].y * t0[0];
+#pragma unroll
+            for (int x = 1; x < 4; ++x) s1v = __builtin_fma(f[l][x].y, t0[x], s1v);
+            double *__restrict__ o0 = ot + (c_hi + (l << q4));
+            o0[0] = s0;
+            o0[1 << 8] = s1v;
+        }
+    }
+}
+
 // Readout order.  Piece e (16 bytes = output cells c, c + 1) of a tile's output block: lanes e = trip * 512 + tid.  With the
 // identity map (c = 2 e) a wave's lanes differ in digit values only, whose LDS strides are multiples of 32 cells: all
 // 32 lanes of a ds_read_b64 group on one bank pair (1.6 us per tile).  Instead the five low bits of e are: two bits of the
@@ -554,11 +674,12 @@ __device__ __forceinline__ int sweep_readout_cell(const int e, const int kout) {
 // two runs of 512 consecutive LDS cells (K = 5: run rho = d3 + 4 d4, fa = d3, pair = d4; K = 4: rho = d2 + 4 d3, fa = d3,
 // pair = d2); the DMA fills the same cells per wave, so nothing between the barrier after stage K - 2 and the landing of
 // the next tile needs the other waves.
-template <int K, bool OWN>
+template <int K, bool OWN, bool DEAD = false>
 __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *__restrict__ T, const uint32_t *stw, const int k_rt,
                                                 const int rb_rt, const double *__restrict__ F, double *__restrict__ outp,
                                                 const long Rcells, const int t_begin, const int t_end, const int kout,
-                                                const uint32_t surv, const int tid, const SweepTables &tb) {
+                                                const uint32_t surv, const int tid, const SweepTables &tb, const int dead = -1) {
+    static_assert(!DEAD || (OWN && K == 5), "one dead digit: the wave-owned tail of a five-variable pass");
     constexpr int WG = kSweepWG;
     constexpr int KS = K ? K : 5;
     constexpr int PER = kSweepTileCells / 2 / WG;  // 16-byte pieces per lane and tile
@@ -608,7 +729,8 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
         // this wave's share of the tile has landed.  Wave-owned tail: the DMA was issued BEFORE the eight 16-byte stores of the
         // last stage (sweep_last_stage_out) and the vector-memory operations of a wave retire in order, so "at most eight
         // operations outstanding" means the DMA is done - the wave does not sit out the write acknowledgements of its stores
-        if (OWN && MIBN_SWEEP_VMCNT == 8 && i > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // (DEAD: a wave may have stored less - or nothing - after its DMA: it drains)
+        if (OWN && !DEAD && MIBN_SWEEP_VMCNT == 8 && i > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MIBN_PROF_TICK(1)
         __syncthreads();  // ... and everybody else's (first tile: T is complete)
@@ -641,8 +763,21 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
             if constexpr (K > J) {                                                                                            \
                 constexpr int kRt = 1 << (13 - 2 * (K ? K : 5));                                                               \
                 constexpr int SX = kRt << (2 * G.dig), SL = kRt << (2 * G.loop);                                              \
-                if (cout == 4) sweep_fiber_pairs<4, SX, SL>(L, T, bs, toff, loop_ts, par_ts);                                 \
-                else sweep_fiber_pairs<1, SX, SL>(L, T, bs, toff, loop_ts, par_ts);                                           \
+                /* DEAD: a stage behind the one in which the digit died (its digit is below the dead one) works on garbage     \
+                   wherever the dead digit is not 0 - three quarters of its fibers.  Those lanes (whole waves where the dead    \
+                   digit is a wave-level field; the second loop value where it is the loop digit) sit the stage out */          \
+                bool alive = true;                                                                                            \
+                int nl = 2;                                                                                                   \
+                if constexpr (DEAD) {                                                                                         \
+                    if (MIBN_SWEEP_DEAD_SKIP && G.dig < dead) {                                                               \
+                        if (dead == G.loop) { alive = ((bs >> (rb + 2 * G.loop + 1)) & 1) == 0; nl = 1; }                     \
+                        else alive = ((bs >> (rb + 2 * dead)) & 3) == 0;                                                      \
+                    }                                                                                                         \
+                }                                                                                                             \
+                if (alive) {                                                                                                  \
+                    if (cout == 4) sweep_fiber_pairs<4, SX, SL>(L, T, bs, toff, loop_ts, par_ts, nl);                         \
+                    else sweep_fiber_pairs<1, SX, SL>(L, T, bs, toff, loop_ts, par_ts, nl);                                   \
+                }                                                                                                             \
                 /* (wave-owned tail: stage K - 2 and the last stage give a wave the same cells - sweep_geom - so that hand-over \
                     is wave-local too: two workgroup barriers per tile, after the landing and after stage 1 / K - 3) */        \
                 if constexpr (G.sync_after && !(MIBN_SWEEP_TAIL_LOCAL && OWN && J == K - 2)) __syncthreads();                 \
@@ -678,8 +813,13 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
 #pragma unroll
             for (int c = 0; c < 3; ++c) par = par || (c < nctrl && (cw[c] & 0xff) == 8);
             auto dma_next = [&]() { if (i + 1 < n_tiles) dma_tile(tile + 1); };
-            if (par) sweep_last_stage_out<(K > 0 ? K : 5), true>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dma_next);  // (uniform)
-            else sweep_last_stage_out<(K > 0 ? K : 5), false>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dma_next);
+            if constexpr (DEAD) {
+                if (par) sweep_last_stage_out_dead<true>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dead, dma_next);  // (uniform)
+                else sweep_last_stage_out_dead<false>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dead, dma_next);
+            } else {
+                if (par) sweep_last_stage_out<(K > 0 ? K : 5), true>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dma_next);  // (uniform)
+                else sweep_last_stage_out<(K > 0 ? K : 5), false>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dma_next);
+            }
             MIBN_PROF_TICK(7)
         } else {
             // the tile's output block, two cells (16 bytes) per lane and trip; a trip in which no lane of the wave has a cell is
@@ -731,7 +871,16 @@ __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_dma_kernel(const LevelAr
     const int t_begin = (int)((wg - it.b) * it.a);
     const int t_end = min(tiles, t_begin + (int)it.a);
     const bool canon = (sh_step[1] >> 16) & kFlagSweepCanon;
+    // one digit dies (kout = 4, the others stay in place): which one = the digit missing from the ascending list of survivors
+    int dead = -1;
+    if (MIBN_SWEEP_DEAD_TAIL && canon && k == 5 && kout == 4) {
+        const uint32_t packs[5] = {0x4321u, 0x4320u, 0x4310u, 0x4210u, 0x3210u};
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+            if (surv == packs[d]) dead = d;
+    }
     if (canon && k == 5 && kout == 5 && surv == 0x43210u) sweep_tiles_dma<5, true>(L, T, stw, 5, 3, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    else if (dead >= 0) sweep_tiles_dma<5, true, true>(L, T, stw, 5, 3, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb, dead);
     else if (canon && k == 5) sweep_tiles_dma<5, false>(L, T, stw, 5, 3, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else if (canon && k == 4 && kout == 4 && surv == 0x3210u) sweep_tiles_dma<4, true>(L, T, stw, 4, 5, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else if (canon && k == 4) sweep_tiles_dma<4, false>(L, T, stw, 4, 5, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);

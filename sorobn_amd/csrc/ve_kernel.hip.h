@@ -1022,7 +1022,10 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
 // inside ve_level_kernel it paid for that kernel's resources: 40 KB of LDS and 168 VGPRs per workgroup = three workgroups =
 // twelve chains per CU.  Here a workgroup needs its four waves' descriptor copies and offset tables (12 KB) and the registers
 // of the GENERIC form alone: the wave slots of a CU, not its LDS, bound the chains in flight.
-__global__ __launch_bounds__(kWG, 4) void ve_segment_kernel(const LevelArgs A) {
+#ifndef MIBN_SEG_WAVES
+#define MIBN_SEG_WAVES 4  // waves per SIMD the segment kernel is compiled for (chains in flight per CU = 4 x this)
+#endif
+__global__ __launch_bounds__(kWG, MIBN_SEG_WAVES) void ve_segment_kernel(const LevelArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char sh_seg[kSegPerWg * (kMaxStepWords * 4 + kMaxIn * kTileMax * 4)];
     const uint32_t wg = blockIdx.x + A.wg_base;
     const uint32_t item_idx = (uint32_t)uni((int)A.wg_item[wg]);

@@ -46,19 +46,20 @@ int main(int argc, char **argv) {
     for (int v = 0; v < n; ++v) hint[v] = v;
     net.set_hints(1, hint.data());
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
-    std::vector<int32_t> qv(B), ev(4 * B), ec(4 * B);
+    const int NE = std::getenv("NEV") ? atoi(std::getenv("NEV")) : 4;  // evidence nodes per request (1 / 8 / 16 variants)
+    std::vector<int32_t> qv(B), ev((size_t)NE * B), ec((size_t)NE * B);
     for (int64_t b = 0; b < B; ++b) {
-        int pick[5];
-        for (int k = 0; k < 5;) {
+        int pick[33];
+        for (int k = 0; k < NE + 1;) {
             const int v = (int)(rng() % n);
             bool dup = false;
             for (int j = 0; j < k; ++j) dup = dup || pick[j] == v;
             if (!dup) pick[k++] = v;
         }
         qv[b] = pick[0];
-        for (int k = 0; k < 4; ++k) { ev[4 * b + k] = pick[1 + k]; ec[4 * b + k] = (int)(rng() % K); }
+        for (int k = 0; k < NE; ++k) { ev[NE * b + k] = pick[1 + k]; ec[NE * b + k] = (int)(rng() % K); }
     }
-    for (int64_t b = 0; b <= B; ++b) { q_off[b] = b; e_off[b] = 4 * b; out_off[b] = 4 * b; }
+    for (int64_t b = 0; b <= B; ++b) { q_off[b] = b; e_off[b] = NE * b; out_off[b] = 4 * b; }
     ThreadPool pool(threads);
     std::vector<ProgBuf> bufs;
     BatchPlan bp;

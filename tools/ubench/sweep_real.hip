@@ -22,6 +22,7 @@ using namespace mibn;
 int main(int argc, char **argv) {
     const int nreq = argc > 1 ? atoi(argv[1]) : 2048;
     const int iters = argc > 2 ? atoi(argv[2]) : 8;
+    const int dead = argc > 3 ? atoi(argv[3]) : -1;  // stage whose digit dies (cout = 1): kout = 4, the readout path instead of the wave-owned tail
     const long kCells = 1 << 20;
     const int k = 5, rb = 3, tiles = 128;
     // constants pool: five CPT-like tables of 64 cells [n][x][ctrl]
@@ -39,9 +40,14 @@ int main(int argc, char **argv) {
     w[4] = (uint32_t)kCells;  // output right behind F in the request's arena
     w[5] = 0;
     w[6] = words;
-    w[7] = 5u | (320u << 16);
+    w[7] = dead < 0 ? (5u | (320u << 16)) : (4u | (272u << 16));
     w[8] = 0x43210;
-    w[9] = (uint32_t)((2 * kCells) >> 2);
+    if (dead >= 0) {  // the surviving digits, ascending
+        uint32_t sv = 0; int m = 0;
+        for (int d = 0; d < 5; ++d) if (d != 4 - dead) sv |= (uint32_t)d << (4 * m++);
+        w[8] = sv;
+    }
+    w[9] = (uint32_t)(((dead < 0 ? 2 : 1) * kCells + (dead < 0 ? 0 : kCells / 4)) >> 2);
     uint32_t *p = w.data() + kHdrWords;
     *p++ = 0; *p++ = 0;  // F at arena offset 0
     int t_off = 0;
@@ -52,16 +58,17 @@ int main(int argc, char **argv) {
             if (d != dig && d != loop) f[m++] = d;
         const int nctrl = 1;
         const int src = dig > 0 ? dig - 1 : 8 + 4;  // the lower neighbour; the last stage reads bits 4-5 of r
-        *p++ = (uint32_t)dig | (4u << 4) | (1u << 8) | ((uint32_t)nctrl << 12) | ((uint32_t)loop << 16) | ((uint32_t)f[0] << 20) | ((uint32_t)f[1] << 24) | ((uint32_t)f[2] << 28);
-        *p++ = (uint32_t)t_off | (64u << 16);
-        *p++ = (uint32_t)src | (16u << 8);
+        const uint32_t cout = j == dead ? 1u : 4u;
+        *p++ = (uint32_t)dig | (cout << 4) | (1u << 8) | ((uint32_t)nctrl << 12) | ((uint32_t)loop << 16) | ((uint32_t)f[0] << 20) | ((uint32_t)f[1] << 24) | ((uint32_t)f[2] << 28);
+        *p++ = (uint32_t)t_off | ((16u * cout) << 16);
+        *p++ = (uint32_t)src | ((4u * cout) << 8);
         *p++ = 0; *p++ = 0;
-        t_off += 64;
+        t_off += 16 * (int)cout;
     }
     for (int j = 0; j < k; ++j) {
         const uint64_t off = kConstFlag | (uint64_t)(j * 64);
         *p++ = (uint32_t)(off & 0xffffffffu); *p++ = (uint32_t)(off >> 32);
-        *p++ = 1; *p++ = 4; *p++ = 16; *p++ = 0; *p++ = 0;
+        *p++ = 1; *p++ = 4; *p++ = 16; *p++ = 0; *p++ = 0;  // strides of n, x, ctrl in the 64-cell table (a dying digit reads n = 0)
     }
     prog.insert(prog.end(), w.begin(), w.end());
     const int wgs_per_req = (tiles + iters - 1) / iters;
@@ -107,8 +114,14 @@ int main(int argc, char **argv) {
         for (int rq : {0, nreq / 2, nreq - 1}) {
             CHECK(hipMemcpy(o.data(), d_arena + (size_t)rq * 2 * kCells + kCells, kCells * 8, hipMemcpyDeviceToHost));
             for (int q = 0; q < 48; ++q) {
-                const int r = (q * 131 + rq) % 1024, nc = (q * 577 + 3 * rq) % 1024;
+                const int r = (q * 131 + rq) % 1024;
+                int nc = (q * 577 + 3 * rq) % 1024;
                 int nn[5]; for (int d = 0; d < 5; ++d) nn[d] = (nc >> (2 * d)) & 3;  // value on digit d after the pass
+                if (dead >= 0) {  // the dead digit carries no value: output cell = the surviving digits packed in ascending order
+                    nn[4 - dead] = 0;
+                    nc = 0;
+                    for (int d = 0, m = 0; d < 5; ++d) if (d != 4 - dead) nc |= nn[d] << (2 * m++);
+                }
                 double s = 0;
                 for (int xc = 0; xc < 1024; ++xc) {
                     int xx[5]; for (int d = 0; d < 5; ++d) xx[d] = (xc >> (2 * d)) & 3;
@@ -120,7 +133,7 @@ int main(int argc, char **argv) {
                     }
                     s += pr;
                 }
-                err = fmax(err, fabs(o[(long)r * 1024 + nc] - s) / s);
+                err = fmax(err, fabs(o[(long)r * (dead < 0 ? 1024 : 256) + nc] - s) / s);
             }
         }
 #ifdef SWEEP_PROF
@@ -134,7 +147,7 @@ int main(int argc, char **argv) {
         }
 #endif
         printf("%-26s %d requests x %d tiles, %d tiles per workgroup (%u workgroups): %.3f ms  %.1f GB/s  max rel err %.1e\n", name, nreq, tiles,
-               iters, grid, ms, 2.0 * nreq * kCells * 8 / ms / 1e6, err);
+               iters, grid, ms, (dead < 0 ? 2.0 : 1.25) * nreq * kCells * 8 / ms / 1e6, err);
         fflush(stdout);
     };
     run("ve_sweep_kernel (r2)", ve_sweep_kernel, kSweepWG, kSweepLdsBytes);
