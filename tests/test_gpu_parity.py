@@ -175,6 +175,30 @@ def test_golden_grid10x10(amd):
     _check_requests(bn, entry["requests"], spec["name"])
 
 
+def test_c3_first16_vs_the_reference_answers(amd):
+    """The fixed request set of bench.py's `cpu_baseline` leg - requests 0..15 of the C3 stream - against the answers the unmodified
+    reference gave in the build container (tests/golden/c3_first16.json, make_c3_first16.py: every request ran to the end, the
+    slowest 39 minutes), through query() one by one and through the batched engine call the bench uses: <= 1e-9, labels exact."""
+    import json
+    gold = json.load(open(os.path.join(gu.GOLDEN, "c3_first16.json")))["requests"]
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    q, ev, ec = netspec.c3_requests(100, 4, 16, 4, seed=1)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    batched = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    worst = 0.0
+    for i, g in enumerate(gold):
+        assert g["query"] == int(q[i]) and [e for e, _ in g["evidence"]] == ev[i].tolist() and [c for _, c in g["evidence"]] == ec[i].tolist()
+        want = np.zeros(4)
+        for key, h in zip(g["index"], g["values_hex"]):
+            want[int(key[0])] = float.fromhex(h)
+        ans = bn.query(f"{int(q[i]):03d}", event={f"{int(e):03d}": int(c) for e, c in zip(ev[i], ec[i])})
+        assert ans.index.tolist() == [int(k[0]) for k in g["index"]], i
+        worst = max(worst, float(np.max(np.abs(ans.to_numpy() - want[ans.index.to_numpy()]))), float(np.max(np.abs(batched[i] - want))))
+    assert worst <= gu.TOL, worst
+
+
 def test_c3_fused_vs_single_variable_passes(amd):
     """Size-independent property at the full C3 shapes: eliminating two variables per pass (cx16 / nc16
     kernels, transposed stores) and one variable per pass (cx4 kernels) are different kernels and different
