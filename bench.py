@@ -357,7 +357,8 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong (default, BASELINE config 4): a step = --global-batch requests of the stream whatever N, split into "
                          "contiguous shards over the N ranks; weak: a step = N x --batch requests")
-    ap.add_argument("--global-batch", type=int, default=250_000, help="requests per step with --scaling strong (a quarter of the 1 M-request stream)")
+    ap.add_argument("--global-batch", type=int, default=262_144, help="requests per step with --scaling strong: 2^18, a quarter of a 2^20-request stream - "
+                    "whole 32 768-request engine calls on 1, 2, 4 and 8 ranks (round 4's first sessions used 250 000: a tail call of 20 624 per step)")
     ap.add_argument("--n-evidence", type=int, default=4)
     ap.add_argument("--balance", default="count", choices=["count", "cost"],
                     help="split of a step's global batch over the ranks: equal counts, or equal planner cost estimates")

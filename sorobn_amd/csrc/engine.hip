@@ -1415,7 +1415,11 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 // the share that would have let both finish together (the device's kernels ran beside the chunk in flight, like they will)
                 // The planner's kernels are latency-bound - one request per lane, their duration hardly depends on how many
                 // requests they plan - so the host's share is what its workers plan in that time, at the rate just measured.
-                if (h->emit_share_opt <= 0 && host_ms > 1.0 && dev_ms > 1.0) {
+                // (whole chunks only: the tail of a call - 20 624 requests behind seven chunks of 32 768 in bench.py's 250 000-request
+                //  steps - gives the latency-bound device a smaller fraction than it takes of a full chunk; fed into the average,
+                //  the tails pushed the share below the switch-off threshold of the policy above and the planning of a 4-thread
+                //  rank oscillated between the device and the host alone: 187 k queries/s, profiles/r04_h_threads.log)
+                if (h->emit_share_opt <= 0 && host_ms > 1.0 && dev_ms > 1.0 && 4 * n >= 3 * h->chunk) {
                     const double host_n = (double)(n - nd) / host_ms * dev_ms;
                     h->emit_share = std::max(0.25, std::min(1.0, 0.5 * h->emit_share + 0.5 * (1.0 - host_n / (double)n)));
                 }
