@@ -899,3 +899,36 @@ def test_sweep_form_with_other_cardinalities_around_it():
         oc, ov = on.query_codes([int(oid[qv])], oid[evs].tolist(), codes.tolist())
         assert float(np.max(np.abs(a[oc[:, 0]] - ov))) <= gu.TOL
     assert n_sweeps >= 3, n_sweeps
+
+
+def test_the_gpu_parity_streams_exercise_every_shape_of_the_sweep_tail():
+    """Round 4 gave the sweep kernel a wave-owned tail for five-variable passes in which ONE digit dies (kout = 4,
+    sweep_last_stage_out_dead): the digit of any of the five stages.  The GPU tests that hold that code against the register-staged
+    kernel bit for bit and against the reference run the first requests of the C3 stream - this checks, on the planner's programs,
+    that those requests contain canonical five-variable passes with EACH of the five digits dying, the all-survive form and the
+    shapes that stay on the readout path (two dead digits)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dump_plan as dp
+    f = flatten(netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet))
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
+    q, ev, ec = netspec.c3_requests(100, 4, 300, 4, seed=1)
+    own, dead, two_dead = 0, set(), 0
+    packs = {0x4321: 0, 0x4320: 1, 0x4310: 2, 0x4210: 3, 0x3210: 4}
+    for i in range(300):
+        w = dp.program(f, [to_var[q[i]]], to_var[ev[i]], ec[i])
+        p = 1
+        for s in dp.decode(w):
+            if s["kind"] == "SWEEP" and s["k"] == 5 and (int(w[p + 1]) >> 16) & 16:  # canonical five-variable pass
+                surv = int(w[p + 8])
+                died = [4 - j for j, g in enumerate(s["stages"]) if g["cout"] == 1]
+                if s["kout"] == 5:
+                    assert surv == 0x43210 and not died
+                    own += 1
+                elif s["kout"] == 4:
+                    assert len(died) == 1 and packs[surv] == died[0], (hex(surv), died)  # the survivors stay in place, ascending
+                    dead.add(died[0])
+                elif s["kout"] == 3:
+                    two_dead += 1
+            p += s["words"]
+    assert own > 100 and dead == {0, 1, 2, 3, 4} and two_dead > 0, (own, dead, two_dead)
