@@ -353,7 +353,11 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=["c3", "c5"])
-    ap.add_argument("--batch", type=int, default=32768, help="requests per engine call (mibn_submit_batch); with --scaling weak also the requests per step and GPU")
+    ap.add_argument("--batch", type=int, default=0, help="requests per engine call (mibn_submit_batch) = per chunk of the engine; 0 (default): a rank's shard of a step in "
+                    "ceil(shard / --call-cap) equal calls (N = 1: 5 x 52 429, N = 2: 3 x 43 691, N = 4: 2 x 32 768, N = 8: 1 x 32 768); with --scaling weak "
+                    "also the requests per step and GPU (then 32 768 unless given)")
+    ap.add_argument("--call-cap", type=int, default=52_429, help="most requests of an engine call when --batch is 0: a C3 chunk of this size needs 224 GB of "
+                    "arena, inside the engine's budget of 0.8 x the free HBM (profiles/r04_m_chunk.log: +1.5 % queries/s over 32 768)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong (default, BASELINE config 4): a step = --global-batch requests of the stream whatever N, split into "
                          "contiguous shards over the N ranks; weak: a step = N x --batch requests")
@@ -384,6 +388,12 @@ def main():
         if world == 1 and a.gpus > 1 and not os.environ.get("MIBN_BENCH_CHILD"):
             sys.exit(spawn_ranks(a.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher
         a.gpus = world
+    if a.batch <= 0:
+        if a.scaling == "strong":
+            shard = -(-a.global_batch // world)
+            a.batch = -(-shard // max(1, -(-shard // max(1024, a.call_cap))))
+        else:
+            a.batch = 32768
 
     # Transport of the final gather: "rccl" (default) = mibn_comm_* of the C-ABI, RCCL over xGMI, no PyTorch.
     # MIBN_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 path run on a box with fewer GPUs than ranks (ranks then
@@ -422,6 +432,9 @@ def main():
         # planning effort follows the host: with few cores per GPU (8 ranks on a small CPU quota) the min-fill search
         # is reserved for the expensive requests; never triggers while planning hides under the kernels (N = 1 here)
         eng.set_option("adaptive", 1)
+    if a.batch > 32768:  # one chunk per engine call: the chunk size and the arena budget follow the call size (the engine caps the budget at 0.8 x free HBM)
+        eng.set_option("chunk", a.batch)
+        eng.set_option("arena_gb", 250)
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, float(v))
@@ -674,7 +687,8 @@ def main():
                 for kv in a.opt:
                     k, v = kv.split("=")
                     eng2.set_option(k, float(v))
-                out["configs"]["C3_two_planner_threads"] = c3_variant(eng2, to_var, a.n_evidence, calls=8, warmup_calls=3, batch=a.batch)
+                # (calls of 32 768: such a rank's shard of a 2^18-request step on eight GPUs)
+                out["configs"]["C3_two_planner_threads"] = c3_variant(eng2, to_var, a.n_evidence, calls=8, warmup_calls=3, batch=32768)
                 eng2.close()
             except Exception as e:  # noqa: BLE001
                 out["configs"]["C3_two_planner_threads"] = {"error": repr(e)}

@@ -577,6 +577,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     }
     else if (n == "order_weights") h->net.order_weights = std::max(0, std::min(64, (int)value));  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
+    else if (n == "sweep_taper") h->net.sweep_taper = std::max(0, (int)value);  // tiles at the end of a level's sweep launch that go out two per workgroup
     else if (n == "sweep_adapt") h->net.sweep_adapt = std::max(0, (int)value);  // fewer tiles per workgroup in sweep launches below this many workgroups
     else if (n == "sweep_min") h->net.sweep_min = std::max(2, std::min(5, (int)value));  // fewest variables of a SWEEP pass
     else if (n == "sweep_iters") h->net.sweep_iters = std::max(1, std::min(kTileMax, (int)value));  // tiles per workgroup of the sweep kernel
@@ -1472,11 +1473,17 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         if ((rc = upload(h, st.stage[0], st.d_prog_off, ck.prog_off.data(), (size_t)n * 8))) return rc;
         h->stats.h2d_ms += now_ms() - t0;
         // waves: consecutive requests whose private arenas fit the scratch budget together
+        // (a chunk that does not fit is cut into waves of about EQUAL scratch - ceil(total / budget) of them - not into full
+        //  waves and a remainder: round 4 runs chunks of 52 429 requests = 224 GB, close to the budget)
+        int64_t chunk_cells = 0;
+        for (int64_t r = 0; r < n; ++r) chunk_cells += (ck.arena_need[r] + 15) & ~int64_t(15);
+        const int64_t n_waves_min = std::max<int64_t>(1, (chunk_cells + budget_cells - 1) / std::max<int64_t>(1, budget_cells));
+        const int64_t wave_target = std::min(budget_cells, chunk_cells / n_waves_min + (chunk_cells / n_waves_min) / 64 + 1);
         for (int64_t r0 = 0; r0 < n;) {
             int64_t r1 = r0, cells = 0;
             while (r1 < n) {
                 const int64_t need = (ck.arena_need[r1] + 15) & ~int64_t(15);
-                if (r1 > r0 && cells + need > budget_cells) break;
+                if (r1 > r0 && (cells + need > budget_cells || (n_waves_min > 1 && cells >= wave_target))) break;
                 cells += need;
                 ++r1;
             }

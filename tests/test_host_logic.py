@@ -910,6 +910,9 @@ def test_the_gpu_parity_streams_exercise_every_shape_of_the_sweep_tail():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import dump_plan as dp
+    L = simengine.lib()  # (the simulator's planner options are process-wide: the product's defaults, whatever an earlier test left)
+    L.plan_sim_set_small_cells(1024); L.plan_sim_set_tiling(4096, 0); L.plan_sim_set_fuse(1); L.plan_sim_set_chain(1)
+    L.plan_sim_set_sweep(5); L.plan_sim_set_sweep_min(2); L.plan_sim_set_prune(1)
     f = flatten(netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet))
     to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
     q, ev, ec = netspec.c3_requests(100, 4, 300, 4, seed=1)
