@@ -577,7 +577,6 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     }
     else if (n == "order_weights") h->net.order_weights = std::max(0, std::min(64, (int)value));  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
-    else if (n == "sweep_taper") h->net.sweep_taper = std::max(0, (int)value);  // tiles at the end of a level's sweep launch that go out two per workgroup
     else if (n == "sweep_adapt") h->net.sweep_adapt = std::max(0, (int)value);  // fewer tiles per workgroup in sweep launches below this many workgroups
     else if (n == "sweep_min") h->net.sweep_min = std::max(2, std::min(5, (int)value));  // fewest variables of a SWEEP pass
     else if (n == "sweep_iters") h->net.sweep_iters = std::max(1, std::min(kTileMax, (int)value));  // tiles per workgroup of the sweep kernel

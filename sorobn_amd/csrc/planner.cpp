@@ -798,7 +798,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_min); mix((uint64_t)net.sweep_adapt); mix((uint64_t)net.sweep_taper); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_min); mix((uint64_t)net.sweep_adapt); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }
@@ -1083,26 +1083,13 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
     if (net.sweep_adapt)
         for (int l = 0; l < n_levels; ++l)
             while (sweep_iters[(size_t)l] > 2 && sweep_tiles[(size_t)l] / sweep_iters[(size_t)l] < (uint64_t)net.sweep_adapt) sweep_iters[(size_t)l] /= 2;
-    // Tapered tail (net.sweep_taper tiles): the items whose tiles come last in a level's launch (items are dispatched in request
-    // order) take 2 tiles per workgroup instead of sweep_iters - a workgroup of the final round then lives ~ 27 us instead of ~ 108.
-    std::vector<uint64_t> sweep_seen((size_t)n_levels, 0);
-    auto iters_of = [&](int level, uint32_t tiles) {
-        uint32_t it = sweep_iters[(size_t)level];
-        uint64_t &seen = sweep_seen[(size_t)level];
-        if (net.sweep_taper > 0 && it > 2 && seen + tiles + (uint64_t)net.sweep_taper > sweep_tiles[(size_t)level] &&
-            sweep_tiles[(size_t)level] > 4 * (uint64_t)net.sweep_taper)
-            it = 2;
-        seen += tiles;
-        return it;
-    };
     for (int64_t i = 0; i < n; ++i) {
         const int64_t r = r0 + i;
         const Tag *tg = bp.tags[bp.thread_of[r]].data() + bp.tag_first[r];
         const int sh = shift(i);
         for (uint32_t k = 0; k < bp.tag_count[r]; ++k)
-            if (tg[k].kid == kKidSweep) { const uint32_t it = iters_of(tg[k].level + sh, tg[k].a); n_wg += (tg[k].a + it - 1) / it; }
+            if (tg[k].kid == kKidSweep) { const uint32_t it = sweep_iters[(size_t)(tg[k].level + sh)]; n_wg += (tg[k].a + it - 1) / it; }
     }
-    std::fill(sweep_seen.begin(), sweep_seen.end(), 0);  // (the scatter pass below walks the items in the same order)
     for (size_t k = 0; k < nb; ++k) count[k + 1] += count[k];
     // pass 2: scatter (Item::b = workgroups of the item for now)
     out.items.resize(n_tags);
@@ -1113,7 +1100,7 @@ void build_schedule(const Network &net, const BatchPlan &bp, const std::vector<P
         const int sh = shift(i);
         for (uint32_t k = 0; k < bp.tag_count[r]; ++k) {
             uint32_t a = tg[k].a, wgs = tg[k].wgs;
-            if (tg[k].kid == kKidSweep) { const uint32_t it = iters_of(tg[k].level + sh, a); wgs = (a + it - 1) / it; a = it; }
+            if (tg[k].kid == kKidSweep) { const uint32_t it = sweep_iters[(size_t)(tg[k].level + sh)]; wgs = (a + it - 1) / it; a = it; }
             out.items[cur[(size_t)(tg[k].level + sh) * kNumKernels + kClassOrder.rank_of[tg[k].kid]]++] = Item{(uint32_t)i, tg[k].rel_off, a, wgs};
         }
     }

@@ -62,8 +62,6 @@ struct Network {
     int sweep_min = 2;       // fewest variables of a SWEEP pass: 2 also takes the PAIR steps of one big table (two stages: a pass bound by
                              // HBM rather than by the LDS) away from the level kernel's MFMA pair class
     int sweep_iters = kSweepItersDefault;  // tiles per workgroup of the sweep kernel
-    int sweep_taper = 0;     // build_schedule: the last this-many TILES of a level's sweep launch go out two per workgroup (their workgroups
-                             // live a quarter as long: the launch's tail - half a workgroup lifetime of a draining chip per level - shrinks)
     int sweep_adapt = 4096;  // build_schedule: fewer tiles per workgroup (down to 2) in sweep launches of fewer workgroups than this (0: off)
     int builtin_sweeps = 1;  // two depth-first topological orders (grid: row- and column-major) as candidate orders next to the host's
                              // hints: -2 % bytes on C3.  Off in round 2 (no measurable time then); with round 3's kernels the bytes
