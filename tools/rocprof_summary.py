@@ -39,7 +39,15 @@ def level_groups(db):
     comps.append((cs, ce))
     tot = sum(e - s for s, e in comps) / 1e6
     single = sum(e - s for s, e in iv) / 1e6
-    return [f"levels (connected components of the VE kernels' intervals = ve_level_kernel||ve_sweep_dma_kernel[||ve_segment_kernel]): {len(comps)} "
+    # the idle time between consecutive levels (no VE kernel running): gaps of less than 0.5 ms are level boundaries inside a chunk
+    # or between the chunks of a pipelined stream - longer ones are the ends of calls / steps
+    gaps = sorted((comps[i + 1][0] - comps[i][1]) / 1e3 for i in range(len(comps) - 1))
+    short = [g for g in gaps if g < 500.0]
+    extra = []
+    if short:
+        extra = [f"idle gaps between consecutive levels (< 0.5 ms: {len(short)} of {len(gaps)}): total {sum(short) / 1e3:.3f} ms = {100 * sum(short) / 1e3 / tot:.2f} % of the "
+                 f"VE busy time, median {short[len(short) // 2]:.1f} us, mean {sum(short) / len(short):.1f} us, 90th percentile {short[int(0.9 * len(short))]:.1f} us"]
+    return extra + [f"levels (connected components of the VE kernels' intervals = ve_level_kernel||ve_sweep_dma_kernel[||ve_segment_kernel]): {len(comps)} "
             f"groups, total {tot:.3f} ms = GPU busy time of the VE kernels, avg {tot / len(comps):.3f} ms per level; the sum of the individual "
             f"kernel durations is {single:.3f} ms ({single / tot:.2f} x: concurrent launches share the chip)"]
 
