@@ -705,7 +705,16 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
     const long g_step = (long)(WG >> (rb - 1)) * Rcells;
     const uint32_t lds_l = lds_byte_addr(L);
     auto dma_tile = [&](const int tile) {
-        const double *__restrict__ Ft = F + (long)tile * Rt + g_tid;
+        long g_lane = g_tid;
+        if constexpr (!OWN) {
+            // (the readout paths are at their register budget: the lane's part of the address, kept across the tile loop, was the
+            //  kernel's only spill - and its reload, with the s_waitcnt vmcnt(0) the compiler puts behind it, sat in front of every
+            //  tile's DMA.  Re-derived per tile from an opaque copy of the lane id instead: a handful of integer operations)
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            g_lane = (long)(t2 >> (rb - 1)) * Rcells + 2 * (t2 & ((Rt >> 1) - 1));
+        }
+        const double *__restrict__ Ft = F + (long)tile * Rt + g_lane;
         if constexpr (OWN) {
             const uint32_t lb = (uint32_t)uni((int)(lds_l + 8u * 512u * (uint32_t)own_rho0));
 #pragma unroll
