@@ -1020,6 +1020,15 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
 
 // Waits for the device planner and fills `ck` for the n requests it planned, like plan_batch would (one "worker": the device).
 // *dev_ms = duration of the kernels.  Returns MIBN_OK, an error, or 1 (see above).
+#ifndef MIBN_EMIT_OFF_SHARE
+#define MIBN_EMIT_OFF_SHARE 0.2  // adaptive policy: the device's share of a chunk at or below which the device planner is switched off again.  Round 4:
+                                 // 0.3 -> 0.2, below the share controller's floor of 0.25 - a rank that was host-bound keeps the device planner.  At
+                                 // 0.3 a 6-thread rank (share ~ 0.33) oscillated between the mix and the host alone: 219 k queries/s against 251 k
+                                 // (profiles/r04_s_policy.log, r04_t_policy.log); at 8 threads the mix and the host alone are level (255 / 251 k)
+#endif
+#ifndef MIBN_HOST_BOUND_RATIO
+#define MIBN_HOST_BOUND_RATIO 1.15  // adaptive policy: planner wall time over GPU kernel time above which a stream of calls counts as host-bound
+#endif
 int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, double *dev_ms) {
     hipStream_t P = h->search_stream;
     const size_t stride = h->emit_words;
@@ -1234,18 +1243,18 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             h->seen_plan_ms = h->total.plan_ms;
             h->seen_kernel_ms = h->total.kernel_ms;
         } else if (dp > 20.0 && dk > 20.0) {
-            if (h->auto_emit && h->emit_share <= 0.3) {
+            if (h->auto_emit && h->emit_share <= MIBN_EMIT_OFF_SHARE) {
                 // (the share follows the host's rate: its workers would plan most of a chunk in the planner kernels' time)
                 h->gpu_emit = 0;
                 h->auto_emit = false;
-            } else if (dp > 1.15 * dk && ++h->host_bound_streak >= 2) {  // (twice in a row: the kernel time of a call is booked when its
+            } else if (dp > MIBN_HOST_BOUND_RATIO * dk && ++h->host_bound_streak >= 2) {  // (twice in a row: the kernel time of a call is booked when its
                                                                           // launches retire, up to two calls late - one window can mislead)
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
                 // not cover give up the min-fill search for ever more expensive requests instead
                 if (h->order_net_ok && h->emit_net_ok && !h->gpu_emit) { h->gpu_emit = 1; h->auto_emit = true; }  // the whole planning, not only the search
                 else if (h->order_net_ok && !h->emit_net_ok && !h->gpu_search) { h->gpu_search = 1; h->auto_search = true; }
                 else if (!h->order_net_ok) h->net.minfill_above = std::min(h->net.minfill_above * 8.0, 1e18);
-            } else if (dp <= 1.15 * dk) {
+            } else if (dp <= MIBN_HOST_BOUND_RATIO * dk) {
                 h->host_bound_streak = 0;
             }
             if (dp < 0.3 * dk) {
