@@ -357,7 +357,7 @@ def main():
                     "ceil(shard / --call-cap) equal calls (N = 1: 5 x 52 429, N = 2: 3 x 43 691, N = 4: 2 x 32 768, N = 8: 1 x 32 768); with --scaling weak "
                     "also the requests per step and GPU (then 32 768 unless given)")
     ap.add_argument("--call-cap", type=int, default=52_429, help="most requests of an engine call when --batch is 0: a C3 chunk of this size needs 224 GB of "
-                    "arena, inside the engine's budget of 0.8 x the free HBM (profiles/r04_m_chunk.log: +1.5 % queries/s over 32 768)")
+                    "arena, inside the engine's budget of 0.8 x the free HBM (profiles/r04_m_chunk.log: +1.5 %% queries/s over 32 768)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong (default, BASELINE config 4): a step = --global-batch requests of the stream whatever N, split into "
                          "contiguous shards over the N ranks; weak: a step = N x --batch requests")
@@ -589,9 +589,11 @@ def main():
                                                 "ms_per_launch": d["ms"] / la, "launches": la, "traffic": None, "traffic_over_alg": pmc_ratio(n)[0],
                                                 "share_of_kernel_time": d["ms"] / agg["kernel_ms"]}
         if "||" in dom:
-            out["roofline"]["note"] = ("option overlap (default): the launches of a level - one of ve_level_kernel, one of ve_sweep_dma_kernel, items of different "
-                                       "requests - run CONCURRENTLY on two streams; the unit whose duration means anything is the pair (from the earlier start to the "
-                                       "later end, HIP events): `kernel` names it, `launches` = levels.  The two kernels' own event durations (per_kernel) then include "
+            out["roofline"]["note"] = ("option overlap (default): the launches of a level - one of ve_level_kernel, one of ve_sweep_dma_kernel, one of "
+                                       "ve_segment_kernel, items of different requests - run CONCURRENTLY on three streams; the unit whose duration means anything "
+                                       "is the level (from the earliest start to the latest end of its launches, HIP events): `kernel` names it, `launches` = levels; "
+                                       "rocprofv3's kernel trace gives the same unit as the connected components of the kernels' intervals "
+                                       "(tools/rocprof_summary.py, profiles/r04_o_rocprofv3_summary.txt).  The kernels' own event durations (per_kernel) then include "
                                        "each other's share of the chip; per_kernel_serialised = the same kernels right after the timed region with the launches "
                                        "serialised (overlap=0), for comparison with earlier rounds.")
         if world == 1 and not a.no_configs and "||" in dom:
