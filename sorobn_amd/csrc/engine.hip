@@ -250,6 +250,8 @@ struct mibn_ctx {
     int host_bound_streak = 0;
     bool adaptive_seeded = false;
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
+    double retired_requests = 0, seen_requests = 0;  // requests whose kernel time has been booked (the unit of kernel_ms in the policy's windows)
+    double host_rate = 0;                            // requests per ms the host's workers planned beside the device planner (smoothed; 0: not measured)
     // device order search (order_kernel)
     int plan_lanes = 32;             // requests per wave of order_kernel / emit_kernel (1..64)
     int plan_waves = 16;             // waves per workgroup of the two (1..16): see order_kernel
@@ -752,6 +754,7 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         if (t.kid != -2) HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[t.e0], st.ev[t.e1]));  // (-2: a level's launch group - any of its event pairs may be absent)
         const bool mine = t.call == h->call_id;  // (launches of an earlier asynchronous call only count in the totals)
         if (t.kid == -1) {
+            h->retired_requests += t.items;  // (the wave's requests)
             // GPU time of a wave, first launch to last.  With two lanes the waves of consecutive chunks overlap: what is
             // booked as kernel_ms is the time the GPU was busy (the union of the intervals, kept as a high-water mark
             // since the epoch event; sets retire in launch order)
@@ -1020,11 +1023,8 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
 
 // Waits for the device planner and fills `ck` for the n requests it planned, like plan_batch would (one "worker": the device).
 // *dev_ms = duration of the kernels.  Returns MIBN_OK, an error, or 1 (see above).
-#ifndef MIBN_EMIT_OFF_SHARE
-#define MIBN_EMIT_OFF_SHARE 0.2  // adaptive policy: the device's share of a chunk at or below which the device planner is switched off again.  Round 4:
-                                 // 0.3 -> 0.2, below the share controller's floor of 0.25 - a rank that was host-bound keeps the device planner.  At
-                                 // 0.3 a 6-thread rank (share ~ 0.33) oscillated between the mix and the host alone: 219 k queries/s against 251 k
-                                 // (profiles/r04_s_policy.log, r04_t_policy.log); at 8 threads the mix and the host alone are level (255 / 251 k)
+#ifndef MIBN_HOST_KEEPS_UP
+#define MIBN_HOST_KEEPS_UP 1.25  // adaptive policy: (requests the host plans per ms) x (kernel ms per request) at or above which the device planner is dropped
 #endif
 #ifndef MIBN_HOST_BOUND_RATIO
 #define MIBN_HOST_BOUND_RATIO 1.15  // adaptive policy: planner wall time over GPU kernel time above which a stream of calls counts as host-bound
@@ -1242,11 +1242,19 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
         if (h->call_id <= 2) {  // the first calls pay one-time costs (thread pool, pinned buffers, first kernel load): not a trend
             h->seen_plan_ms = h->total.plan_ms;
             h->seen_kernel_ms = h->total.kernel_ms;
+            h->seen_requests = h->retired_requests;
         } else if (dp > 20.0 && dk > 20.0) {
-            if (h->auto_emit && h->emit_share <= MIBN_EMIT_OFF_SHARE) {
-                // (the share follows the host's rate: its workers would plan most of a chunk in the planner kernels' time)
+            const double dreq = h->retired_requests - h->seen_requests;
+            // The device planner goes again where the host ALONE would keep up: the requests its workers plan per ms (measured
+            // beside the device planner) x the kernel time per request must cover a request with a margin - the margin also
+            // absorbs that the kernels of device-planned chunks run ~ 17 % longer than they would without the planner's kernels.
+            // (Up to session S the rule was "the device's share has fallen to 0.3": a 6-thread rank - share 0.33 - oscillated
+            // around it, 219 k queries/s; a fixed lower bar, 0.2, kept the device planner on a full-quota rank that had
+            // switched it on during its first calls: 278 k instead of 300 k.  profiles/r04_s_policy.log, r04_t_policy.log)
+            if (h->auto_emit && h->host_rate > 0 && dreq > 0 && h->host_rate * (dk / dreq) >= MIBN_HOST_KEEPS_UP) {
                 h->gpu_emit = 0;
                 h->auto_emit = false;
+                h->host_bound_streak = 0;
             } else if (dp > MIBN_HOST_BOUND_RATIO * dk && ++h->host_bound_streak >= 2) {  // (twice in a row: the kernel time of a call is booked when its
                                                                           // launches retire, up to two calls late - one window can mislead)
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
@@ -1263,6 +1271,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
             }
             h->seen_plan_ms = h->total.plan_ms;
             h->seen_kernel_ms = h->total.kernel_ms;
+            h->seen_requests = h->retired_requests;
         }
     }
     int rc;
@@ -1428,6 +1437,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 //  steps - gives the latency-bound device a smaller fraction than it takes of a full chunk; fed into the average,
                 //  the tails pushed the share below the switch-off threshold of the policy above and the planning of a 4-thread
                 //  rank oscillated between the device and the host alone: 187 k queries/s, profiles/r04_h_threads.log)
+                if (host_ms > 1.0) h->host_rate = h->host_rate > 0 ? 0.5 * h->host_rate + 0.5 * (double)(n - nd) / host_ms : (double)(n - nd) / host_ms;
                 if (h->emit_share_opt <= 0 && host_ms > 1.0 && dev_ms > 1.0 && 4 * n >= 3 * h->chunk) {
                     const double host_n = (double)(n - nd) / host_ms * dev_ms;
                     h->emit_share = std::max(0.25, std::min(1.0, 0.5 * h->emit_share + 0.5 * (1.0 - host_n / (double)n)));
@@ -1609,7 +1619,7 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
                 }
                 size_t e_last = 0;
                 if ((rc = next_event(h, st, e_last, S))) return rc;
-                st.timed.push_back({-1, e_first, e_last, 0.0, 0.0, h->call_id});
+                st.timed.push_back({-1, e_first, e_last, 0.0, (double)(r1 - r0), h->call_id});
             }
             HIP_TRY(h, hipGetLastError());
             if (h->trace) {
