@@ -367,6 +367,7 @@ static int upload_order_net(mibn_ctx *h) {
     const size_t o_asc = put(net.topo_asc.data(), n * 4), o_desc = put(net.topo_desc.data(), n * 4);
     const size_t o_hint = put(net.hint_flat.data(), nh * n * 4), o_log = put(net.log2card.data(), n * 8);
     const size_t o_anc = put(net.anc2.data(), n * sizeof(B2)), o_sc = put(net.scope2.data(), n * sizeof(B2));
+    const size_t o_fam = put(net.fam2.data(), n * sizeof(B2));
     if (h->d_order_net) { HIP_TRY(h, hipFree(h->d_order_net)); h->d_order_net = nullptr; }
     HIP_TRY(h, hipMalloc(&h->d_order_net, buf.size()));
     HIP_TRY(h, hipMemcpy(h->d_order_net, buf.data(), buf.size(), hipMemcpyHostToDevice));
@@ -381,6 +382,7 @@ static int upload_order_net(mibn_ctx *h) {
     o.log2card = reinterpret_cast<const double *>(d + o_log);
     o.anc = reinterpret_cast<const B2 *>(d + o_anc);
     o.cpt_scope = reinterpret_cast<const B2 *>(d + o_sc);
+    o.fam = reinterpret_cast<const B2 *>(d + o_fam);
     h->order_net_ok = true;
     return MIBN_OK;
 }

@@ -44,9 +44,13 @@ struct OrderNet {
     const int32_t *depth = nullptr;      // [n] longest path from a root
     const B2 *anc = nullptr;             // [n] ancestors
     const B2 *cpt_scope = nullptr;       // [n] scope of variable v's CPT ([*parents, v])
+    const B2 *fam = nullptr;             // [n] the CPTs that mention v: v itself and its children
     const int32_t *topo_asc = nullptr;   // [n] all variables by (depth ascending, id)
     const int32_t *topo_desc = nullptr;  // [n] all variables by (depth descending, id)
     const int32_t *hint_sorted = nullptr;  // [n_hints][n] every hint as a variable list in ascending (priority, id) order
+    B2 multi;                            // the variables with more than one state (the others are never axes)
+    int32_t uniform_log2 = -1;           // l >= 0: every multi-state variable has 2^l states - cell counts are 2^(l x axes) and
+                                         // sums of log2card are l x axes, exactly what the loops over the axes compute
     int32_t prune = 1;
     double minfill_above = 2e7;
     // Weight of an elimination that consumes exactly ONE big table (> big_cells cells) in the byte model below.  Such steps
@@ -57,27 +61,40 @@ struct OrderNet {
     double chain_weight = 1.0, big_cells = 1024.0;
 };
 
-constexpr int kOrderSlotWords = 5, kOrderSlots = 64 * kOrderSlotWords;  // factor slots of the byte model: <= 128 CPTs + 128 created + 1
+// factor slots of the byte model: slot v < 128 = the evidence-sliced CPT of variable v, slot 128 + o = the factor the o-th
+// elimination creates
+constexpr int kOrderSlotWords = 4, kOrderSlots = 64 * kOrderSlotWords;
 
 struct OrderScratch {
-    // factor scopes of the request (evidence axes removed) and their cells
-    B2 f0[128];
-    double f0c[128];
-    int32_t n_f0;
-    // byte model
+    // the request: relevant variables, and per relevant variable v the scope of its CPT without the evidence axes (f[v]) and
+    // its cells (fc[v]); behind them the factors the byte model creates
+    B2 rel;
     B2 f[kOrderSlots];
     double fc[kOrderSlots];
     uint64_t mem[128][kOrderSlotWords];
     // min-fill
     B2 adj[128];
-    double ws[128];
+    double ws[128], score[128];
     int32_t miss[128];
     // candidates
     uint8_t cand[128], best[128];
     int32_t n_cand, n_best;
 };
 
+MIBN_HD inline double order_pow2(int e) {  // 2^e, e >= 0
+    if (e > 1023) return __builtin_inf();
+    const uint64_t bits = (uint64_t)(1023 + e) << 52;
+    double d;
+    __builtin_memcpy(&d, &bits, 8);
+    return d;
+}
+
 MIBN_HD inline double order_exp2(double x) {
+    // (integers - every network of two- / four- / eight-state variables - without the library call: exp2 is exact there)
+    if (x >= 0 && x < 1024) {
+        const int e = (int)x;
+        if ((double)e == x) return order_pow2(e);
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     return ::exp2(x);
 #else
@@ -85,29 +102,40 @@ MIBN_HD inline double order_exp2(double x) {
 #endif
 }
 
+MIBN_HD inline int b2_count(const B2 &s) { return __builtin_popcountll(s.a) + __builtin_popcountll(s.b); }
+
 MIBN_HD inline double order_cells(const OrderNet &net, const B2 &u) {
+    if (net.uniform_log2 >= 0) return order_pow2(net.uniform_log2 * b2_count(u));
     double c = 1;
     b2_each(u, [&](int v) { c *= net.card[v]; });
     return c;
 }
 
-// SURVEY section 8(d) byte model of eliminating `order` from the factors S.f0: every variable keeps the set of factor
-// slots whose scope contains it, so an elimination touches only the factors it consumes.
+// sum of log2card over a set, in ascending order of the variables
+MIBN_HD inline double order_log2sum(const OrderNet &net, const B2 &u) {
+    if (net.uniform_log2 >= 0) return (double)(net.uniform_log2 * b2_count(u));
+    double w = 0;
+    b2_each(u, [&](int y) { w += net.log2card[y]; });
+    return w;
+}
+
+// SURVEY section 8(d) byte model of eliminating `order` from the request's factors (order_prepare): every variable keeps the
+// set of factor slots whose scope contains it, so an elimination touches only the factors it consumes.  The slots of the
+// request's own factors are the variable ids, so a variable's initial set is a property of the network (OrderNet::fam)
+// restricted to the relevant set - nothing is built per candidate order.
 MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const uint8_t *order, int n_order, double abort_above) {
-    const int nv = net.n_vars;
-    int nf = S.n_f0;
-    // slot words in use: the request's factors + one per elimination (the rest of a row is neither written nor read)
-    const int kw = (nf + n_order + 64) / 64 < kOrderSlotWords ? (nf + n_order + 64) / 64 : kOrderSlotWords;
-    for (int v = 0; v < nv; ++v)
-        for (int k = 0; k < kw; ++k) S.mem[v][k] = 0;
+    const int kw = 2 + (n_order + 63) / 64;  // slot words in use: the request's factors + one slot per elimination
+    const B2 rel = S.rel;
+    b2_each(rel, [&](int v) {
+        S.mem[v][0] = net.fam[v].a & rel.a;
+        S.mem[v][1] = net.fam[v].b & rel.b;
+        for (int k = 2; k < kw; ++k) S.mem[v][k] = 0;
+    });
     uint64_t alive[kOrderSlotWords];
-    for (int k = 0; k < kOrderSlotWords; ++k) alive[k] = 0;
-    for (int i = 0; i < nf; ++i) {
-        S.f[i] = S.f0[i];
-        S.fc[i] = S.f0c[i];
-        alive[i >> 6] |= 1ull << (i & 63);
-        b2_each(S.f[i], [&](int v) { S.mem[v][i >> 6] |= 1ull << (i & 63); });
-    }
+    alive[0] = rel.a;
+    alive[1] = rel.b;
+    for (int k = 2; k < kOrderSlotWords; ++k) alive[k] = 0;
+    int nf = 128;
     double bytes = 0;
     for (int o = 0; o < n_order; ++o) {
         const int x = order[o];
@@ -149,37 +177,33 @@ MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const
 
 // Greedy min-fill elimination order on the interaction graph: eliminate the vertex whose elimination adds the fewest
 // edges, ties by the size of the factor it creates, then by depth and id.  The fill counts are maintained
-// incrementally: eliminating a vertex changes the neighbourhood of its neighbours (recomputed) and connects pairs of
-// them - every common neighbour of a newly connected pair loses that pair from its fill count.
+// incrementally: eliminating a vertex makes a clique of its neighbours - their counts are recomputed, from the neighbours
+// they have OUTSIDE that clique only (a pair inside it is connected by construction) - and every common neighbour of a
+// newly connected pair loses that pair from its count.
 // `abort_above`: every factor an elimination creates is written once and read once later, so 16 bytes x the cells
 // created so far is a lower bound of the order's section-8(d) cost - once it passes the best sweep the search stops
 // (returns false: the order cannot win).  The order goes to S.cand.
 MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 &hidden, double abort_above) {
-    const int n = net.n_vars;
     B2 *adj = S.adj;
-    for (int v = 0; v < n; ++v) adj[v] = B2{};
-    for (int i = 0; i < S.n_f0; ++i) {
-        const B2 sc = S.f0[i];
+    const B2 rel = S.rel;
+    b2_each(rel, [&](int v) { adj[v] = B2{}; S.miss[v] = 0; S.ws[v] = 0; S.score[v] = 0; });
+    b2_each(rel, [&](int i) {
+        const B2 sc = S.f[i];
         b2_each(sc, [&](int v) { adj[v].a |= sc.a; adj[v].b |= sc.b; });
-    }
-    for (int v = 0; v < n; ++v) adj[v].clr(v);
-    double *ws = S.ws;
+    });
+    b2_each(rel, [&](int v) { adj[v].clr(v); });
+    double *ws = S.ws, *score = S.score;
     int32_t *miss = S.miss;
-    B2 alive = hidden;  // the vertices not yet eliminated - a register pair, scanned in ascending order (the order of the list the
-                        // first version kept in memory: two loads fewer per candidate, the same winner)
-    int n_alive = __builtin_popcountll(hidden.a) + __builtin_popcountll(hidden.b);
-    auto full = [&](int x) {
+    B2 alive = hidden;  // the vertices not yet eliminated - a register pair, scanned in ascending order
+    int n_alive = b2_count(hidden);
+    b2_each(alive, [&](int x) {
         const B2 ax = adj[x];
-        double w = 0;
-        int missing = 0;
-        b2_each(ax, [&](int y) {
-            w += net.log2card[y];
-            missing += __builtin_popcountll(ax.a & ~adj[y].a) + __builtin_popcountll(ax.b & ~adj[y].b) - 1;
-        });
-        ws[x] = w;
+        int missing = 0;  // (ordered) pairs of neighbours that are not adjacent
+        b2_each(ax, [&](int y) { missing += __builtin_popcountll(ax.a & ~adj[y].a) + __builtin_popcountll(ax.b & ~adj[y].b) - 1; });
+        ws[x] = order_log2sum(net, ax);
         miss[x] = missing;
-    };
-    b2_each(alive, [&](int x) { full(x); });
+        score[x] = missing * 64.0 + ws[x];
+    });
     S.n_cand = 0;
     const int total = n_alive;
     double created = 0;
@@ -187,7 +211,7 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
         int best = -1, dbest = 0;
         double wbest = 0;
         b2_each(alive, [&](int x) {
-            const double wx = miss[x] * 64.0 + ws[x];
+            const double wx = score[x];
             const double d = wx - wbest;
             if (best < 0 || wx < wbest - 1e-12) {
                 best = x;
@@ -214,7 +238,7 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
                 common.a = adj[y].a & adj[u].a & ~nb.a;
                 common.b = adj[y].b & adj[u].b & ~nb.b;
                 common.clr(best);
-                b2_each(common, [&](int z) { miss[z] -= 2; });
+                b2_each(common, [&](int z) { miss[z] -= 2; score[z] = miss[z] * 64.0 + ws[z]; });
             });
         });
         b2_each(nb, [&](int y) {
@@ -223,12 +247,31 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
             adj[y].clr(best);
             adj[y].clr(y);
         });
-        b2_each(nb, [&](int y) { if (alive.test(y)) full(y); });
+        // the neighbours' own counts: nb is a clique now, so a missing pair of y has at least one end outside it -
+        //   miss[y] = sum over e in ext = adj[y] - nb of  |nb - y - adj[e]| (pairs (w, e), counted from e's side: once
+        //             here and once as (e, w) below)  +  |adj[y] - adj[e]| - 1 (pairs (e, w'), e itself taken off)
+        const B2 live_nb{nb.a & alive.a, nb.b & alive.b};
+        b2_each(live_nb, [&](int y) {
+            const B2 ay = adj[y];
+            B2 ext, nbm = nb;
+            ext.a = ay.a & ~nb.a;
+            ext.b = ay.b & ~nb.b;
+            nbm.clr(y);
+            int missing = 0;
+            b2_each(ext, [&](int e) {
+                const uint64_t na = ~adj[e].a, nb_ = ~adj[e].b;
+                missing += __builtin_popcountll(nbm.a & na) + __builtin_popcountll(nbm.b & nb_) + __builtin_popcountll(ay.a & na) +
+                           __builtin_popcountll(ay.b & nb_) - 1;
+            });
+            ws[y] = order_log2sum(net, ay);
+            miss[y] = missing;
+            score[y] = missing * 64.0 + ws[y];
+        });
     }
     return true;
 }
 
-// Relevant set, hidden set and the factor scopes (S.f0 / S.f0c) of one request.
+// Relevant set, hidden set and the factor scopes (S.f / S.fc of the relevant variables) of one request.
 MIBN_HD inline void order_prepare(const OrderNet &net, OrderScratch &S, int nq, const int32_t *qvars, int ne, const int32_t *evars,
                                   bool no_prune, B2 &rel, B2 &hidden) {
     B2 qb, eb;
@@ -239,21 +282,19 @@ MIBN_HD inline void order_prepare(const OrderNet &net, OrderScratch &S, int nq, 
         for (int v = 0; v < net.n_vars; ++v) rel.set(v);
     hidden.a = rel.a & ~qb.a & ~eb.a;
     hidden.b = rel.b & ~qb.b & ~eb.b;
+    S.rel = rel;
     // factors = the CPTs of the relevant variables with the evidence (and single-state) axes removed
-    S.n_f0 = 0;
+    const B2 keep{net.multi.a & ~eb.a, net.multi.b & ~eb.b};
     b2_each(rel, [&](int v) {
         B2 sc;
-        double cells = 1;
-        b2_each(net.cpt_scope[v], [&](int u) {
-            if (!eb.test(u) && net.card[u] > 1) { sc.set(u); cells *= net.card[u]; }
-        });
-        S.f0[S.n_f0] = sc;
-        S.f0c[S.n_f0] = cells;
-        ++S.n_f0;
+        sc.a = net.cpt_scope[v].a & keep.a;
+        sc.b = net.cpt_scope[v].b & keep.b;
+        S.f[v] = sc;
+        S.fc[v] = order_cells(net, sc);
     });
     // single-state variables carry no information: they are never axes, never eliminated
-    const B2 h0 = hidden;
-    b2_each(h0, [&](int v) { if (net.card[v] <= 1) hidden.clr(v); });
+    hidden.a &= net.multi.a;
+    hidden.b &= net.multi.b;
 }
 
 // The two sweep candidates into S.cand: which = 0 "meet" (down from the roots to the query's depth, then up from the

@@ -103,15 +103,26 @@ std::string Network::set(int32_t n, const int32_t *card_, const int64_t *scope_o
     }
     anc2.clear();
     scope2.clear();
+    fam2.clear();
+    multi2 = B2{};
+    uniform_log2 = -1;
     hint_flat.clear();
     if (n <= 128 && err.empty()) {
         anc2.resize(n);
         scope2.resize(n);
+        fam2.resize(n);
+        int l = -2;  // -2: no multi-state variable seen yet
         for (int v = 0; v < n; ++v) {
             anc2[v].a = anc[v].w[0];
             anc2[v].b = anc[v].w[1];
-            for (int32_t u : scope[v]) scope2[v].set(u);
+            for (int32_t u : scope[v]) { scope2[v].set(u); fam2[u].set(v); }
+            if (card[v] > 1) {
+                multi2.set(v);
+                const int lv = (card[v] & (card[v] - 1)) == 0 ? __builtin_ctz((unsigned)card[v]) : -1;
+                l = l == -2 ? lv : (l == lv ? l : -1);
+            }
         }
+        uniform_log2 = l < 0 ? -1 : l;
     }
     scope_off32.assign(1, 0);
     scope_flat.clear();
@@ -188,6 +199,9 @@ OrderNet Network::order_view() const {
     o.depth = depth.data();
     o.anc = anc2.data();
     o.cpt_scope = scope2.data();
+    o.fam = fam2.data();
+    o.multi = multi2;
+    o.uniform_log2 = uniform_log2;
     o.topo_asc = topo_asc.data();
     o.topo_desc = topo_desc.data();
     o.hint_sorted = hint_flat.data();

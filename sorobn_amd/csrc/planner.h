@@ -36,7 +36,9 @@ struct Network {
     std::vector<std::vector<int32_t>> hint_sorted;  // every hint as a variable list in ascending (priority, id) order, then the built-in sweeps
     std::vector<int32_t> topo_asc, topo_desc;    // all variables by (depth ascending, id) / (depth descending, id)
     // networks of up to 128 variables: what the shared host / device order search reads (order_search.h)
-    std::vector<B2> anc2, scope2;
+    std::vector<B2> anc2, scope2, fam2;          // fam2[v]: the CPTs that mention v (v and its children)
+    B2 multi2;                                   // the variables with more than one state
+    int32_t uniform_log2 = -1;                   // l: every multi-state variable has 2^l states (OrderNet::uniform_log2)
     std::vector<int32_t> hint_flat;
     OrderNet order_view() const;
     // what the shared host / device emission reads (emit_core.h): the CPT scopes as one CSR, the ancestor sets as n x nw words
