@@ -13,8 +13,8 @@ states per node (Dirichlet(1) CPTs from default_rng(0)).  Inputs (the flattened 
 the timed region; the timed region covers planning, program upload, the VE kernel, result download and - for N > 1 -
 the RCCL all-gather of the posteriors.  Multi-GPU: one process per GPU, requests are independent so every rank
 processes its own contiguous shard of the stream (weak scaling, no data-path collective besides the final gather).
-The whole product path is ctypes -> libmibn.so (HIP kernels + RCCL through the C-ABI): PyTorch is NOT imported unless
-the MIBN_BENCH_BACKEND=gloo|nccl test hook asks for a torch.distributed transport.
+The whole product path is ctypes -> libmibn.so (HIP kernels + RCCL through the C-ABI): PyTorch is never imported, and there
+is no second transport behind mibn_comm_*: if it is unavailable on a rank, the launch exits non-zero.
 
 Rank 0 prints ONE JSON line with the driver's contract fields plus
   `roofline`      dominant kernel: algorithmic bytes per launch / HIP-event duration, vs the 8 TB/s HBM peak
@@ -286,32 +286,30 @@ def c3_variant(eng, to_var, n_evidence, calls=6, warmup_calls=2, batch=32768):
 # ------------------------------------------------------------------------------------------------ transports
 
 def make_comm(backend, world, rank, local_rank, engine):
-    """-> (comm, transport name).  "rccl" = the C-ABI's mibn_comm_* (no PyTorch); should its initialisation fail on this
-    node (every rank sees the same error: the call is collective) the ranks fall back to RCCL through torch.distributed
-    rather than lose the run, and the JSON line says so."""
+    """-> (comm, transport name).  "rccl" = the C-ABI's mibn_comm_* (RCCL over xGMI, no PyTorch) - the only transport of a
+    measurement: whatever goes wrong between dlopen and ncclCommInitRank raises, the rank exits non-zero and the launcher ends
+    the launch (a fallback would mask a real RCCL defect in the first N > 1 line).  "files" = the dry run."""
     from sorobn_amd import sharding
     if world == 1:
         return sharding.SoloComm(), "none"
     if backend == "files":  # the dry run: everything of the N > 1 path but ncclCommInitRank and the collectives (sharding.FileComm)
         return sharding.FileComm(engine, rank, world), "files"
-    if backend == "rccl":
-        try:
-            return sharding.RcclComm(engine, rank, world), "rccl"
-        except Exception as e:  # noqa: BLE001 - anything from dlopen to ncclCommInitRank
-            print(f"[bench] rank {rank}: mibn_comm_* unavailable ({e!r}); falling back to torch.distributed nccl", file=sys.stderr, flush=True)
-            import torch
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            return sharding.TorchComm(), "nccl-fallback"
-    return sharding.TorchComm(), backend
+    if backend != "rccl":
+        raise SystemExit(f"MIBN_BENCH_BACKEND={backend!r}: only 'rccl' (default) and 'files' (dry run) exist")
+    return sharding.RcclComm(engine, rank, world), "rccl"
+
+
+def pci_numbers(info):
+    """The PCI bus id in mibn_device_info's line ("... pci 0000:05:00.0 ...") as [domain, bus, device, function] floats (what the
+    ranks all-gather for the line's per_rank.device_pci), [-1] * 4 if it cannot be read."""
+    import re
+    m = re.search(r"pci ([0-9a-fA-F]+):([0-9a-fA-F]+):([0-9a-fA-F]+)\.([0-9a-fA-F]+)", info or "")
+    return [float(int(g, 16)) for g in m.groups()] if m else [-1.0] * 4
 
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) with the environment a launcher
-    would give them - RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR / MASTER_PORT (only the gloo test hook opens
-    a socket on it) - plus a private directory and a nonce for the out-of-band RCCL id (sharding.exchange_id), wait for them,
+    would give them - RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR / MASTER_PORT (unused here: no socket is opened on it) - plus a private directory and a nonce for the out-of-band RCCL id (sharding.exchange_id), wait for them,
     and pass rank 0's line through.  No PyTorch: the ranks talk RCCL through the C-ABI (mibn_comm_*)."""
     import secrets
     import shutil
@@ -345,6 +343,54 @@ def spawn_ranks(n):
                 p.kill()
         shutil.rmtree(comm_dir, ignore_errors=True)
     return rc
+
+
+def host_cpu_quota():
+    """CPUs' worth of time this container may use: the cgroup quota (v2 cpu.max / v1 cfs_quota), else the hardware threads."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                return q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    return float(os.cpu_count() or 1)
+
+
+def project_8gpu(out):
+    """What this box's measurements say about eight ranks on one node (no 8-GPU node is available to the builder; the driver's
+    SCALE run is the measurement, this is the arithmetic behind DESIGN section 7, reproducible from the line): a rank of an 8-GPU
+    node whose container has the SAME CPU quota as this box plans with quota / 8 threads; its rate is read off the measured
+    few-threads configs (linear interpolation between the measured thread counts, the headline = the whole quota), the node's
+    rate is 8 x that (requests are independent, the gather moves 32 B per query)."""
+    quota = host_cpu_quota()
+    pts = {}
+    for nt, name in ((1, "C3_planner_threads_1"), (2, "C3_two_planner_threads"), (4, "C3_planner_threads_4")):
+        v = out.get("configs", {}).get(name, {}).get("queries_per_s")
+        if v:
+            pts[float(nt)] = float(v)
+    pts[max(quota, 5.0)] = float(out["value"])  # the headline: this box's whole quota on one rank
+    xs = sorted(pts)
+    t = quota / 8.0
+    if t <= xs[0]:
+        rate = pts[xs[0]] * min(1.0, t / xs[0]) if t < 1.0 else pts[xs[0]]
+    elif t >= xs[-1]:
+        rate = pts[xs[-1]]
+    else:
+        hi = next(x for x in xs if x >= t)
+        lo = max(x for x in xs if x <= t)
+        rate = pts[lo] if hi == lo else pts[lo] + (pts[hi] - pts[lo]) * (t - lo) / (hi - lo)
+    return {"host_cpu_quota": quota, "planner_threads_per_rank_on_8_gpus_same_quota": t,
+            "measured_queries_per_s_by_planner_threads": {str(int(x)) if x == int(x) else str(x): pts[x] for x in xs},
+            "per_rank_queries_per_s": rate, "node_queries_per_s": 8.0 * rate, "scaling_vs_this_line": 8.0 * rate / float(out["value"]),
+            "scaling_if_each_rank_keeps_this_quota": 8.0,
+            "note": "PROJECTION from one-GPU measurements of this run, not a measurement: 8 x the rate of a rank restricted to (this box's CPU "
+                    "quota / 8) planning threads (adaptive policy: the rank's own GPU plans what its host threads cannot); the all-gather of "
+                    "32 B per query over xGMI is not modelled (2^18 x 32 B = 8 MB per step)"}
 
 
 def main():
@@ -395,22 +441,13 @@ def main():
         else:
             a.batch = 32768
 
-    # Transport of the final gather: "rccl" (default) = mibn_comm_* of the C-ABI, RCCL over xGMI, no PyTorch.
-    # MIBN_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 path run on a box with fewer GPUs than ranks (ranks then
-    # share devices and the collectives run on host tensors through torch.distributed); "nccl" = RCCL through PyTorch.
+    # Transport of the final gather: "rccl" (default) = mibn_comm_* of the C-ABI, RCCL over xGMI, no PyTorch - and nothing behind
+    # it.  MIBN_BENCH_BACKEND=files is the dry run: it lets the N > 1 path run on a box with fewer GPUs than ranks (the ranks then
+    # share devices and the collectives go through files of the launch's directory, sharding.FileComm).
     backend = os.environ.get("MIBN_BENCH_BACKEND", "rccl")
     from sorobn_amd import _capi
     n_dev = max(1, _capi.device_count())
-    device = local_rank if backend not in ("gloo", "files") else local_rank % n_dev
-    if world > 1 and backend not in ("rccl", "files"):
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            torch.cuda.set_device(device)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    device = local_rank if backend != "files" else local_rank % n_dev
 
     import netspec
     import sorobn_amd
@@ -475,8 +512,13 @@ def main():
     kagg = {n: {f: ks1[n][f] - ks0.get(n, {}).get(f, 0.0) for f in ks1[n]} for n in ks1}
     kagg = {n: d for n, d in kagg.items() if d["launches"] > 0}
     # per rank: what it processed in the timed region (requests, section-8(d) bytes, GPU busy time) - the shard imbalance as run
+    try:
+        my_info = eng.device_info()
+    except Exception as e:  # noqa: BLE001
+        my_info = f"unavailable ({e!r})"
     per_rank = comm.allgather(np.array([[float(stream.ranges(a.warmup)[rank][1] - stream.ranges(a.warmup)[rank][0]), agg["alg_bytes"],
-                                         agg["kernel_ms"], agg["plan_ms"]]]))[:, 0, :] if world > 1 else None
+                                         agg["kernel_ms"], agg["plan_ms"], float(device), *pci_numbers(my_info),
+                                         float(getattr(comm, "rccl_ranks", 0)), float(getattr(comm, "rccl_rank", -1))]]))[:, 0, :] if world > 1 else None
     if world > 1:
         dt = float(comm.allreduce_max([dt])[0])
 
@@ -542,11 +584,10 @@ def main():
                        "requests_per_step": G, "requests_per_step_per_gpu": G / world, "requests_per_engine_call": a.batch,
                        "parallelism": f"dp{world} (independent contiguous shards, one all-gather per step)",
                        "gather": {"none": "none", "rccl": "RCCL via the C-ABI (mibn_comm_allgather_f64), no PyTorch",
-                                  "nccl": "RCCL via torch.distributed (hook)",
-                                  "nccl-fallback": "RCCL via torch.distributed (mibn_comm_init failed on this node: see stderr)",
-                                  "gloo": "gloo via torch.distributed (test hook)",
                                   "files": "DRY RUN (MIBN_BENCH_BACKEND=files): launch, librccl probe, vote and id exchange as with "
                                            "RCCL, the collectives through files - a check of the plumbing, not a measurement"}[transport],
+                       # ncclCommCount of the live communicator (0: no RCCL communicator - N = 1 or the dry run)
+                       "rccl_ranks": int(getattr(comm, "rccl_ranks", 0)),
                        "shard_balance": a.balance, "planner_threads": a.threads or "auto (cgroup quota / ranks)",
                        "adaptive_planning": not a.no_adaptive,
                        # chunks planned by order_kernel + emit_kernel in the timed region (option gpu_emit, or the adaptive policy when
@@ -574,6 +615,9 @@ def main():
         if per_rank is not None:
             out["per_rank"] = {"requests_per_step": per_rank[:, 0].tolist(), "alg_GB": (per_rank[:, 1] / 1e9).tolist(),
                                "gpu_busy_ms": per_rank[:, 2].tolist(), "planner_wall_ms": per_rank[:, 3].tolist(),
+                               "device": [int(x) for x in per_rank[:, 4]],
+                               "device_pci": ["%04x:%02x:%02x.%x" % tuple(int(x) for x in r[5:9]) if r[5] >= 0 else "?" for r in per_rank],
+                               "rccl_comm_count": [int(x) for x in per_rank[:, 9]], "rccl_user_rank": [int(x) for x in per_rank[:, 10]],
                                "imbalance_alg_bytes_max_over_mean": float(per_rank[:, 1].max() / per_rank[:, 1].mean()),
                                "imbalance_gpu_busy_max_over_mean": float(per_rank[:, 2].max() / per_rank[:, 2].mean())}
         out["roofline"]["traffic_over_alg"], out["roofline"]["traffic_source"] = pmc_ratio(dom)
@@ -678,28 +722,28 @@ def main():
                 out["cpu_baseline"]["note"] = "oracle/_ref unavailable on this box: " + (ref[0]["error"] if ref else "not built")
             out["max_abs_marginal_err_vs_oracle"] = err_port
         if world == 1 and not a.no_configs and not a.threads:
-            # a rank with TWO planner threads (8 ranks sharing a small CPU quota): a fresh engine whose pool has two workers; the
-            # adaptive policy hands the planning to order_kernel + emit_kernel (the main engine's arena is released first)
-            try:
-                eng.close()
-                bn2 = netspec.build(spec, sorobn_amd.BayesNet).use_device(device)
-                eng2 = bn2.backend.engine
-                eng2.set_option("threads", 2)
-                eng2.set_option("adaptive", 1)
-                for kv in a.opt:
-                    k, v = kv.split("=")
-                    eng2.set_option(k, float(v))
-                # (calls of 32 768: such a rank's shard of a 2^18-request step on eight GPUs)
-                out["configs"]["C3_two_planner_threads"] = c3_variant(eng2, to_var, a.n_evidence, calls=8, warmup_calls=3, batch=32768)
-                eng2.close()
-            except Exception as e:  # noqa: BLE001
-                out["configs"]["C3_two_planner_threads"] = {"error": repr(e)}
+            # a rank with ONE / TWO / FOUR planner threads (8 ranks sharing a small CPU quota): a fresh engine whose pool has that many
+            # workers; the adaptive policy hands planning to order_kernel + emit_kernel where the host's workers would bound the
+            # pipeline (the main engine's arena is released first).  Calls of 32 768: such a rank's shard of a 2^18-request step on
+            # eight GPUs.  C3_two_planner_threads keeps its round-3 name.
+            eng.close()
+            for nt, name in ((2, "C3_two_planner_threads"), (1, "C3_planner_threads_1"), (4, "C3_planner_threads_4")):
+                try:
+                    bn2 = netspec.build(spec, sorobn_amd.BayesNet).use_device(device)
+                    eng2 = bn2.backend.engine
+                    eng2.set_option("threads", nt)
+                    eng2.set_option("adaptive", 1)
+                    for kv in a.opt:
+                        k, v = kv.split("=")
+                        eng2.set_option(k, float(v))
+                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=8 if nt == 2 else 6, warmup_calls=3, batch=32768)
+                    eng2.close()
+                except Exception as e:  # noqa: BLE001
+                    out["configs"][name] = {"error": repr(e)}
+            out["projected_8gpu"] = project_8gpu(out)
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()
-    if world > 1 and transport not in ("rccl", "files"):
-        import torch.distributed as dist
-        dist.destroy_process_group()
 
 
 def run_c5(a, rank, world, local_rank, device, backend):
@@ -755,9 +799,6 @@ def run_c5(a, rank, world, local_rank, device, backend):
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()
-    if world > 1 and transport not in ("rccl", "files"):
-        import torch.distributed as dist
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

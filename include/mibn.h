@@ -277,6 +277,8 @@ int mibn_count_tables(mibn_t *h, int64_t n_rows, int32_t n_cols, const uint8_t *
  *                         a message naming the likely causes instead of hanging the launch
  *   mibn_device_info      one text line about this context's device (name, PCI bus id, link type / hops to every other
  *                         visible device) for the launch log
+ *   mibn_comm_count       ncclCommCount / ncclCommUserRank of the live communicator: what RCCL itself reports, for the
+ *                         bench line of an N > 1 run (`config.rccl_ranks`)
  *   mibn_comm_allgather_f64   recv[r * n .. (r+1) * n) = rank r's send[0 .. n)   (host buffers, staged through HBM)
  *   mibn_comm_reduce_i64      sum over ranks of buf[0 .. n) -> buf on `root` (other ranks' buf unchanged)
  *   mibn_comm_allreduce_max_f64   element-wise max over ranks, in place (the bench's max-over-ranks step time)
@@ -287,6 +289,7 @@ int mibn_comm_probe(mibn_t *h);
 int mibn_device_info(mibn_t *h, char *buf, int32_t cap);
 int mibn_comm_unique_id(mibn_t *h, void *id_out /* MIBN_COMM_ID_BYTES */);
 int mibn_comm_init(mibn_t *h, int32_t rank, int32_t world, const void *id /* MIBN_COMM_ID_BYTES */);
+int mibn_comm_count(mibn_t *h, int32_t *n_ranks, int32_t *my_rank);
 int mibn_comm_destroy(mibn_t *h);
 int mibn_comm_allgather_f64(mibn_t *h, const double *send, int64_t n, double *recv);
 int mibn_comm_reduce_i64(mibn_t *h, int64_t *buf, int64_t n, int32_t root);

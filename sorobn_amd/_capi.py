@@ -21,7 +21,7 @@ SYMBOLS = [
     "mibn_query_batch_ex", "mibn_plan_order", "mibn_estimate_costs", "mibn_device_synchronize", "mibn_gibbs_shard",
     "mibn_comm_unique_id", "mibn_comm_init", "mibn_comm_destroy", "mibn_comm_allgather_f64",
     "mibn_comm_reduce_i64", "mibn_comm_allreduce_max_f64", "mibn_comm_barrier", "mibn_gibbs_conditional", "mibn_sample_probe",
-    "mibn_comm_probe", "mibn_device_info",
+    "mibn_comm_probe", "mibn_device_info", "mibn_comm_count",
 ]
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE, E_LIMIT, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -86,6 +86,7 @@ def lib():
         L.mibn_comm_unique_id.argtypes = [vp, C.c_char_p]
         L.mibn_comm_init.argtypes = [vp, C.c_int32, C.c_int32, C.c_char_p]
         L.mibn_comm_destroy.argtypes = [vp]
+        L.mibn_comm_count.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.mibn_comm_allgather_f64.argtypes = [vp, f64p, C.c_int64, f64p]
         L.mibn_comm_reduce_i64.argtypes = [vp, i64p, C.c_int64, C.c_int32]
         L.mibn_comm_allreduce_max_f64.argtypes = [vp, f64p, C.c_int64]
@@ -357,6 +358,12 @@ class Engine:
     def comm_init(self, rank, world, unique_id):
         assert len(unique_id) == COMM_ID_BYTES
         self._check(self._L.mibn_comm_init(self._h, int(rank), int(world), unique_id))
+
+    def comm_count(self):
+        """(ncclCommCount, ncclCommUserRank) of the live communicator - what RCCL itself reports."""
+        n, r = C.c_int32(0), C.c_int32(-1)
+        self._check(self._L.mibn_comm_count(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
 
     def comm_destroy(self):
         self._check(self._L.mibn_comm_destroy(self._h))

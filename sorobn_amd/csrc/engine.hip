@@ -300,6 +300,8 @@ struct mibn_ctx {
         decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
         decltype(&ncclCommInitRank) CommInitRank = nullptr;
         decltype(&ncclCommDestroy) CommDestroy = nullptr;
+        decltype(&ncclCommCount) CommCount = nullptr;
+        decltype(&ncclCommUserRank) CommUserRank = nullptr;
         decltype(&ncclAllGather) AllGather = nullptr;
         decltype(&ncclReduce) Reduce = nullptr;
         decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -1921,6 +1923,8 @@ int comm_load(mibn_ctx *h) {
     MIBN_SYM(GetUniqueId, ncclGetUniqueId)
     MIBN_SYM(CommInitRank, ncclCommInitRank)
     MIBN_SYM(CommDestroy, ncclCommDestroy)
+    MIBN_SYM(CommCount, ncclCommCount)
+    MIBN_SYM(CommUserRank, ncclCommUserRank)
     MIBN_SYM(AllGather, ncclAllGather)
     MIBN_SYM(Reduce, ncclReduce)
     MIBN_SYM(AllReduce, ncclAllReduce)
@@ -2044,6 +2048,19 @@ extern "C" int mibn_comm_init(mibn_t *h, int32_t rank, int32_t world, const void
     }
     h->comm.rank = rank;
     h->comm.world = world;
+    return MIBN_OK;
+}
+
+// What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank) - not what the caller asked for: the bench
+// line of an N > 1 run carries these, so that a transport that silently degraded cannot claim N ranks.
+extern "C" int mibn_comm_count(mibn_t *h, int32_t *n_ranks, int32_t *my_rank) {
+    int rc;
+    if ((rc = comm_ready(h))) return rc;
+    int n = 0, r = -1;
+    NCCL_TRY(h, h->comm.CommCount(h->comm.comm, &n));
+    NCCL_TRY(h, h->comm.CommUserRank(h->comm.comm, &r));
+    if (n_ranks) *n_ranks = n;
+    if (my_rank) *my_rank = r;
     return MIBN_OK;
 }
 

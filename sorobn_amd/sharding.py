@@ -11,8 +11,8 @@ byte estimates, `Engine.estimate_costs`): one request of the 10x10 grid costs be
 Transports behind one small interface (`rank`, `world`, `allgather`, `reduce_i64`, `allreduce_max`, `barrier`):
   * `RcclComm`  - the product path: the C-ABI's mibn_comm_* entry points, directly on RCCL over xGMI, no PyTorch.  The
                   128-byte RCCL id travels from rank 0 to the other ranks of the node through a file.
-  * `TorchComm` - a test hook: the same calls on a torch.distributed process group ("gloo" on CPU: the world-size-2
-                  tests of the N > 1 logic in the GPU-less build container).
+                  (The world-size-2 CPU tests run the same calls on a torch.distributed gloo group through `tests/torchcomm.py` -
+                  test infrastructure: nothing in this package or in bench.py imports PyTorch.)
   * `FileComm`  - the dry run (`MIBN_BENCH_BACKEND=files`): N ranks on FEWER GPUs than ranks (RCCL refuses two ranks on one
                   device) run everything of the N > 1 path - the launch, the librccl probe on every rank, the vote, rank 0's
                   ncclGetUniqueId and the id exchange, the shards, the gather's packing - except ncclCommInitRank and the
@@ -123,17 +123,27 @@ def _fresh(path, t0):
     return os.path.getmtime(path) >= (start - 1.0 if start is not None else t0 - 600.0)
 
 
+_ID_ERR = b"MIBN-ID-ERROR:"  # what rank 0 publishes in place of an id it could not create
+
+
 def exchange_id(rank, world, make_id, path=None, timeout_s=120.0):
     """Rank 0 calls make_id() and publishes the bytes (atomic rename, after removing whatever an earlier launch left under the
-    same name); the others wait for a file of this launch."""
+    same name); the others wait for a file of this launch.  If make_id() raises, rank 0 publishes an error marker instead and the
+    readers fail at once with its text."""
     path = path or _id_file()
     if rank == 0:
         try:
             os.unlink(path)
         except OSError:
             pass
-        uid = make_id()
         tmp = f"{path}.{os.getpid()}.tmp"
+        try:
+            uid = make_id()
+        except Exception as e:  # the readers must not poll for two minutes for an id that will never come (ADVICE r4)
+            with open(tmp, "wb") as f:
+                f.write(_ID_ERR + repr(e).encode()[:200])
+            os.replace(tmp, path)
+            raise
         with open(tmp, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)
@@ -144,6 +154,8 @@ def exchange_id(rank, world, make_id, path=None, timeout_s=120.0):
             if _fresh(path, t0):
                 with open(path, "rb") as f:
                     uid = f.read()
+                if uid.startswith(_ID_ERR):
+                    raise RuntimeError(f"rank {rank}: rank 0 could not create the RCCL id: {uid[len(_ID_ERR):].decode(errors='replace')}")
                 if len(uid) >= 128:
                     return uid[:128], path
         except OSError:
@@ -216,8 +228,7 @@ def _probe_and_vote(engine, rank, world):
     import sys
     print(f"[mibn comm] rank {rank}/{world} pid {os.getpid()} {info}", file=sys.stderr, flush=True)
     ok, vote = all_agree(rank, world, err is None, "rccl_load")
-    if not ok:
-        _unlink(vote)
+    if not ok:  # (the vote file stays: a slower peer may still be reading it - the launcher's directory is cleaned anyway)
         raise RuntimeError(f"mibn_comm_* unavailable on at least one rank of the node (this rank: {err!r})")
     return vote
 
@@ -231,18 +242,21 @@ class RcclComm:
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         # What can fail on one rank only - loading librccl.so - happens BEFORE anybody enters the collective
         # ncclCommInitRank, and the ranks agree on the outcome: either all of them build the communicator or all of them
-        # raise (and the caller falls back as a whole); a rank that failed alone would leave the others hanging in the init
+        # raise (there is no fallback transport: the launch fails as a whole); a rank that failed alone would leave the others hanging in the init
         # (which is bounded besides: mibn_comm_init gives up after MIBN_COMM_INIT_TIMEOUT_S seconds).
         vote = _probe_and_vote(engine, self.rank, self.world)
         uid, path = exchange_id(self.rank, self.world, engine.comm_unique_id,  # (ncclGetUniqueId on rank 0 only)
                                 path=f"{_id_file()}.a{_next_attempt('id')}")
-        try:
-            engine.comm_init(self.rank, self.world, uid)
-            engine.comm_barrier()  # every rank has read the id and everybody's vote
-        finally:
-            _unlink(vote)
-            if self.rank == 0:
-                _unlink(path)
+        # (on a failure the vote and id files stay where they are: a peer may still be polling for them, and a rank that raised
+        #  here is on its way out - bench.py exits non-zero, there is no second transport behind this one)
+        engine.comm_init(self.rank, self.world, uid)
+        engine.comm_barrier()  # every rank has read the id and everybody's vote
+        _unlink(vote)
+        if self.rank == 0:
+            _unlink(path)
+        self.rccl_ranks, self.rccl_rank = engine.comm_count()  # what RCCL itself reports (ncclCommCount / ncclCommUserRank)
+        if (self.rccl_ranks, self.rccl_rank) != (self.world, self.rank):
+            raise RuntimeError(f"RCCL reports rank {self.rccl_rank} of {self.rccl_ranks}, the launch says {self.rank} of {self.world}")
 
     def allgather(self, rows):
         rows = np.ascontiguousarray(rows, np.float64)
@@ -333,52 +347,11 @@ class FileComm:
         self._mine = []
 
 
-class TorchComm:
-    """Test hook: the same interface on a torch.distributed group (gloo on CPU, or nccl = RCCL through PyTorch)."""
-
-    def __init__(self, group=None):
-        import torch
-        import torch.distributed as dist
-
-        self._torch, self._dist, self.group = torch, dist, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        backend = dist.get_backend(group)
-        self.dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-
-    def allgather(self, rows):
-        torch = self._torch
-        rows = np.ascontiguousarray(rows, np.float64)
-        mine = torch.from_numpy(rows.reshape(-1)).to(self.dev)
-        out = torch.empty(self.world * mine.numel(), dtype=torch.float64, device=self.dev)
-        self._dist.all_gather_into_tensor(out, mine, group=self.group)
-        return out.cpu().numpy().reshape((self.world,) + rows.shape)
-
-    def reduce_i64(self, arr, root=0):
-        torch = self._torch
-        t = torch.from_numpy(np.ascontiguousarray(arr, np.int64).copy()).to(self.dev)
-        self._dist.reduce(t, dst=root, op=self._dist.ReduceOp.SUM, group=self.group)
-        return t.cpu().numpy() if self.rank == root else np.ascontiguousarray(arr, np.int64).copy()
-
-    def allreduce_max(self, values):
-        torch = self._torch
-        t = torch.from_numpy(np.ascontiguousarray(values, np.float64).copy().reshape(-1)).to(self.dev)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
-        return t.cpu().numpy()
-
-    def barrier(self):
-        self._dist.barrier(group=self.group)
-
-    def close(self):
-        pass
-
-
 # ------------------------------------------------------------------------------------------------ the two gathers
 
-def gather_posteriors(local: np.ndarray, n_total: int, comm=None, ranges=None, group=None):
+def gather_posteriors(local: np.ndarray, n_total: int, comm, ranges=None):
     """All-gather row shards back into the full [n_total, cells] array (every rank gets it).  `ranges` = the shard of
     every rank (default: the count split of `shard_range`); shards of different length are padded for the collective."""
-    if comm is None:
-        comm = TorchComm(group)  # (the pre-round-2 signature: a torch.distributed group)
     world = comm.world
     ranges = ranges or [shard_range(n_total, world, r) for r in range(world)]
     rows = max(hi - lo for lo, hi in ranges)

@@ -1,6 +1,6 @@
 """Worker of tests/test_dist.py: world_size-2 gloo run of the multi-GPU path's logic (sorobn_amd/sharding.py) - count-
 and cost-balanced request shards + the posterior gather, chain shards + the int64 histogram reduce, max-over-ranks -
-with the CPU plan simulator standing in for the GPU engine and torch.distributed/gloo (the `TorchComm` test hook)
+with the CPU plan simulator standing in for the GPU engine and torch.distributed/gloo (tests/torchcomm.py)
 standing in for RCCL."""
 import os
 import sys
@@ -17,6 +17,7 @@ import netspec  # noqa: E402
 import simengine  # noqa: E402
 import sorobn_amd  # noqa: E402
 from sorobn_amd import _capi, sharding  # noqa: E402
+from torchcomm import TorchComm  # noqa: E402
 
 
 class FakeGibbsEngine:
@@ -31,7 +32,7 @@ class FakeGibbsEngine:
 
 def main():
     dist.init_process_group("gloo")
-    comm = sharding.TorchComm()
+    comm = TorchComm()
     rank, world = comm.rank, comm.world
     spec = netspec.grid_spec(5, 5, 4, seed=0)
     bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
@@ -41,10 +42,10 @@ def main():
     to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(25)], np.int32)
     ref = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec) if rank == 0 else None
 
-    # 1. count-balanced contiguous shards, gather (the pre-round-2 call shape: a torch group) and through a Comm
+    # 1. count-balanced contiguous shards, gathered through a Comm
     lo, hi = sharding.shard_range(n, world, rank)
     local = be.engine.query_fixed(to_var[q[lo:hi]][:, None], to_var[ev[lo:hi]], ec[lo:hi])
-    for full in (sharding.gather_posteriors(local, n), sharding.gather_posteriors(local, n, comm)):
+    for full in (sharding.gather_posteriors(local, n, comm),):
         assert full.shape == (n, 4)
         if rank == 0:
             assert np.array_equal(full, ref)

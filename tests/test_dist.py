@@ -77,12 +77,13 @@ import pytest  # noqa: E402
 @pytest.mark.gpu
 def test_bench_two_ranks_launch_path():
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process), on however
-    many GPUs the box has: with the MIBN_BENCH_BACKEND=gloo test hook the ranks may share a device and the barrier /
-    gather / max-over-ranks run on host tensors - everything but the RCCL transport itself."""
+    many GPUs the box has: with MIBN_BENCH_BACKEND=files (the dry run, sharding.FileComm) the ranks may share a device and the
+    barrier / gather / max-over-ranks go through files - everything but ncclCommInitRank and the collectives themselves.  The ranks
+    never import PyTorch (torchrun is only the launcher)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MIBN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MIBN_BENCH_BACKEND="files", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "4096", "--scaling", "weak"]
@@ -96,13 +97,15 @@ def test_bench_two_ranks_launch_path():
     assert abs(out["value"] - 2 * 2 * 4096 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     assert out["per_rank"]["requests_per_step"] == [4096.0, 4096.0]
+    assert out["config"]["rccl_ranks"] == 0 and out["config"]["gather"].startswith("DRY RUN")  # no RCCL communicator in the dry run
+    assert len(out["per_rank"]["device_pci"]) == 2 and all(":" in p for p in out["per_rank"]["device_pci"])
 
 
 @pytest.mark.gpu
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher at all: bench.py starts the ranks itself (RANK / WORLD_SIZE / a private
-    directory for the RCCL id in their environment).  With the gloo test hook the two ranks may share the box's one GPU."""
-    env = dict(os.environ, MIBN_BENCH_BACKEND="gloo")
+    directory for the RCCL id in their environment).  As a dry run (files) the two ranks may share the box's one GPU."""
+    env = dict(os.environ, MIBN_BENCH_BACKEND="files")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
@@ -186,3 +189,70 @@ def test_file_comm_collectives(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     assert [o[0] for o in outs] == ["ok", "ok"]
     assert len([f for f in os.listdir(tmp_path) if f.startswith("mibn_filecomm")]) <= 2, os.listdir(tmp_path)  # (the last barrier's)
+
+
+def test_no_pytorch_and_no_second_transport_in_the_product_path():
+    """the first N > 1 run must be unable to lie.  bench.py and the package never import PyTorch (the gloo
+    stand-in lives in tests/torchcomm.py), bench.py knows exactly two transports - mibn_comm_* ("rccl") and the dry run ("files") -
+    and an unknown or failing one ends the rank with a non-zero exit instead of a quiet substitute."""
+    import ast
+    import glob
+    for path in [os.path.join(ROOT, "bench.py"), *glob.glob(os.path.join(ROOT, "sorobn_amd", "*.py"))]:
+        tree = ast.parse(open(path).read())
+        mods = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import):
+                mods.update(a.name.split(".")[0] for a in node.names)
+            elif isinstance(node, ast.ImportFrom) and node.module:
+                mods.add(node.module.split(".")[0])
+        assert "torch" not in mods, path
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "nccl-fallback" not in src and "TorchComm" not in src and "init_process_group" not in src
+    from sorobn_amd import sharding
+    assert not hasattr(sharding, "TorchComm")
+    sys.path.insert(0, ROOT)
+    import bench
+    with pytest.raises(SystemExit):
+        bench.make_comm("gloo", 2, 0, 0, None)
+
+    import inspect
+    assert "except" not in inspect.getsource(bench.make_comm)  # nothing between RcclComm's exception and the rank's exit code
+
+    class NoRccl:  # an engine whose librccl probe fails: RcclComm raises
+        planner_only = False
+
+        def comm_probe(self):
+            raise RuntimeError("cannot load librccl.so")
+
+        def device_info(self):
+            return "device 0 test pci 0000:05:00.0 links: none"
+
+    env_keep = {k: os.environ.get(k) for k in ("MIBN_COMM_DIR", "MIBN_LAUNCH_NONCE")}
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        os.environ.update(MIBN_COMM_DIR=d, MIBN_LAUNCH_NONCE="t_norccl")
+        try:
+            with pytest.raises(RuntimeError, match="unavailable on at least one rank"):
+                sharding.RcclComm(NoRccl(), 0, 1)
+        finally:
+            for k, v in env_keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    assert bench.pci_numbers("device 0 X pci 0000:c5:00.0 links:") == [0.0, 197.0, 0.0, 0.0] and bench.pci_numbers("nothing") == [-1.0] * 4
+
+
+def test_id_exchange_publishes_an_error_marker(tmp_path):
+    """if rank 0 cannot create the id, the readers fail at once with its message instead of polling for two minutes."""
+    path = str(tmp_path / "id")
+
+    def boom():
+        raise RuntimeError("ncclGetUniqueId: unhandled system error")
+
+    with pytest.raises(RuntimeError, match="unhandled system error"):
+        exchange_id(0, 2, boom, path=path)
+    t0 = __import__("time").time()
+    with pytest.raises(RuntimeError, match="rank 0 could not create the RCCL id"):
+        exchange_id(1, 2, None, path=path, timeout_s=30)
+    assert __import__("time").time() - t0 < 5

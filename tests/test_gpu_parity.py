@@ -1023,6 +1023,7 @@ def test_rccl_comm_world_of_one(amd):
     bn = netspec.build(spec, amd.BayesNet)
     be = bn.backend
     comm = sharding.RcclComm(be.engine, rank=0, world=1)
+    assert (comm.rccl_ranks, comm.rccl_rank) == (1, 0) and be.engine.comm_count() == (1, 0)  # ncclCommCount / ncclCommUserRank
     x = np.arange(12, dtype=np.float64).reshape(3, 4)
     assert np.array_equal(comm.allgather(x), x[None])
     assert np.array_equal(comm.reduce_i64(np.array([1, 2, 3], np.int64)), [1, 2, 3])
