@@ -1191,7 +1191,7 @@ int run_tiny(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const i
 // Plan, upload and launch a batch.  Synchronous (ticket == nullptr): waits and writes `out`.  Asynchronous: the
 // results land in a pinned buffer, *ticket identifies the call for mibn_wait; up to two calls may be in flight, so
 // the host plans call s+1 while the GPU still runs call s.
-int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
+int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
               const int32_t *e_codes, const int64_t *out_off, double *out, int32_t *ticket) {
     if (!h || B < 0 || !q_off || !e_off || !out_off || (B && !out)) return MIBN_E_ARG;
     if (h->planner_only) { h->err = "planner-only context: no HIP device bound (there is no CPU fallback)"; return MIBN_E_NODEVICE; }
@@ -1690,6 +1690,26 @@ int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const 
     return MIBN_OK;
 }
 }  // namespace
+
+// Every error exit of a call drains what the call (and earlier asynchronous calls) already put on the streams before the caller
+// sees the error: the caller may free or reuse its request arrays and the pinned `out` the kernels and copies still touch
+// (ADVICE r3 did this for the device-planner exits only; ADVICE r4: every exit behind the first launch).
+static int run_batch(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off, const int32_t *e_vars,
+              const int32_t *e_codes, const int64_t *out_off, double *out, int32_t *ticket) {
+    const int rc = run_batch_body(h, flags, B, q_off, q_vars, e_off, e_vars, e_codes, out_off, out, ticket);
+    if (rc != MIBN_OK && h && !h->planner_only) {
+        const std::string keep = h->err;
+        (void)hipSetDevice(h->device);
+        for (hipStream_t q : {h->search_stream, h->copy_stream, h->stream, h->stream2})
+            if (q) (void)hipStreamSynchronize(q);
+        for (auto &la : h->aux)
+            for (hipStream_t a : la)
+                if (a) (void)hipStreamSynchronize(a);
+        (void)hipGetLastError();
+        h->err = keep;
+    }
+    return rc;
+}
 
 extern "C" int mibn_query_batch(mibn_t *h, int64_t B, const int64_t *q_off, const int32_t *q_vars,
                                 const int64_t *e_off, const int32_t *e_vars, const int32_t *e_codes,

@@ -461,6 +461,13 @@ __device__ __forceinline__ void sweep_fiber_pairs(double *__restrict__ L, const 
 // the DMA of the NEXT tile is issued before the FMAs and lands under them and the stores.  Lane bits, low to high: the first
 // field d1 (four lanes = the 4 x 4 outputs of a 128-byte line: n = digit 0, then d1), rp, the other fields, the half of the
 // loop digit.  The 4-way bank conflict of the reads (only rp spreads the lanes of a group) is the one this stage had anyway.
+// Vector-memory instructions a lane issues BEHIND dma_next() in sweep_last_stage_out: two loop-digit halves x four unconditional
+// 16-byte stores.  sweep_tiles_dma's wait for the next tile's DMA is `s_waitcnt vmcnt(kSweepOwnTailStores)` - correct only while
+// (a) exactly this many VMEM operations follow the DMA in program order, none of them predicated away, and (b) the vector-memory
+// operations of a wave retire in order (gfx9: loads and stores share one in-order vmcnt).  Both uses name this constant.
+constexpr int kSweepOwnTailHalves = 2, kSweepOwnTailStoresPerHalf = 4;
+constexpr int kSweepOwnTailStores = kSweepOwnTailHalves * kSweepOwnTailStoresPerHalf;
+
 template <int K, bool PAR, class DmaNext>
 __device__ __forceinline__ void sweep_last_stage_out(const double *__restrict__ L, const double *__restrict__ T, double *__restrict__ ot,
                                                      const int tid, const int rg_tile, const uint32_t s1, const uint32_t (&cw)[3],
@@ -508,7 +515,7 @@ __device__ __forceinline__ void sweep_last_stage_out(const double *__restrict__ 
     dma_next();
     double t0[16];
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < kSweepOwnTailHalves; ++l) {
         double s0[4], s1v[4];
         if (PAR || l == 0 || loop_ts) {
             const double2 *__restrict__ Tp = reinterpret_cast<const double2 *>(T + (toff + l * loop_ts));
@@ -535,6 +542,7 @@ __device__ __forceinline__ void sweep_last_stage_out(const double *__restrict__ 
         // output cell: digits as in LDS (identity), r slowest: c = n + c_hi + (l << 2 loop) + 4^K r
         double *__restrict__ o0 = ot + (c_hi + (l << (2 * G.loop)) + ((2 * rp) << (2 * K)));
         double *__restrict__ o1 = o0 + (1 << (2 * K));
+        static_assert(kSweepOwnTailStoresPerHalf == 4, "the four unconditional stores below are what vmcnt(kSweepOwnTailStores) counts");
         *reinterpret_cast<double2 *>(o0) = make_double2(s0[0], s0[1]);
         *reinterpret_cast<double2 *>(o0 + 2) = make_double2(s0[2], s0[3]);
         *reinterpret_cast<double2 *>(o1) = make_double2(s1v[0], s1v[1]);
@@ -739,7 +747,8 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
         // last stage (sweep_last_stage_out) and the vector-memory operations of a wave retire in order, so "at most eight
         // operations outstanding" means the DMA is done - the wave does not sit out the write acknowledgements of its stores
         // (DEAD: a wave may have stored less - or nothing - after its DMA: it drains)
-        if (OWN && !DEAD && MIBN_SWEEP_VMCNT == 8 && i > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        static_assert(MIBN_SWEEP_VMCNT == 0 || MIBN_SWEEP_VMCNT == kSweepOwnTailStores, "the wait must leave exactly the tail's stores in flight");
+        if (OWN && !DEAD && MIBN_SWEEP_VMCNT == kSweepOwnTailStores && i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kSweepOwnTailStores) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MIBN_PROF_TICK(1)
         __syncthreads();  // ... and everybody else's (first tile: T is complete)
