@@ -281,6 +281,32 @@ def wide_fixture():
     netspec.save(os.path.join(HERE, "wide_cards.json"), nets)
 
 
+def huge_fixture():
+    """Cardinalities far above the kernels' compile-time shapes (the reference's join has no limit,
+    bayes_net.py:233-250): random DAGs of 5-8 nodes whose cardinalities come from {2, 3, 17, 33, 64, 100} - axes of 17 ... 100
+    states in the GENERIC / FIBER runtime-cx / runtime-NC kernels - with CPTs capped at 12 000 cells (the recipe is stored, not the
+    CPTs: golden_util.dag_spec_from_recipe), zeros and missing rows as in the other DAG fixtures; plus chains / a 2x2 grid of one
+    huge cardinality."""
+    out = []
+    for k, (seed, n, cards) in enumerate([(300, 5, (17, 33, 64, 100)), (301, 6, (2, 3, 17, 33, 64, 100)), (302, 7, (3, 17, 100)),
+                                          (303, 8, (2, 17, 33, 64)), (304, 6, (33, 100)), (305, 5, (64, 100))]):
+        recipe = {"name": f"huge_dag{k}", "seed": seed, "n_nodes": n, "cards": list(cards), "max_parents": 2, "max_cells": 12000,
+                  "labels": "str" if k % 2 else "int"}
+        entry = {"recipe": recipe}
+        r = dict(recipe)
+        name = r.pop("name")
+        spec = netspec.random_dag_spec(r.pop("seed"), cards=tuple(r.pop("cards")), **r)
+        spec["name"] = name
+        entry["cpt_sum_hex"] = float(sum(row[-1] for c in spec["cpts"].values() for row in c["rows"])).hex()
+        entry["cards"] = {nm: len(d) for nm, d in netspec.domains(spec).items()}
+        bn = netspec.build(spec, sorobn.BayesNet, wrap=refload.HashedName)
+        reqs = random_requests(spec, 12, seed=3000 + k, max_q=1, max_e=3) + random_requests(spec, 2, seed=3100 + k, max_q=2, max_e=2)
+        entry["requests"] = run_requests(bn, reqs, refload.HashedName)
+        out.append(entry)
+        print("huge dag", k, entry["cards"], [r["ref_seconds"] for r in entry["requests"]], flush=True)
+    netspec.save(os.path.join(HERE, "huge_cards.json"), out)
+
+
 def many_nodes_fixture():
     """Networks with more than 128 variables: the planner's generic (kMaxVars-wide) bitset paths instead of the
     two-word fast paths."""
@@ -375,7 +401,7 @@ if __name__ == "__main__":
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide", "many", "joint", "learn"]
+    todo = a.only.split(",") if a.only else ["examples", "impute", "dags", "grids", "wide", "many", "huge", "joint", "learn"]
     if "examples" in todo:
         examples_fixture()
     if "impute" in todo:
@@ -390,6 +416,8 @@ if __name__ == "__main__":
         wide_fixture()
     if "many" in todo:
         many_nodes_fixture()
+    if "huge" in todo:
+        huge_fixture()
     if "joint" in todo:
         joint_fixture()
     if "learn" in todo:

@@ -39,3 +39,15 @@ def grid_spec_from_recipe(entry):
     s = float(sum(row[-1] for c in spec["cpts"].values() for row in c["rows"]))
     assert s.hex() == entry["cpt_sum_hex"], "grid recipe drifted from the golden generator"
     return spec
+
+
+def dag_spec_from_recipe(entry):
+    """huge_cards.json stores the recipe of a random DAG (cardinalities up to 100: its CPTs would be megabytes of JSON), not the
+    CPTs; the sum of all CPT numbers pins the regenerated network to the one the reference answered."""
+    r = dict(entry["recipe"])
+    name = r.pop("name")
+    spec = netspec.random_dag_spec(r.pop("seed"), cards=tuple(r.pop("cards")), **r)
+    spec["name"] = name
+    s = float(sum(row[-1] for c in spec["cpts"].values() for row in c["rows"]))
+    assert s.hex() == entry["cpt_sum_hex"], "DAG recipe drifted from the golden generator"
+    return spec

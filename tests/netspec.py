@@ -138,8 +138,9 @@ def mixed_grid_spec(R, C, cards, seed):
 
 
 def random_dag_spec(seed, n_nodes=None, max_parents=3, cards=(2, 3, 4, 5), p_zero=0.08,
-                    p_missing=0.05, labels="int"):
-    """Random DAG with mixed cardinalities, Dirichlet CPTs, some exact zeros and missing rows."""
+                    p_missing=0.05, labels="int", max_cells=None):
+    """Random DAG with mixed cardinalities, Dirichlet CPTs, some exact zeros and missing rows.  `max_cells` (cardinalities in the
+    hundreds): parents are dropped from the end until a CPT has at most that many cells (consumes no random numbers)."""
     rng = np.random.default_rng(seed)
     n = int(n_nodes or rng.integers(4, 13))
     names = [f"{i:03d}" for i in range(n)]
@@ -152,6 +153,8 @@ def random_dag_spec(seed, n_nodes=None, max_parents=3, cards=(2, 3, 4, 5), p_zer
     for i in range(n):
         k = int(rng.integers(0, min(i, max_parents) + 1))
         ps = sorted(rng.choice(i, size=k, replace=False).tolist()) if k else []
+        while max_cells and ps and card[i] * int(np.prod([card[p] for p in ps])) > max_cells:
+            ps = ps[:-1]
         parents[i] = ps
         edges += [[names[p], names[i]] for p in ps]
     cpts = {}

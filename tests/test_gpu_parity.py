@@ -118,6 +118,29 @@ def test_golden_networks(amd, fname, small_cells, tiling, fuse):
         _check_requests(bn, net["requests"], net["spec"]["name"])
 
 
+@pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (1, (2, 1), 1), (6, (8, 3), 1), (1, (2, 1), 0)])
+def test_golden_huge_cardinalities(amd, small_cells, tiling, fuse):
+    """the reference's join has no cardinality limit (bayes_net.py:233-250); the goldens stopped at 16.  Random DAGs
+    with axes of 17, 33, 64 and 100 states (tests/golden/huge_cards.json: the reference's answers, networks regenerated from their
+    recipes) through the GENERIC / FIBER kernels with the same forcing options as test_golden_networks - the streaming forms and the
+    tiled levels on tables they would normally never see - and the kernels' classes that actually ran are recorded."""
+    seen = set()
+    for entry in gu.load("huge_cards.json"):
+        spec = gu.dag_spec_from_recipe(entry)
+        bn = netspec.build(spec, amd.BayesNet)
+        eng = bn.backend.engine
+        eng.set_option("tiny", 0)
+        eng.set_option("small_cells", small_cells)
+        eng.set_option("big_iters", tiling[0])
+        eng.set_option("tile_h", tiling[1])
+        eng.set_option("fuse", fuse)
+        eng.set_option("split_kinds", 1)  # one launch per class: the statistics name the classes
+        _check_requests(bn, entry["requests"], spec["name"])
+        seen.update(k["name"] for k in eng.kernel_stats())
+    assert seen and "tiny_kernel" not in seen, seen
+    print(f"huge cardinalities, small_cells {small_cells} tiling {tiling} fuse {fuse}: classes run = {sorted(seen)}")
+
+
 @pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (3, (4, 1), 1), (20, (64, 2), 1), (3, (4, 1), 0)])
 def test_golden_small_grids(amd, small_cells, tiling, fuse):
     for entry in gu.load("grids_small.json"):

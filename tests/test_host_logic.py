@@ -155,6 +155,15 @@ def test_planner_programs_reproduce_reference(fname, small_cells, tiling, fuse):
         _check_requests(bn, net["requests"], net["spec"]["name"], limit=None if small_cells == 1024 else 60)
 
 
+@pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (1, (2, 1), 1), (6, (8, 3), 1), (1, (2, 1), 0)])
+def test_planner_programs_reproduce_reference_huge_cardinalities(small_cells, tiling, fuse):
+    """Axes of 17 ... 100 states (huge_cards.json): the planner's programs on the CPU plan simulator against the reference."""
+    for entry in _nets("huge_cards.json"):
+        spec = gu.dag_spec_from_recipe(entry)
+        bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet), small_cells, tiling, fuse)
+        _check_requests(bn, entry["requests"], spec["name"])
+
+
 @pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (3, (4, 1), 1), (20, (64, 2), 1), (3, (4, 1), 0)])
 def test_planner_programs_reproduce_reference_grids(small_cells, tiling, fuse):
     for entry in _nets("grids_small.json"):

@@ -126,6 +126,12 @@ def test_oracle_reproduces_reference_networks(fname):
     assert total > {"wide_cards.json": 150, "many_nodes.json": 25}.get(fname, 500)
 
 
+def test_oracle_reproduces_reference_huge_cardinalities():
+    """Cardinalities 17 ... 100 (huge_cards.json): the reference's answers on regenerated DAG recipes."""
+    total = sum(_check_net(gu.dag_spec_from_recipe(e), e["requests"]) for e in gu.load("huge_cards.json"))
+    assert total == 6 * 14
+
+
 def test_oracle_reproduces_reference_small_grids():
     for entry in gu.load("grids_small.json"):
         _check_net(gu.grid_spec_from_recipe(entry), entry["requests"])
