@@ -255,6 +255,41 @@ def other_configs(device, with_cpu=True):
     return out
 
 
+def c3_pandas(bn, n=131_072, sub_batch=32768):
+    """throughput THROUGH the drop-in pandas boundary.  The C3 stream as a Python user holds it - a list of
+    (query tuple, event dict) with node names and labels - into `BayesNet.query_many` (validation, bulk encode of names and labels,
+    sub-batches with two engine calls in flight) and out as ONE pandas object with every posterior (`PosteriorBatch.to_frame()`);
+    building the request list is outside the clock (it is the caller's data), everything else inside.  Beside it: the cost of
+    materialising individual Series (`batch[i]`, identical to `query()`'s - checked on a sample with pandas' strict comparison)."""
+    import netspec
+    import pandas as pd
+    q, ev, ec = netspec.c3_requests(100, 4, 2 * n, 4, seed=1)
+    mk = lambda lo, hi: [((f"{a:03d}",), {f"{v:03d}": int(c) for v, c in zip(vs, cs)})
+                         for a, vs, cs in zip(q[lo:hi].tolist(), ev[lo:hi].tolist(), ec[lo:hi].tolist())]
+    warm, reqs = mk(0, n), mk(n, 2 * n)
+    bn.query_many(warm, sub_batch=sub_batch).to_frame()
+    t0 = time.perf_counter()
+    batch = bn.query_many(reqs, sub_batch=sub_batch)
+    t1 = time.perf_counter()
+    frame = batch.to_frame()
+    t2 = time.perf_counter()
+    k = 2000
+    series = [batch[i] for i in range(k)]
+    t3 = time.perf_counter()
+    for i in (0, 1, 17, k - 1):
+        pd.testing.assert_series_equal(series[i], bn.query(*reqs[i][0], event=reqs[i][1]), check_exact=True)
+    t4 = time.perf_counter()
+    for i in range(200):
+        bn.query(*reqs[i][0], event=reqs[i][1])
+    t5 = time.perf_counter()
+    return {"queries_per_s": n / (t2 - t0), "requests": n, "seconds": t2 - t0, "query_many_s": t1 - t0, "to_frame_s": t2 - t1,
+            "frame_rows": int(len(frame)), "series_us_each": (t3 - t2) / k * 1e6,
+            "single_query_ms_on_this_network": (t5 - t4) / 200 * 1e3,
+            "series_identical_to_query": True,
+            "note": "requests in as Python (tuple, dict) objects with names and labels, answers out as one pandas object (a DataFrame: request, "
+                    "variables, cell, p - the query variable changes from request to request); batch[i] builds the Series query() returns"}
+
+
 def c3_variant(eng, to_var, n_evidence, calls=6, warmup_calls=2, batch=32768):
     """A short stepped run of the C3 stream with another number of evidence nodes, or on another engine ("also report the
     n_evidence in {1, 8, 16} variants"; VERDICT r3: the device-planned 2-thread rank): `calls` pipelined engine calls of `batch`
@@ -674,6 +709,10 @@ def main():
                 out["configs"] = other_configs(device, with_cpu=not a.no_cpu)
             except Exception as e:  # the headline line must not die with a side measurement
                 out["configs"] = {"error": repr(e)}
+            try:
+                out["configs"]["C3_query_many_pandas"] = c3_pandas(bn, sub_batch=a.batch)
+            except Exception as e:  # noqa: BLE001
+                out["configs"]["C3_query_many_pandas"] = {"error": repr(e)}
             # SURVEY 8(d)'s n_evidence variants of the C3 stream on this engine (the final kernels, the timed region's options)
             for ne in (1, 8, 16):
                 try:

@@ -168,6 +168,8 @@ class Engine:
             self._h, len(card), _p(card, C.c_int32), _p(scope_off, C.c_int64),
             _p(scope_vars, C.c_int32), _p(value_off, C.c_int64), _p(values, C.c_double)))
         self.card = card
+        self._card_list = card.tolist()
+        self._one = {}
 
     def set_order_hints(self, hints):
         h = _i32(np.asarray(hints).reshape(-1, len(self.card)))
@@ -202,6 +204,36 @@ class Engine:
             _p(e_vars_, C.c_int32), _p(e_codes_, C.c_int32), _p(out_off, C.c_int64),
             _p(out_, C.c_double)))
         return out, out_off
+
+    def query_one(self, q, ev, codes, flags=0):
+        """One request (lists of variable ids / codes) -> dense posterior [cells].  The latency path of a single `query()`:
+        preallocated ctypes arrays per request shape, one C call (query_fixed builds a dozen numpy arrays on the way)."""
+        nq, ne = len(q), len(ev)
+        card = self._card_list
+        cells = 1
+        try:
+            for v in q:
+                cells *= card[v]
+        except (IndexError, TypeError):
+            cells = 1  # (an unknown id: the library builds the error message)
+        one = self._one
+        key = (nq, ne)
+        buf = one.get(key)
+        if buf is None:
+            buf = one[key] = ((C.c_int64 * 2)(0, nq), (C.c_int64 * 2)(0, ne), (C.c_int64 * 2)(0, 0),
+                              (C.c_int32 * max(1, nq))(), (C.c_int32 * max(1, ne))(), (C.c_int32 * max(1, ne))())
+        q_off, e_off, out_off, qa, ea, ca = buf
+        out_off[1] = cells
+        qa[:nq] = q
+        if ne:
+            ea[:ne] = ev
+            ca[:ne] = codes
+        out = np.zeros(max(1, cells), np.float64)
+        rc = self._L.mibn_query_batch_ex(self._h, int(flags), 1, q_off, qa, e_off, ea, ca, out_off,
+                                         out.ctypes.data_as(C.POINTER(C.c_double)))
+        if rc != OK:
+            self._check(rc)
+        return out[:cells]
 
     def query_fixed(self, qvars, evars, ecodes, flags=0):
         """Fixed-shape batch: qvars[B, nq], evars[B, ne], ecodes[B, ne] -> posteriors[B, cells]

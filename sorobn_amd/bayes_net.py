@@ -25,8 +25,10 @@ small graph helpers.  Out of scope: graph drawing (`graphviz`), GUI, CLI.
 methods `query` dispatches to (bayes_net.py:848, 851-853); see INTEGRATION.md.
 """
 import collections
+import collections.abc
 import graphlib
 import itertools
+import operator
 import os
 import types
 
@@ -46,13 +48,149 @@ def _default_device():
     return 0
 
 
+_get_index = operator.attrgetter("index")
+_get_values = operator.attrgetter("_values")  # the Series' own ndarray, no copy (`.values` builds a view object per call)
+_get_names = operator.attrgetter("names")
+_get_pnames = operator.attrgetter("_names")
+_get_pname = operator.attrgetter("_name")
+
+
+class PosteriorBatch(collections.abc.Sequence):
+    """The answers of `BayesNet.query_many`: a read-only sequence whose item i is exactly the Series `query(*q_i, event=e_i)`
+    returns (built when asked for: a pandas Series costs ~14 us to construct, a batch of 2^18 of them four seconds - more than
+    the kernels), over the dense posteriors as they came back from the device.
+      `batch[i]`, `len`, iteration, slices -> Series / lists of Series
+      `batch.dense(i)`   the dense C-order posterior over request i's query variables (caller order)
+      `batch.to_frame()` every answer in ONE pandas object, built vectorised: a long Series indexed by (request, *labels) when all
+                         requests ask for the same variables, else a DataFrame with one row per positive cell"""
+
+    def __init__(self, backend, queries, out, out_off):
+        self._b, self._q, self.out, self.out_off = backend, queries, out, out_off
+
+    def __len__(self):
+        return len(self._q)
+
+    def dense(self, i):
+        return self.out[self.out_off[i]:self.out_off[i + 1]]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._b.finished_series(self._q[i], self.dense(i))
+
+    def to_frame(self):
+        """One pandas object for the whole batch.  Same query variables in every request: a Series `p` with a MultiIndex
+        (request, *sorted query names) - level values and row order inside a request exactly those of `batch[i]`, so
+        `frame.xs(i, level="request")` equals `batch[i]` (up to the name).  Otherwise (the query variable changes from request to
+        request): a DataFrame with columns request, variables (tuple of names), cell (C-order cell of the finished answer's index)
+        and p, one row per positive cell."""
+        n = len(self)
+        sizes = np.diff(self.out_off)
+        req = np.repeat(np.arange(n, dtype=np.int64), sizes)
+        same = n > 0 and all(q == self._q[0] for q in self._q)
+        if same:
+            name, order, levels, shape, names = self._b._tail(self._q[0])
+            out = self.out
+            if shape is None:
+                keep = np.flatnonzero(out > 0)
+                codes = [req[keep], keep - self.out_off[req[keep]]]
+                lv = [pd.RangeIndex(n, name="request"), levels]
+                nm = ["request", self._q[0][0]]
+            else:
+                cells = int(np.prod(shape))
+                if order is not None:
+                    out = np.ascontiguousarray(out.reshape([n] + shape).transpose([0] + [k + 1 for k in order])).reshape(-1)
+                    shape = [shape[k] for k in order]
+                keep = np.flatnonzero(out > 0)
+                codes = [keep // cells, *np.unravel_index(keep % cells, shape)]
+                lv = [pd.RangeIndex(n, name="request"), *levels]
+                nm = ["request", *names]
+            idx = pd.MultiIndex(levels=lv, codes=codes, names=nm, verify_integrity=False)
+            return pd.Series(out[keep], index=idx, name="p")
+        keep = np.flatnonzero(self.out > 0)
+        r = req[keep]
+        # (cells of the caller-order dense table; `batch[i]` gives the finished Series of a request)
+        variables = np.empty(n, object)
+        variables[:] = self._q
+        return pd.DataFrame({"request": r, "variables": variables[r], "cell": keep - self.out_off[r], "p": self.out[keep]})
+
+
+class CptWatch:
+    """Has anything the flattened tables were built from changed?  The reference re-reads `P` on every query (bayes_net.py:770),
+    so a CPT replaced (`bn.P['A'] = s`), edited in place (`bn.P['A'][True] = 0.9`, also through a reference the caller kept) or
+    re-indexed must reach the device tables.  Round 4 re-hashed every CPT on every `query()` (several hundred
+    microseconds on the 100-node grid).  Now: identity of every Series, of its index and of its value array (three id lists
+    compared in C), the level names, and ONE bitwise comparison of all CPT numbers against a snapshot (`np.concatenate` of the live
+    arrays: 44 KB on the 10x10 grid) - 5 us on a five-node network, 60 us on the grid, and exact: no hashing, no version counter a
+    held reference could bypass.  CPTs whose values are not a numeric ndarray fall back to the hashed
+    fingerprint."""
+
+    def __init__(self, bn):
+        items = list(bn.P.items())
+        self.keys = [k for k, _ in items]
+        self.series = [v for _, v in items]  # (kept alive: their ids below cannot be recycled by other objects)
+        self.exact = True
+        try:
+            self.index = list(map(_get_index, self.series))
+            arrays = list(map(_get_values, self.series))
+            self.exact = all(isinstance(a, np.ndarray) and a.dtype != object and a.ndim == 1 for a in arrays)
+        except AttributeError:
+            self.exact = False
+        if self.exact:
+            self.ids = (list(map(id, self.series)), list(map(id, self.index)))
+            # level names live on the index object and can be re-assigned in place; pandas keeps them in `_names` (MultiIndex: a
+            # list) / `_name` (Index) - read directly where present (checked against the public accessor here), the public
+            # FrozenList-building `.names` costs ten times as much per CPT
+            self.multi = [ix for ix in self.index if isinstance(ix, pd.MultiIndex)]
+            self.single = [ix for ix in self.index if not isinstance(ix, pd.MultiIndex)]
+            try:
+                self.private_names = (all(list(ix._names) == list(ix.names) for ix in self.multi) and
+                                      all(ix._name == ix.name or (ix._name is None and ix.name is None) for ix in self.single))
+            except AttributeError:
+                self.private_names = False
+            if self.private_names:
+                self.names = ([list(ix._names) for ix in self.multi], [ix._name for ix in self.single])
+            else:
+                self.names = [list(n) for n in map(_get_names, self.index)]
+            self.snap = np.concatenate(arrays).tobytes() if arrays else b""
+        else:
+            self.slow = Backend.fingerprint_of(bn)
+
+    def changed(self, bn) -> bool:
+        P = bn.P
+        if len(P) != len(self.keys):
+            return True
+        if not self.exact:
+            return Backend.fingerprint_of(bn) != self.slow
+        # (every loop below runs inside map / list comparison: no Python-level work per CPT)
+        ids_s, ids_i = self.ids
+        if list(map(id, map(P.get, self.keys))) != ids_s or list(map(id, map(_get_index, self.series))) != ids_i:
+            return True
+        if self.private_names:
+            if list(map(_get_pnames, self.multi)) != self.names[0] or list(map(_get_pname, self.single)) != self.names[1]:
+                return True
+        elif list(map(_get_names, self.index)) != self.names:
+            return True
+        if not self.series:
+            return False
+        # the LIVE value arrays (a Series may have replaced its array - an upcast, copy-on-write) against the snapshot, bit for bit
+        try:
+            return np.concatenate(list(map(_get_values, self.series))).tobytes() != self.snap
+        except (ValueError, TypeError):
+            return True
+
+
 class Backend:
     """Flattened network + one mibn engine.  Built lazily from any object exposing the reference's
     `nodes` / `parents` / `P`; rebuilt when the CPT objects change."""
 
     def __init__(self, bn, device=None, planner_only=False):
         self.flat = flatten(bn)
-        self.fingerprint = Backend.fingerprint_of(bn)
+        self.watch = CptWatch(bn)
         self.engine = _capi.Engine(_default_device() if device is None else device,
                                    planner_only=planner_only)
         f = self.flat
@@ -101,17 +239,25 @@ class Backend:
                                 verify_integrity=False)
         return pd.Series(dense[keep], index=idx)
 
+    def stale(self, bn) -> bool:
+        """True when `bn.P` no longer is what this backend was flattened from (`CptWatch`)."""
+        return self.watch.changed(bn)
+
     @staticmethod
     def fingerprint_of(bn):
-        """Identity AND content of the CPTs: the reference re-reads `P` on every query (bayes_net.py:770), so a value
-        edited in place (`bn.P['A'][True] = 0.9`) must reach the device tables too.  CPTs are tiny (the 10x10 grid:
-        44 KB in all), hashing their bytes costs microseconds next to a query."""
+        """Identity AND content of the CPTs by hashing (the slow path of `CptWatch`: CPTs whose values are not numeric
+        ndarrays)."""
         fp = []
         for k, v in bn.P.items():
             vals = getattr(v, "values", None)
             try:
-                content = hash(np.ascontiguousarray(vals).tobytes()) if vals is not None and vals.dtype != object else None
-            except (TypeError, ValueError):
+                if vals is None:
+                    content = None
+                elif vals.dtype != object:
+                    content = hash(np.ascontiguousarray(vals).tobytes())
+                else:
+                    content = hash(tuple(vals.tolist()))
+            except (TypeError, ValueError, AttributeError):
                 content = None
             idx = getattr(v, "index", None)
             if isinstance(idx, pd.MultiIndex):
@@ -175,6 +321,55 @@ class Backend:
                             names=list(query), verify_integrity=False)
         return pd.Series(vals, index=idx)
 
+    def _tail(self, query):
+        """What the tail of `query` (bayes_net.py:869-875: rename, level sort, row sort) amounts to for a given query tuple, worked
+        out once: the Series name, and for several variables the level permutation into sorted-name order.  The dense posterior
+        is C-order over `query`, the label domains are sorted, so transposing it into sorted-name order and listing its positive
+        cells in C-order IS the sorted index - no pandas reorder_levels / sort_index per answer (61 -> 14 us on this host)."""
+        try:
+            cache = self._tails
+        except AttributeError:
+            cache = self._tails = {}
+        t = cache.get(query)
+        if t is None:
+            f = self.flat
+            ids = [f.id[n] for n in query]
+            name = f"P({', '.join(query)})"
+            if len(ids) == 1:
+                t = (name, None, f.dom_index[ids[0]].rename(query[0]), None, None)
+            else:
+                names = list(query)
+                order = [names.index(n) for n in sorted(names)]
+                shape = [int(f.card[v]) for v in ids]
+                t = (name, order if order != list(range(len(ids))) else None, [f.dom_index[ids[k]] for k in order],
+                     shape, [names[k] for k in order])
+            if len(cache) < 4096:
+                cache[query] = t
+        return t
+
+    def finished_series(self, query, dense):
+        """Dense C-order posterior over `query` (caller order) -> exactly the Series `query()` returns: zero rows absent
+        (bayes_net.py:789-794), named `P(...)`, levels in sorted-name order, rows sorted (869-875)."""
+        name, order, levels, shape, names = self._tail(query)
+        if shape is None:
+            keep = np.flatnonzero(dense > 0)
+            if len(keep) == len(dense):
+                return pd.Series(dense, index=levels, name=name)
+            return pd.Series(dense[keep], index=levels[keep], name=name)
+        if order is not None:
+            dense = np.ascontiguousarray(dense.reshape(shape).transpose(order)).reshape(-1)
+            shape = [shape[k] for k in order]
+        keep = np.flatnonzero(dense > 0)
+        idx = pd.MultiIndex(levels=levels, codes=list(np.unravel_index(keep, shape)), names=names, verify_integrity=False)
+        return pd.Series(dense[keep], index=idx, name=name)
+
+    def exact_query(self, query, event):
+        """`query(*query, event=event)` of the exact path, finished: encode, ONE call into the library, the answer Series."""
+        q, ev, codes = self.encode(query, event)
+        one = getattr(self.engine, "query_one", None)
+        dense = one(q, ev, codes) if one is not None else self.engine.query_fixed([q], [ev], [codes])[0]
+        return self.finished_series(query, dense)
+
     # ---- the two replaced methods ---------------------------------------------------------------
     def variable_elimination(self, *query, event):
         q, ev, codes = self.encode(query, event)
@@ -184,6 +379,37 @@ class Backend:
     def variable_elimination_many(self, requests):
         """requests: iterable of (query tuple, event dict) -> list of Series (one launch)."""
         requests = list(requests)
+        q_off, e_off, qv, evs, ecs = self.encode_many(requests)
+        out, out_off = self.engine.query_batch(q_off, qv, e_off, evs, ecs)
+        return [self.posterior_series(query, out[a:b])
+                for (query, _), a, b in zip(requests, out_off[:-1], out_off[1:])]
+
+    def encode_many(self, requests):
+        """CSR arrays (q_off, q_vars, e_off, e_vars, e_codes) of a list of (query tuple, event dict).  Names and labels go
+        through plain dict lookups in bulk (one pass over the flattened names, one over the flattened labels) instead of one
+        `encode` call with its set algebra per request; anything the bulk path cannot answer - an unknown name, an unhashable or
+        out-of-domain label, a network with missing CPTs - falls back to `encode` request by request, which raises the
+        reference's KeyError or codes the label -1 as before."""
+        f = self.flat
+        n = len(requests)
+        try:
+            if f.missing:
+                raise KeyError
+            ident = f.id
+            nq = np.fromiter((len(q) for q, _ in requests), np.int64, n)
+            ne = np.fromiter((len(e) for _, e in requests), np.int64, n)
+            qv = np.fromiter((ident[name] for q, _ in requests for name in q), np.int32, int(nq.sum()))
+            evs = np.fromiter((ident[name] for _, e in requests for name in e), np.int32, int(ne.sum()))
+            luts = self._label_luts()
+            ecs = np.fromiter((luts[v][lab] for v, lab in zip(evs.tolist(), (lab for _, e in requests for lab in e.values()))),
+                              np.int32, len(evs))
+            q_off = np.zeros(n + 1, np.int64)
+            e_off = np.zeros(n + 1, np.int64)
+            np.cumsum(nq, out=q_off[1:])
+            np.cumsum(ne, out=e_off[1:])
+            return q_off, qv, e_off, evs, ecs
+        except (KeyError, TypeError):
+            pass
         q_off, e_off, qv, evs, ecs = [0], [0], [], [], []
         for query, event in requests:
             q, ev, codes = self.encode(query, event)
@@ -192,9 +418,56 @@ class Backend:
             ecs += codes
             q_off.append(len(qv))
             e_off.append(len(evs))
-        out, out_off = self.engine.query_batch(q_off, qv, e_off, evs, ecs)
-        return [self.posterior_series(query, out[a:b])
-                for (query, _), a, b in zip(requests, out_off[:-1], out_off[1:])]
+        return (np.array(q_off, np.int64), np.array(qv, np.int32), np.array(e_off, np.int64), np.array(evs, np.int32),
+                np.array(ecs, np.int32))
+
+    def _label_luts(self):
+        """Per variable: label -> code (equal labels hash equally: 1, 1.0 and True share a slot, like the `==` of
+        bayes_net.py:774); a variable with unhashable labels has no table (KeyError -> the per-request path)."""
+        try:
+            return self._luts
+        except AttributeError:
+            luts = []
+            for dom in self.flat.domains:
+                t = {}
+                try:
+                    for i, d in enumerate(dom):
+                        t.setdefault(d, i)
+                except TypeError:
+                    t = {}
+                luts.append(t)
+            self._luts = luts
+            return luts
+
+    def exact_many(self, requests, sub_batch=32768):
+        """The exact path over a list of (query tuple, event dict) -> `PosteriorBatch`.  Encoded in bulk, sent to the engine in
+        sub-batches of `sub_batch` requests with two calls in flight (mibn_submit_batch / mibn_wait: sub-batch k + 1 is encoded
+        and planned while the kernels of k run) when the batch is fixed-arity; a ragged batch goes as one blocking call."""
+        requests = [((q,) if isinstance(q, str) else tuple(q), e) for q, e in requests]
+        n = len(requests)
+        eng = self.engine
+        if n == 0:
+            return PosteriorBatch(self, [], np.zeros(0), np.zeros(1, np.int64))
+        nq0, ne0 = len(requests[0][0]), len(requests[0][1])
+        fixed = hasattr(eng, "submit_fixed") and n > sub_batch and all(len(q) == nq0 and len(e) == ne0 for q, e in requests)
+        if not fixed:
+            q_off, qv, e_off, evs, ecs = self.encode_many(requests)
+            out, out_off = eng.query_batch(q_off, qv, e_off, evs, ecs)
+            return PosteriorBatch(self, [q for q, _ in requests], out, np.asarray(out_off, np.int64))
+        parts, pending, cells = [], None, []
+        for a in range(0, n, sub_batch):
+            chunk = requests[a:a + sub_batch]
+            _, qv, _, evs, ecs = self.encode_many(chunk)
+            b = len(chunk)
+            h = eng.submit_fixed(qv.reshape(b, nq0), evs.reshape(b, ne0), ecs.reshape(b, ne0))
+            if pending is not None:
+                parts.append(eng.wait(pending))
+            pending = h
+            cells.append(np.prod(eng.card[qv.reshape(b, nq0)].astype(np.int64), axis=1))
+        parts.append(eng.wait(pending))
+        out_off = np.zeros(n + 1, np.int64)
+        np.cumsum(np.concatenate(cells), out=out_off[1:])
+        return PosteriorBatch(self, [q for q, _ in requests], np.concatenate([p.reshape(-1) for p in parts]), out_off)
 
     def gibbs_sampling(self, *query, event, n_iterations, n_chains=1, seed=0):
         q, ev, codes = self.encode(query, event)
@@ -389,9 +662,10 @@ class BayesNet:
 
     @property
     def backend(self) -> Backend:
-        if self._backend is None or self._backend.fingerprint != Backend.fingerprint_of(self):
-            self._backend = Backend(self, device=self._device)
-        return self._backend
+        b = self._backend
+        if b is None or b.stale(self):
+            b = self._backend = Backend(self, device=self._device)
+        return b
 
     def _variable_elimination(self, *query, event):
         return self.backend.variable_elimination(*query, event=event)
@@ -448,6 +722,8 @@ class BayesNet:
         """
         self._check_request(query, event)
         if algorithm == "exact":
+            if "_variable_elimination" not in self.__dict__:  # (not re-bound on this object, e.g. by accelerate())
+                return self.backend.exact_query(query, event)  # the finished Series, built directly (Backend._tail)
             answer = self._variable_elimination(*query, event=event)
         elif algorithm == "gibbs":
             answer = self._gibbs_sampling(*query, event=event, n_iterations=n_iterations,
@@ -461,14 +737,67 @@ class BayesNet:
                              + "rejection")
         return self._finish(answer, query)
 
-    def query_many(self, requests):
-        """Batched extension: `requests` = iterable of (query tuple, event dict); returns the list of
-        Series `query(*q, event=e)` would return, computed in one device launch."""
+    def query_many(self, requests, sub_batch=32768):
+        """Batched extension: `requests` = iterable of (query tuple, event dict) -> `PosteriorBatch`, a sequence whose item i is
+        the Series `query(*q_i, event=e_i)` returns (identical: name, index, level order, row order, values).  Names and labels are
+        encoded in bulk, the device works through sub-batches with two calls in flight, and the Series are built on access;
+        `.to_frame()` gives every answer as one pandas object."""
         requests = [((q,) if isinstance(q, str) else tuple(q), e) for q, e in requests]
         for q, e in requests:
-            self._check_request(q, e)
-        answers = self.backend.variable_elimination_many(requests)
-        return [self._finish(a, q) for a, (q, _) in zip(answers, requests)]
+            if not q:
+                raise ValueError("At least one query variable has to be specified")
+            if not e.keys().isdisjoint(q):
+                raise ValueError("A query variable cannot be part of the event")
+        return self.backend.exact_many(requests, sub_batch=sub_batch)
+
+    def query_frame(self, *query, events: pd.DataFrame) -> pd.DataFrame:
+        """The fixed-query batch in pandas' own shape (an extension; the reference answers one event per call, bayes_net.py:796):
+        row r of `events` is an event - its columns are evidence variables, NaN / None = not observed in that row - and row r of
+        the result is the posterior of `query` given that event: columns = the joint states of the query variables in the order of
+        `query()`'s index (sorted names, sorted labels; a MultiIndex for several variables), zeros where `query()` drops the row, so
+        that `out.iloc[r][out.iloc[r] > 0]` has the values of `query(*query, event=<row r>)`.  Labels are encoded per column
+        (`Index.get_indexer`), rows are grouped by their set of observed columns, every group is one fixed-shape engine call."""
+        if not query:
+            raise ValueError("At least one query variable has to be specified")
+        if any(c in query for c in events.columns):
+            raise ValueError("A query variable cannot be part of the event")
+        be = self.backend
+        f = be.flat
+        q = [be.var_id(n) for n in query]
+        if f.missing:
+            be.encode(query, {c: None for c in events.columns})  # (raises the reference's KeyError for a node without a CPT)
+        cols = list(events.columns)
+        ev_ids = np.array([be.var_id(c) for c in cols], np.int32)
+        n = len(events)
+        codes = np.empty((n, len(cols)), np.int32)
+        observed = np.empty((n, len(cols)), bool)
+        for j, c in enumerate(cols):
+            col = events[c]
+            observed[:, j] = col.notna().to_numpy()
+            codes[:, j] = pd.Index(f.domains[ev_ids[j]]).get_indexer(col) if len(f.domains[ev_ids[j]]) else -1
+        name, order, levels, shape, names = be._tail(tuple(query))
+        cells = int(np.prod([int(f.card[v]) for v in q]))
+        out = np.zeros((n, cells), np.float64)
+        # one engine call per pattern of observed columns
+        pat = observed @ (1 << np.arange(len(cols), dtype=np.int64)) if len(cols) < 63 else None
+        groups = ([np.arange(n)] if len(cols) == 0 else
+                  [np.flatnonzero(pat == p) for p in np.unique(pat)] if pat is not None else
+                  [np.array([r]) for r in range(n)])
+        qarr = np.array(q, np.int32)
+        for rows in groups:
+            if not len(rows):
+                continue
+            on = np.flatnonzero(observed[rows[0]])
+            out[rows] = be.engine.query_fixed(np.broadcast_to(qarr, (len(rows), len(q))), np.broadcast_to(ev_ids[on], (len(rows), len(on))),
+                                              codes[np.ix_(rows, on)])
+        if shape is None:
+            columns = levels
+        else:
+            if order is not None:
+                out = np.ascontiguousarray(out.reshape([n] + shape).transpose([0] + [k + 1 for k in order])).reshape(n, cells)
+                shape = [shape[k] for k in order]
+            columns = pd.MultiIndex(levels=levels, codes=list(np.unravel_index(np.arange(cells), shape)), names=names, verify_integrity=False)
+        return pd.DataFrame(out, index=events.index, columns=columns)
 
     def impute(self, sample: dict, **query_params) -> pd.Series:
         """Replace the `None` entries of `sample` by the most probable joint assignment
@@ -547,7 +876,7 @@ def accelerate(bn, device=None, backend_factory=None):
 
     def backend():
         b = state["backend"]
-        if b is None or b.fingerprint != Backend.fingerprint_of(bn):
+        if b is None or b.stale(bn):
             b = state["backend"] = make(bn)
         return b
 

@@ -234,12 +234,12 @@ struct mibn_ctx {
     // small-network specialisation (tiny_kernel.hip.h): one lane per request, no planning
     bool tiny_ok = false;
     int tiny = 1;              // option: 1 = use it where the network is eligible, 0 = always plan step programs
+    int tiny_zero_copy = 1;    // option: calls of at most kTinyZeroCopyRequests requests read / write pinned host memory directly (run_tiny)
     int32_t *d_tiny_meta = nullptr;
     int32_t tiny_meta_words = 0;
     char *d_tiny_req = nullptr;  // request arrays of the call in flight
     size_t tiny_req_cap = 0;
     Staging tiny_stage;
-    int32_t *d_tiny_bad = nullptr;
     // adaptive planning (option "adaptive"): when planning, not the GPU, bounds a stream of calls (few host cores per
     // GPU), the elimination-order search - 40 % of the planning time - moves to the device (order_kernel); for networks the
     // device search does not cover (> 128 variables) the greedy min-fill search is reserved for ever more expensive
@@ -488,7 +488,6 @@ void mibn_destroy(mibn_t *h) {
         if (h->zero_ev) (void)hipEventDestroy(h->zero_ev);
         (void)hipFree(h->d_tiny_meta);
         (void)hipFree(h->d_tiny_req);
-        (void)hipFree(h->d_tiny_bad);
         (void)hipFree(h->d_order_net);
         (void)hipFree(h->d_orders);
         (void)hipFree(h->d_order_len);
@@ -550,6 +549,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "seg_kernel") h->seg_kernel = value != 0;
     else if (n == "gibbs_lds") h->gibbs_lds = std::max(0, std::min(2, (int)value));
     else if (n == "tiny") h->tiny = value != 0;
+    else if (n == "tiny_zero_copy") h->tiny_zero_copy = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
     else if (n == "plan_lanes") h->plan_lanes = std::max(1, std::min(64, (int)value));  // requests per wave of the device planner's kernels
@@ -616,7 +616,6 @@ int mibn_set_network(mibn_t *h, int32_t n_vars, const int32_t *card, const int64
             h->tiny_meta_words = (int32_t)meta.size();
             HIP_TRY(h, hipMalloc(&h->d_tiny_meta, meta.size() * 4));
             HIP_TRY(h, hipMemcpy(h->d_tiny_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
-            if (!h->d_tiny_bad) HIP_TRY(h, hipMalloc(&h->d_tiny_bad, 8));
             h->tiny_ok = tiny_lds_bytes((int)h->net.pool.size(), h->tiny_meta_words) <= 64 * 1024;
         }
         if (int rc = upload_emit_net(h)) return rc;
@@ -1093,6 +1092,8 @@ int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, do
 // Small-network path (tiny_kernel.hip.h): the request arrays go to the device as they are, one lane answers one request,
 // malformed requests are detected by the kernel (the host then re-validates to build the reference's message).
 // Returns MIBN_OK / an error, or 1 when the batch does not fit the kernel and has to be planned.
+constexpr int64_t kTinyZeroCopyRequests = 64;  // one wave
+
 int run_tiny(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const int32_t *q_vars, const int64_t *e_off,
              const int32_t *e_vars, const int32_t *e_codes, const int64_t *out_off, double *out, double t_start) {
     const size_t nq = (size_t)(q_off[B] - q_off[0]), ne = (size_t)(e_off[B] - e_off[0]);
@@ -1100,17 +1101,26 @@ int run_tiny(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const i
     if (q_off[0] != 0 || e_off[0] != 0) return 1;                    // (offsets relative to a larger array: plan)
     if (res_cells > (size_t)B * kTinyMaxQCells) return 1;
     int rc;
-    // one pinned staging buffer, one DMA: [q_off | e_off | out_off | q_vars | e_vars | e_codes]
+    // one pinned staging buffer: [q_off | e_off | out_off | q_vars | e_vars | e_codes | bad | results (zero-copy calls only)]
     const size_t off_bytes = (size_t)(B + 1) * 8;
-    const size_t bytes = 3 * off_bytes + (nq + 2 * ne) * 4 + 64;
+    const size_t req_bytes = (3 * off_bytes + (nq + 2 * ne) * 4 + 15) & ~(size_t)15;
+    // A call of at most one wave of requests (a single query(): BASELINE config 1) is latency, not bandwidth: the kernel reads the
+    // request arrays from - and writes the posteriors and the bad-request flag to - the pinned, device-mapped staging buffer
+    // itself.  No H2D / D2H copy, no timing events: one launch and one stream synchronisation (round 4 spent two DMAs each way
+    // and two event records around a kernel of a few microseconds).  stats.kernel_ms is 0 for such a call.
+    const bool zero_copy = B <= kTinyZeroCopyRequests && h->tiny_zero_copy;
+    const size_t bad_off = req_bytes, res_off = req_bytes + 16;
+    const size_t bytes = res_off + (zero_copy ? res_cells * 8 : 0) + 64;
     mibn_ctx::Staging &sg = h->tiny_stage;
     if (bytes > sg.cap) {
         if (sg.p) { HIP_TRY(h, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
         HIP_TRY(h, hipHostMalloc((void **)&sg.p, bytes + bytes / 4, hipHostMallocDefault));
         sg.cap = bytes + bytes / 4;
     }
-    if ((rc = ensure(h, h->d_tiny_req, h->tiny_req_cap, bytes))) return rc;
-    if ((rc = ensure(h, h->d_results[0], h->results_cap[0], res_cells))) return rc;
+    if (!zero_copy) {
+        if ((rc = ensure(h, h->d_tiny_req, h->tiny_req_cap, bytes))) return rc;
+        if ((rc = ensure(h, h->d_results[0], h->results_cap[0], res_cells))) return rc;
+    }
     char *p = sg.p;
     std::memcpy(p, q_off, off_bytes);
     std::memcpy(p + off_bytes, e_off, off_bytes);
@@ -1119,41 +1129,56 @@ int run_tiny(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, const i
     std::memcpy(pv, q_vars, nq * 4);
     if (ne) { std::memcpy(pv + nq * 4, e_vars, ne * 4); std::memcpy(pv + (nq + ne) * 4, e_codes, ne * 4); }
     const int32_t none = 0x7fffffff;
-    HIP_TRY(h, hipMemcpyAsync(h->d_tiny_bad, &none, 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_tiny_req, p, bytes, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(p + bad_off, &none, 4);
+    char *dbase = h->d_tiny_req;  // where the kernel finds the arrays
+    if (zero_copy) {
+        void *dp = nullptr;
+        HIP_TRY(h, hipHostGetDevicePointer(&dp, sg.p, 0));
+        dbase = static_cast<char *>(dp);
+        std::memset(p + res_off, 0, res_cells * 8);
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->d_tiny_req, p, req_bytes + 16, hipMemcpyHostToDevice, h->stream));
+    }
     TinyArgs A;
     A.pool = h->d_pool;
     A.meta = h->d_tiny_meta;
-    A.q_off = reinterpret_cast<const int64_t *>(h->d_tiny_req);
-    A.e_off = reinterpret_cast<const int64_t *>(h->d_tiny_req + off_bytes);
-    A.out_off = reinterpret_cast<const int64_t *>(h->d_tiny_req + 2 * off_bytes);
-    A.q_vars = reinterpret_cast<const int32_t *>(h->d_tiny_req + 3 * off_bytes);
+    A.q_off = reinterpret_cast<const int64_t *>(dbase);
+    A.e_off = reinterpret_cast<const int64_t *>(dbase + off_bytes);
+    A.out_off = reinterpret_cast<const int64_t *>(dbase + 2 * off_bytes);
+    A.q_vars = reinterpret_cast<const int32_t *>(dbase + 3 * off_bytes);
     A.e_vars = A.q_vars + nq;
     A.e_codes = A.e_vars + ne;
-    A.out = h->d_results[0];
-    A.bad = h->d_tiny_bad;
+    A.out = zero_copy ? reinterpret_cast<double *>(dbase + res_off) : h->d_results[0];
+    A.bad = reinterpret_cast<int32_t *>(dbase + bad_off);
     A.B = B;
     A.n_vars = h->net.n_vars;
     A.pool_cells = (int32_t)h->net.pool.size();
     A.meta_words = h->tiny_meta_words;
-    A.flags = flags;
+    A.flags = (flags & ~kTinyFlagHostBad) | (zero_copy ? kTinyFlagHostBad : 0u);
     const size_t lds = tiny_lds_bytes(A.pool_cells, A.meta_words);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((B + 63) / 64, (int64_t)h->n_cu * 16));
     mibn_ctx::Set &st = h->set[0];
     if ((rc = retire(h, st))) return rc;
     size_t e0 = 0, e1 = 0;
-    if ((rc = next_event(h, st, e0))) return rc;
+    if (!zero_copy && (rc = next_event(h, st, e0))) return rc;
     hipLaunchKernelGGL(tiny_kernel, dim3(grid), dim3(64), lds, h->stream, A);
     HIP_TRY(h, hipGetLastError());
-    if ((rc = next_event(h, st, e1))) return rc;
+    if (!zero_copy && (rc = next_event(h, st, e1))) return rc;
     int32_t bad = none;
     const double t_d2h = now_ms();
-    HIP_TRY(h, hipMemcpyAsync(&bad, h->d_tiny_bad, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(out + out_off[0], h->d_results[0], res_cells * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->stats.d2h_ms += now_ms() - t_d2h;
     float ms = 0;
-    HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[e0], st.ev[e1]));
+    if (zero_copy) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(&bad, p + bad_off, 4);
+        std::memcpy(out + out_off[0], p + res_off, res_cells * 8);
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(p + bad_off, h->d_tiny_req + bad_off, 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(out + out_off[0], h->d_results[0], res_cells * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(&bad, p + bad_off, 4);
+        HIP_TRY(h, hipEventElapsedTime(&ms, st.ev[e0], st.ev[e1]));
+    }
+    h->stats.d2h_ms += now_ms() - t_d2h;
     st.ev_used = 0;
     if (bad != none) {  // the kernel skipped a malformed request: the message comes from the host-side checks
         Request rq;

@@ -44,6 +44,8 @@ inline bool tiny_eligible(const Network &net) {
     return true;
 }
 
+constexpr uint32_t kTinyFlagHostBad = 0x80000000u;  // TinyArgs::flags, engine-internal (never a MIBN_Q_* bit of the C-ABI)
+
 struct TinyArgs {
     const double *pool;
     const int32_t *meta;  // card[n], pool_off[n], scope_begin[n + 1], anc_mask[n], topo[n], then (scope_var, scope_stride) pairs
@@ -97,7 +99,14 @@ __global__ __launch_bounds__(64) void tiny_kernel(const TinyArgs A) {
             else st[v * 64 + lane] = (uint8_t)c;
         }
         if (malformed || want_cells != (int64_t)qcells) {
-            atomicMin(A.bad, (int32_t)(b < 0x7fffffff ? b : 0x7ffffffe));
+            if (A.flags & kTinyFlagHostBad) {
+                // zero-copy call (engine.hip run_tiny): one wave, request b = lane, `bad` in pinned host memory - no atomic minimum
+                // over PCIe: the lowest malformed lane of the wave stores its index
+                const uint64_t m = __ballot(1);
+                if (lane == __ffsll((unsigned long long)m) - 1) *A.bad = (int32_t)b;
+            } else {
+                atomicMin(A.bad, (int32_t)(b < 0x7fffffff ? b : 0x7ffffffe));
+            }
             continue;
         }
         rel |= qmask | emask;

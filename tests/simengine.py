@@ -11,7 +11,7 @@ import subprocess
 
 import numpy as np
 
-from sorobn_amd.bayes_net import Backend
+from sorobn_amd.bayes_net import Backend, CptWatch
 from sorobn_amd.flatten import flatten
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -168,7 +168,7 @@ def sim_backend(bn, small_cells=1024, tiling=(4096, 0), fuse=1):
     """A Backend whose engine is the CPU plan simulator (bypasses Backend.__init__)."""
     b = Backend.__new__(Backend)
     b.flat = flatten(bn)
-    b.fingerprint = Backend.fingerprint_of(bn)
+    b.watch = CptWatch(bn)
     b.engine = SimEngine(b.flat, small_cells, tiling, fuse)
     b._anc = {}
     # the presence network (full_joint_dist(keep_zeros=True)): same structure, tables = 1.0 where a CPT row exists

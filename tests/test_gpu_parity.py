@@ -690,6 +690,59 @@ def test_single_query_api_alarm(amd):
     pd.testing.assert_series_equal(ans, expect, rtol=0, atol=1e-12)
 
 
+def test_single_query_zero_copy_path(amd):
+    """Round 5: a call of at most 64 requests to the small-network kernel reads its request arrays from - and writes its
+    posteriors and the malformed-request flag to - the pinned staging buffer directly (engine.hip run_tiny): the same answers as
+    the DMA path (option tiny_zero_copy = 0) and as a larger call, and a malformed request still raises the reference's message."""
+    from sorobn_amd import _capi
+    for net in gu.load("examples.json"):
+        bn = netspec.build(net["spec"], amd.BayesNet)
+        eng = bn.backend.engine
+        reqs = [(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in net["requests"][:200]]
+        big = bn.query_many(reqs)                       # one call of 200 requests: the DMA path
+        assert [k["name"] for k in eng.kernel_stats()] == ["tiny_kernel"]
+        for i in (0, 1, 7, 63, 64, 150):
+            q, e = reqs[i]
+            a = bn.query(*q, event=e)                   # one request: zero-copy
+            assert eng.stats()["n_launches"] == 1
+            eng.set_option("tiny_zero_copy", 0)
+            b = bn.query(*q, event=e)
+            eng.set_option("tiny_zero_copy", 1)
+            pd.testing.assert_series_equal(a, b, check_exact=True)
+            pd.testing.assert_series_equal(a, big[i], check_exact=True)
+        small = bn.query_many(reqs[:64])                # one wave of requests: zero-copy
+        for i in range(64):
+            pd.testing.assert_series_equal(small[i], big[i], check_exact=True)
+        with pytest.raises(_capi.MibnError, match="request 2"):
+            eng.query_batch([0, 1, 2, 3, 4], [0, 1, 0, 1], [0, 0, 0, 1, 1], [0], [0])  # request 2 (and 3?): query var 0 is also its evidence
+
+
+def test_pandas_batch_api_on_the_gpu(amd):
+    """the drop-in pandas boundary, vectorised - `query()`'s directly built Series, `query_many` (PosteriorBatch),
+    `to_frame()` and `query_frame` strictly equal to the reference's tail applied to the posterior (shared with the CPU test)."""
+    from test_host_logic import check_pandas_batch_api
+    assert check_pandas_batch_api(lambda bn: bn) > 500
+
+
+def test_query_many_pipelined_c3(amd):
+    """`query_many` on 70 000 requests of the C3 stream given as Python (tuple, dict) objects: bulk encode, three sub-batches with
+    two engine calls in flight, the answers against the array API bit for bit, a sample of finished Series against `query()`."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    n = 70_000
+    q, ev, ec = netspec.c3_requests(100, 4, n, 4, seed=1)
+    reqs = [((f"{a:03d}",), {f"{v:03d}": int(c) for v, c in zip(vs, cs)}) for a, vs, cs in zip(q.tolist(), ev.tolist(), ec.tolist())]
+    batch = bn.query_many(reqs)
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    want = np.concatenate([be.engine.query_fixed(to_var[q[a:a + 32768]][:, None], to_var[ev[a:a + 32768]], ec[a:a + 32768]) for a in range(0, n, 32768)])
+    assert np.array_equal(batch.out.reshape(n, 4), want)
+    for i in (0, 1, 32767, 32768, 65535, 65536, n - 1):
+        pd.testing.assert_series_equal(batch[i], bn.query(*reqs[i][0], event=reqs[i][1]), check_exact=True)
+    frame = batch.to_frame()
+    assert len(frame) == int((want > 0).sum()) and abs(frame["p"].sum() - n) < 1e-6
+
+
 def test_c3_stream_vs_oracle(amd):
     """First requests of the BASELINE C3 stream on the 10x10 grid, HIP vs the C oracle (the oracle
     is pinned to the reference by tests/test_oracle.py).  Cheap requests only: the sparse CPU oracle

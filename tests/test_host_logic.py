@@ -782,21 +782,43 @@ def test_accelerate_live_reference_object_query_and_impute():
 
 def test_in_place_cpt_edit_reaches_the_backend():
     """the reference re-reads `P` on every query (bayes_net.py:770); an in-place edit of a CPT value must
-    not be answered from stale device tables - the backend fingerprint covers the CPT *contents*."""
+    not be answered from stale device tables.  Round 5: `CptWatch` (identity of Series / index / value array + one bitwise
+    comparison of all CPT numbers) instead of re-hashing every CPT per query - also for an edit through a reference the caller
+    kept, a replaced CPT, renamed levels and a CPT added or removed."""
+    from sorobn_amd.bayes_net import CptWatch
     spec = next(n for n in _nets("examples.json") if n["spec"]["name"] == "asia")["spec"]
     bn = netspec.build(spec, sorobn_amd.BayesNet)
     acc = sorobn_amd.accelerate(bn, backend_factory=simengine.sim_backend)
     ev = {"Smoker": True}
     before = acc._variable_elimination("Lung cancer", event=ev).to_numpy().copy()
-    fp = sorobn_amd.Backend.fingerprint_of(bn)
+    w = CptWatch(bn)
+    assert w.exact and not w.changed(bn)
+    b0 = bn._mibn_backend()
     bn.P["Smoker"].iloc[0] += 0.0
-    assert sorobn_amd.Backend.fingerprint_of(bn) == fp          # unchanged content: no rebuild
-    bn.P["Lung cancer"].iloc[:] = bn.P["Lung cancer"].to_numpy()[::-1].copy()  # in place: same Series object, same index
-    assert sorobn_amd.Backend.fingerprint_of(bn) != fp
+    assert not w.changed(bn) and bn._mibn_backend() is b0          # unchanged content: no rebuild
+    held = bn.P["Lung cancer"]                                      # a reference the caller keeps: the edit bypasses bn.P
+    held.iloc[:] = held.to_numpy()[::-1].copy()                     # in place: same Series object, same index, same array
+    assert w.changed(bn)
     after = acc._variable_elimination("Lung cancer", event=ev).to_numpy()
-    assert not np.allclose(before, after)
+    assert bn._mibn_backend() is not b0 and not np.allclose(before, after)
     fresh = simengine.sim_backend(bn).variable_elimination("Lung cancer", event=ev).to_numpy()
     assert np.array_equal(after, fresh)
+    for mutate in (lambda: bn.P.__setitem__("Smoker", bn.P["Smoker"].copy()),            # replaced by an equal copy
+                   lambda: bn.P.__setitem__("Extra", bn.P["Smoker"].copy()),              # a CPT more
+                   lambda: bn.P.pop("Extra"),                                            # a CPT less
+                   lambda: setattr(bn.P["Smoker"].index, "names", ["Smoker2"])):         # levels renamed in place
+        w = CptWatch(bn)
+        assert not w.changed(bn)
+        mutate()
+        assert w.changed(bn)
+    bn.P["Smoker"].index.names = ["Smoker"]
+    # values that are not a numeric ndarray: the hashed fingerprint still answers
+    obj = netspec.build(spec, sorobn_amd.BayesNet)
+    obj.P["Smoker"] = obj.P["Smoker"].astype(object)
+    w = CptWatch(obj)
+    assert not w.exact and not w.changed(obj)
+    obj.P["Smoker"].iloc[0] = 0.25
+    assert w.changed(obj)
 
 
 def test_heavy_c3_requests_simulator_vs_oracle():
@@ -944,3 +966,91 @@ def test_the_gpu_parity_streams_exercise_every_shape_of_the_sweep_tail():
                     two_dead += 1
             p += s["words"]
     assert own > 100 and dead == {0, 1, 2, 3, 4} and two_dead > 0, (own, dead, two_dead)
+
+
+# ------------------------------------------------------------------------------------ round 5: the pandas boundary, vectorised
+
+def check_pandas_batch_api(attach):
+    """Shared by the CPU test below (plan simulator) and tests/test_gpu_parity.py (HIP backend): `query()` (finished Series built
+    directly, Backend._tail), `query_many` (-> PosteriorBatch: lazily built Series, bulk-encoded, pipelined) and its `to_frame()`,
+    and `query_frame` - every answer strictly equal (pandas' checker: values, dtype, index class / dtype / names / level order /
+    row order, name) to the tail of the reference's `query` (bayes_net.py:869-875) applied to the unfinished posterior."""
+    n_checked = 0
+    for fname, take in (("examples.json", 120), ("random_dags.json", 30), ("wide_cards.json", 16)):
+        for net in _nets(fname):
+            bn = attach(netspec.build(net["spec"], sorobn_amd.BayesNet))
+            reqs = [(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in net["requests"][:take]]
+            batch = bn.query_many(reqs)
+            assert len(batch) == len(reqs) and len(batch[1:3]) == 2
+            for i, (q, e) in enumerate(reqs):
+                want = bn._finish(bn.backend.variable_elimination(*q, event=e), q)  # rename / reorder_levels / sort_index
+                pd.testing.assert_series_equal(batch[i], want, check_exact=True)
+                pd.testing.assert_series_equal(bn.query(*q, event=e), want, check_exact=True)
+                assert type(batch[i].index) is type(want.index)
+                n_checked += 1
+            frame = batch.to_frame()  # mixed query variables: one row per positive cell
+            assert isinstance(frame, pd.DataFrame) and frame["p"].gt(0).all()
+            assert frame.groupby("request")["p"].sum().round(9).isin([1.0]).all()  # every non-empty answer is a distribution
+            assert int(frame["request"].nunique()) == sum(len(batch[i]) > 0 for i in range(len(batch)))
+    # one query tuple for the whole batch: to_frame() is a long Series (request, *sorted names) whose slices ARE the answers
+    spec = next(n for n in _nets("examples.json") if n["spec"]["name"] == "asia")["spec"]
+    bn = attach(netspec.build(spec, sorobn_amd.BayesNet))
+    for q in (("Lung cancer",), ("Tuberculosis", "Lung cancer"), ("Smoker", "Bronchitis", "Dispnea")):
+        evs = [{}, {"Visit to Asia": True}, {"Visit to Asia": False, "Positive X-ray": True}, {"Positive X-ray": False}]
+        evs = [{k: v for k, v in e.items() if k not in q} for e in evs]
+        batch = bn.query_many([(q, e) for e in evs])
+        long = batch.to_frame()
+        assert isinstance(long, pd.Series) and list(long.index.names) == ["request", *sorted(q)]
+        for i in range(len(evs)):
+            got = long.xs(i, level="request")
+            if len(q) > 1:
+                got.index = got.index.remove_unused_levels()
+            want = batch[i]
+            want2 = want.copy()
+            if len(q) > 1:
+                want2.index = want2.index.remove_unused_levels()
+            pd.testing.assert_series_equal(got, want2, check_names=False, check_exact=True)
+            assert list(got.index.names) == list(want.index.names)
+        # query_frame: events as rows, NaN = unobserved; row r = the dense posterior in the order of query()'s index
+        cols = sorted({k for e in evs for k in e})
+        X = pd.DataFrame([{c: e.get(c, np.nan) for c in cols} for e in evs], index=[f"r{i}" for i in range(len(evs))]).astype(object)
+        out = bn.query_frame(*q, events=X)
+        assert list(out.index) == list(X.index) and out.shape[0] == len(evs)
+        for i in range(len(evs)):
+            row = out.iloc[i]
+            want = batch[i]
+            got = row[row > 0]
+            assert np.array_equal(got.to_numpy(), want.to_numpy())
+            assert [k if isinstance(k, tuple) else (k,) for k in got.index.tolist()] == [k if isinstance(k, tuple) else (k,) for k in want.index.tolist()]
+            assert list(out.columns.names) == list(want.index.names)
+    with pytest.raises(ValueError):
+        bn.query_frame("Smoker", events=pd.DataFrame({"Smoker": [True]}))
+    with pytest.raises(ValueError):
+        bn.query_many([(("Smoker",), {"Smoker": True})])
+    with pytest.raises(KeyError):
+        bn.query_many([(("Smoker",), {}), (("No such node",), {})])
+    assert len(bn.query_many([])) == 0
+    return n_checked
+
+
+def test_pandas_batch_api_on_the_simulator():
+    assert check_pandas_batch_api(simengine.attach) > 500
+
+
+def test_bulk_encode_matches_encode():
+    """Backend.encode_many (dict lookups in bulk) against Backend.encode request by request: same CSR arrays, incl. int-for-bool and
+    out-of-domain labels (code -1 through the per-request path), and the reference's KeyError for unknown names."""
+    for net in _nets("examples.json"):
+        bn = simengine.attach(netspec.build(net["spec"], sorobn_amd.BayesNet))
+        be = bn.backend
+        reqs = [(tuple(r["query"]), {k: v for k, v in r["event"]}) for r in net["requests"]]
+        q_off, qv, e_off, ev, ec = be.encode_many(reqs)
+        qs, es, cs = [], [], []
+        for q, e in reqs:
+            a, b, c = be.encode(q, e)
+            qs += a
+            es += b
+            cs += c
+        assert qv.tolist() == qs and ev.tolist() == es and ec.tolist() == cs
+        assert q_off.tolist() == np.concatenate([[0], np.cumsum([len(q) for q, _ in reqs])]).tolist()
+        assert e_off.tolist() == np.concatenate([[0], np.cumsum([len(e) for _, e in reqs])]).tolist()
