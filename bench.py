@@ -255,6 +255,114 @@ def other_configs(device, with_cpu=True):
     return out
 
 
+def f_configs(device, with_cpu=True):
+    """SURVEY section 8(f) rows in the line: predict_proba, likelihood weighting, fit, Chow-Liu - each on the
+    GPU path and, side by side on this box's host (one single-threaded process per row: oracle/ref_worker.py --workload f1..f4),
+    on the UNMODIFIED reference with the same inputs.  None of them is HBM-bound; the bound is named per row."""
+    import netspec
+    import pandas as pd
+    import sorobn_amd
+
+    frame = lambda rows, names, K, seed: pd.DataFrame(np.random.default_rng(seed).integers(0, K, (rows, len(names))), columns=names)
+    sizes = {"f1": 200_000, "f2": 300_000, "f3": 1_000_000, "f4": 20_000}
+    ref = {}
+    procs = None
+    if with_cpu:
+        from oracle import refload
+        if refload.available():
+            env = dict(os.environ, PYTHONHASHSEED="0", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            worker = os.path.join(ROOT, "oracle", "ref_worker.py")
+            procs = {w: subprocess.Popen([sys.executable, worker, "--workload", w, "--rows", str(n), "--budget", "60"], env=env,
+                                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for w, n in sizes.items()}
+    out = {}
+
+    def best_of(fn, reps=2):
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, r
+
+    # F1 predict_proba (bayes_net.py:934-962 over full_joint_dist 398-465): a 3x3 K=4 grid - the largest grid whose 4^9-row full
+    # joint the reference builds in reasonable time - all nine columns observed; and the 10x10 grid with three observed columns,
+    # which the reference cannot answer at all (a 4^100-row joint): there the 97 other variables are eliminated on the device
+    spec33 = netspec.grid_spec(3, 3, 4, seed=0)
+    bn33 = netspec.build(spec33, sorobn_amd.BayesNet).use_device(device)
+    X1 = frame(sizes["f1"], list(spec33["nodes"]), 4, 11)
+    bn33.predict_proba(X1.iloc[:8])
+    dt, pp = best_of(lambda: bn33.predict_proba(X1))
+    out["F1_predict_proba_grid"] = {"rows_per_s": len(X1) / dt, "rows": len(X1), "seconds": dt, "network": "3x3 grid, K=4, nine observed columns",
+                                    "checksum": float(pp.sum()), "bound": "host: pandas MultiIndex look-up of the rows in the joint (the device computes the "
+                                    "262 144-cell joint once, 2 MB: HBM roofline n/a)"}
+    grid = netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet).use_device(device)
+    Xg = frame(100_000, ["011", "055", "090"], 4, 1)
+    grid.predict_proba(Xg.iloc[:4])
+    dt, _ = best_of(lambda: grid.predict_proba(Xg))
+    out["F1_predict_proba_grid10x10_3_columns"] = {"rows_per_s": len(Xg) / dt, "rows": len(Xg), "seconds": dt,
+                                                   "reference": "cannot run: predict_proba builds the full joint (4^100 rows)",
+                                                   "bound": "host pandas look-up; the elimination of the 97 unobserved variables is one exact query"}
+    # F2 likelihood weighting (bayes_net.py:621-663, forward sampling 518-575) on Asia
+    asia = netspec.build({n["spec"]["name"]: n["spec"] for n in __import__("golden_util").load("examples.json")}["asia"], sorobn_amd.BayesNet).use_device(device)
+    ev2 = {"Smoker": True, "Dispnea": True}
+    asia.query("Lung cancer", event=ev2, algorithm="likelihood", n_iterations=1000)
+    n2 = 16_000_000
+    dt, a2 = best_of(lambda: asia.query("Lung cancer", event=ev2, algorithm="likelihood", n_iterations=n2))
+    out["F2_likelihood_weighting"] = {"samples_per_s": n2 / dt, "samples": n2, "seconds": dt, "answer": a2.to_numpy().tolist(),
+                                      "exact": asia.query("Lung cancer", event=ev2).to_numpy().tolist(),
+                                      "bound": "latency / Philox throughput: one sample per lane walks 8 variables, CPTs in LDS; HBM roofline n/a"}
+    # F3 fit (bayes_net.py:467-516): 1 M rows x 100 four-state columns onto the 10x10 grid's structure, end to end (factorise the
+    # label columns on the host, one counting launch for the 100 contingency tables, the CPT Series)
+    X3 = frame(sizes["f3"], [f"{i:03d}" for i in range(100)], 4, 12)
+    learner = netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet).use_device(device)
+    learner.fit(X3.iloc[:1000])
+    dt, _ = best_of(lambda: learner.fit(X3))
+    out["F3_fit_grid"] = {"rows_per_s": len(X3) / dt, "rows": len(X3), "columns": 100, "seconds": dt,
+                          "bound": "host factorisation of 100 label columns + the PCIe copy of the 100 MB code matrix; the count kernel itself is LDS-atomic bound"}
+    # F4 structure.chow_liu (structure.py:9-63): 100 four-state columns, all 4 950 pairwise tables in one counting launch
+    X4 = frame(sizes["f4"], [f"{i:03d}" for i in range(100)], 4, 13)
+    sorobn_amd.structure.chow_liu(X4.iloc[:500])
+    dt, tree = best_of(lambda: sorobn_amd.structure.chow_liu(X4))
+    X4b = frame(200_000, [f"{i:03d}" for i in range(100)], 4, 13)
+    dtb, _ = best_of(lambda: sorobn_amd.structure.chow_liu(X4b), reps=1)
+    out["F4_chow_liu_100cols"] = {"seconds": dt, "rows": len(X4), "rows_per_s": len(X4) / dt, "edges": len(tree),
+                                  "seconds_200k_rows": dtb, "bound": "LDS atomics of the count kernel (4 950 16-cell tables per row block) + the host's "
+                                  "mutual-information arithmetic and Kruskal over 4 950 edges"}
+    if procs:
+        key = {"f1": ("F1_predict_proba_grid", "rows_per_s"), "f2": ("F2_likelihood_weighting", "samples_per_s"), "f3": ("F3_fit_grid", "rows_per_s"),
+               "f4": ("F4_chow_liu_100cols", "rows_per_s")}
+        for w, pr in procs.items():
+            try:
+                so, se = pr.communicate(timeout=200)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                so, se = pr.communicate()
+            d = None
+            for line in so.splitlines():
+                try:
+                    j = json.loads(line)
+                except ValueError:
+                    continue
+                if j.get("done"):
+                    d = j
+            name, unit = key[w]
+            if d is None:
+                out[name]["cpu_baseline"] = {"error": se[-300:]}
+                continue
+            rate = d["units"] / d["elapsed"] if d["finished"] else 0.0
+            out[name]["cpu_baseline"] = {"value": rate, "unit": unit.replace("_per_s", "/s"), "cores": 1, "kind": "reference", "seconds": d["elapsed"],
+                                         "finished": bool(d["finished"]),
+                                         "sample": f"unmodified sorobn (oracle/_ref, '{d['reference']}') on the same input: {d['units']} "
+                                                   f"{'samples' if w == 'f2' else 'rows'}, one single-threaded process, beside the three other 8(f) "
+                                                   "reference processes" + ("; its sampler is oracle/refload's pure-Python stand-in for the absent third-party "
+                                                                            "`vose` (Cython in the original): the reference's own rate would be higher" if w == "f2" else "")}
+            if rate > 0:
+                ours = out[name][unit] if w != "f2" else out[name]["samples_per_s"]
+                out[name]["speedup_vs_reference_one_core"] = ours / rate
+    return out
+
+
 def c3_pandas(bn, n=131_072, sub_batch=32768):
     """throughput THROUGH the drop-in pandas boundary.  The C3 stream as a Python user holds it - a list of
     (query tuple, event dict) with node names and labels - into `BayesNet.query_many` (validation, bulk encode of names and labels,
@@ -455,7 +563,7 @@ def main():
     ap.add_argument("--port-seconds", type=float, default=6.0, help="wall budget of the C-port leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true")
-    ap.add_argument("--only-configs", action="store_true", help="measure C1 / C2 / C5 only and print them (quick check)")
+    ap.add_argument("--only-configs", action="store_true", help="measure C1 / C2 / C5 and the section-8(f) rows only and print them (quick check)")
     ap.add_argument("--no-adaptive", action="store_true", help="keep the planner's full order search even when the host is the bottleneck")
     ap.add_argument("--sync", action="store_true", help="one blocking mibn_query_batch per step instead of the two-deep pipeline")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (experiments), e.g. --opt chunk=32768")
@@ -489,7 +597,9 @@ def main():
     from sorobn_amd import sharding
 
     if a.only_configs:
-        print(json.dumps(other_configs(device)), flush=True)
+        cfg = other_configs(device, with_cpu=not a.no_cpu)
+        cfg.update(f_configs(device, with_cpu=not a.no_cpu))
+        print(json.dumps(cfg), flush=True)
         return
     if a.config == "c5":
         return run_c5(a, rank, world, local_rank, device, backend)
@@ -709,6 +819,10 @@ def main():
                 out["configs"] = other_configs(device, with_cpu=not a.no_cpu)
             except Exception as e:  # the headline line must not die with a side measurement
                 out["configs"] = {"error": repr(e)}
+            try:
+                out["configs"].update(f_configs(device, with_cpu=not a.no_cpu))
+            except Exception as e:  # noqa: BLE001
+                out["configs"]["F_rows"] = {"error": repr(e)}
             try:
                 out["configs"]["C3_query_many_pandas"] = c3_pandas(bn, sub_batch=a.batch)
             except Exception as e:  # noqa: BLE001

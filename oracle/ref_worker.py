@@ -31,7 +31,8 @@ class _Budget(Exception):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="c3", choices=["c3", "c1", "c2"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c1", "c2", "f1", "f2", "f3", "f4"])
+    ap.add_argument("--rows", type=int, default=0, help="f1 / f3 / f4: rows of the data frame; f2: likelihood-weighting samples")
     ap.add_argument("--first", type=int, default=200)
     ap.add_argument("--shard", type=int, default=0)
     ap.add_argument("--nshards", type=int, default=1)
@@ -44,6 +45,8 @@ def main():
     from oracle import refload
 
     sorobn = refload.load()
+    if a.workload in ("f1", "f2", "f3", "f4"):
+        return section_8f(a, sorobn, netspec, time.perf_counter() - t_setup)
     if a.workload == "c3":
         spec = netspec.grid_spec(10, 10, 4, seed=0)
         bn = netspec.build(spec, sorobn.BayesNet, wrap=refload.HashedName)
@@ -79,6 +82,52 @@ def main():
         pass
     signal.setitimer(signal.ITIMER_REAL, 0)
     print(json.dumps({"done": True, "elapsed": time.perf_counter() - t0, "finished": finished, "attempted": attempted,
+                      "setup_s": setup_s, "reference": getattr(sorobn, "_mibn_refload", "?")}), flush=True)
+
+
+def section_8f(a, sorobn, netspec, setup_s):
+    """The SURVEY section 8(f) rows on the unmodified reference, one call each, on the inputs bench.py's `f_configs` gives the GPU
+    path (same generators, same seeds): f1 `predict_proba` (bayes_net.py:934-962, through `full_joint_dist` 398-465) on a 3x3
+    K=4 grid; f2 `query(algorithm="likelihood")` (621-663) on Asia; f3 `fit` (467-516) on the 10x10 K=4 grid's structure; f4
+    `structure.chow_liu` (structure.py:9-63) on 100 four-state columns.  Output: one closing JSON line with `units` (rows or
+    samples) and `elapsed`; a call that does not finish inside `--budget` reports `finished` 0."""
+    import numpy as np
+    import pandas as pd
+
+    def frame(n_rows, names, K, seed):
+        return pd.DataFrame(np.random.default_rng(seed).integers(0, K, (n_rows, len(names))), columns=names)
+
+    if a.workload == "f1":
+        spec = netspec.grid_spec(3, 3, 4, seed=0)
+        bn = netspec.build(spec, sorobn.BayesNet)
+        X = frame(a.rows, list(spec["nodes"]), 4, 11)
+        call = lambda: float(bn.predict_proba(X).sum())
+    elif a.workload == "f2":
+        bn = sorobn.examples.asia()
+        call = lambda: bn.query("Lung cancer", event={"Smoker": True, "Dispnea": True}, algorithm="likelihood", n_iterations=a.rows).tolist()
+    elif a.workload == "f3":
+        spec = netspec.grid_spec(10, 10, 4, seed=0)
+        bn = netspec.build(spec, sorobn.BayesNet)
+        X = frame(a.rows, list(spec["nodes"]), 4, 12)
+        call = lambda: len(bn.fit(X).P)
+    else:
+        X = frame(a.rows, [f"{i:03d}" for i in range(100)], 4, 13)
+        call = lambda: len(sorobn.structure.chow_liu(X))
+
+    def on_alarm(signum, frame_):
+        raise _Budget()
+
+    signal.signal(signal.SIGALRM, on_alarm)
+    signal.setitimer(signal.ITIMER_REAL, a.budget)
+    t0 = time.perf_counter()
+    finished, result = 0, None
+    try:
+        result = call()
+        finished = 1
+    except _Budget:
+        pass
+    signal.setitimer(signal.ITIMER_REAL, 0)
+    print(json.dumps({"done": True, "elapsed": time.perf_counter() - t0, "finished": finished, "attempted": 1, "units": a.rows, "result": result,
                       "setup_s": setup_s, "reference": getattr(sorobn, "_mibn_refload", "?")}), flush=True)
 
 
