@@ -108,7 +108,7 @@ def section_8f(a, sorobn, netspec, setup_s):
     elif a.workload == "f3":
         spec = netspec.grid_spec(10, 10, 4, seed=0)
         bn = netspec.build(spec, sorobn.BayesNet)
-        X = frame(a.rows, list(spec["nodes"]), 4, 12)
+        X = frame(a.rows, [f"{i:03d}" for i in range(100)], 4, 12)
         call = lambda: len(bn.fit(X).P)
     else:
         X = frame(a.rows, [f"{i:03d}" for i in range(100)], 4, 13)
