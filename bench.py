@@ -329,6 +329,12 @@ def f_configs(device, with_cpu=True):
     out["F4_chow_liu_100cols"] = {"seconds": dt, "rows": len(X4), "rows_per_s": len(X4) / dt, "edges": len(tree),
                                   "seconds_200k_rows": dtb, "bound": "LDS atomics of the count kernel (4 950 16-cell tables per row block) + the host's "
                                   "mutual-information arithmetic and Kruskal over 4 950 edges"}
+    from sorobn_amd import learning
+    for b in (bn33, grid, asia, learner):
+        b.backend.engine.close()
+    for e in list(learning._engines.values()):
+        e.close()
+    learning._engines.clear()
     if procs:
         key = {"f1": ("F1_predict_proba_grid", "rows_per_s"), "f2": ("F2_likelihood_weighting", "samples_per_s"), "f3": ("F3_fit_grid", "rows_per_s"),
                "f4": ("F4_chow_liu_100cols", "rows_per_s")}
@@ -819,14 +825,6 @@ def main():
                 out["configs"] = other_configs(device, with_cpu=not a.no_cpu)
             except Exception as e:  # the headline line must not die with a side measurement
                 out["configs"] = {"error": repr(e)}
-            try:
-                out["configs"].update(f_configs(device, with_cpu=not a.no_cpu))
-            except Exception as e:  # noqa: BLE001
-                out["configs"]["F_rows"] = {"error": repr(e)}
-            try:
-                out["configs"]["C3_query_many_pandas"] = c3_pandas(bn, sub_batch=a.batch)
-            except Exception as e:  # noqa: BLE001
-                out["configs"]["C3_query_many_pandas"] = {"error": repr(e)}
             # SURVEY 8(d)'s n_evidence variants of the C3 stream on this engine (the final kernels, the timed region's options)
             for ne in (1, 8, 16):
                 try:
@@ -894,6 +892,19 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     out["configs"][name] = {"error": repr(e)}
             out["projected_8gpu"] = project_8gpu(out)
+            # the drop-in pandas boundary and the section-8(f) rows last, on engines of their own (session A of round 5 ran them in front
+            # of the n_evidence variants: their engines' device memory cut the main engine's arena budget and n_evidence = 8 ran in
+            # several arena waves per call)
+            try:
+                bnp = netspec.build(spec, sorobn_amd.BayesNet).use_device(device)
+                out["configs"]["C3_query_many_pandas"] = c3_pandas(bnp)
+                bnp.backend.engine.close()
+            except Exception as e:  # noqa: BLE001
+                out["configs"]["C3_query_many_pandas"] = {"error": repr(e)}
+            try:
+                out["configs"].update(f_configs(device, with_cpu=not a.no_cpu))
+            except Exception as e:  # noqa: BLE001
+                out["configs"]["F_rows"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()

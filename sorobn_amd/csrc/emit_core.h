@@ -1064,8 +1064,13 @@ struct Emitter {
             out.alloc = cells;
         }
         const size_t step_base = prog.size;
-        const bool fiber = nx == 3 ? (!final_ && emit_chain(ins, n_in, s, xs, out))
-                                   : !final_ && ((net.outer && nx > 0 && emit_outer(ins, n_in, s, xs, out, cx, c1)) || emit_fiber(ins, n_in, s, xs, out, cx, c1));
+        // (a step of fewer than big_iters output cells runs in the segment interpreter, GENERIC form: every streaming form ends with
+        //  that test - emit_fiber `rcells * NC`, emit_outer `rcells * 16`, emit_chain_as `rcells * 64` are all the output's cells -
+        //  so two thirds of the steps skip their layout work here)
+        const bool streaming = !final_ && cells >= net.big_iters;
+        const bool fiber = !streaming ? false
+                           : nx == 3  ? emit_chain(ins, n_in, s, xs, out)
+                                      : ((net.outer && nx > 0 && emit_outer(ins, n_in, s, xs, out, cx, c1)) || emit_fiber(ins, n_in, s, xs, out, cx, c1));
         if (!fiber) {
             if (fiber_only) {
                 if (out.alloc) arena.release((int64_t)out.off, out.alloc);

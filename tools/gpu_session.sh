@@ -22,7 +22,7 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{\"metric\"'):
         d = json.loads(l); r = d['roofline']; b = d['pipeline_clocks_ms_per_step']; s = r.get('per_kernel_serialised', {})
-        print('%-52s %.0f q/s  ms/step %.1f  gpu busy %.1f  planner wall %.1f  device-planned %.0f  all kernels %.0f GB/s  ' % ('$1', d['value'], d['ms_per_step'], b['gpu_busy_ms'], b['planner_wall_ms_inside_submit_calls'], d['config'].get('device_planned_requests_per_step', 0), r['all_kernels_GBps']) + '  '.join('%s %.0f' % (k.replace('ve_', '').replace('_kernel', ''), v['GBps']) for k, v in s.items()))
+        print('%-52s %.0f q/s  ms/step %.1f  gpu busy %.1f  planner wall %.1f  device-planned %.0f  all kernels %.0f GB/s  ' % ('$1', d['value'], d['ms_per_step'], b['gpu_busy_ms'], b['planner_wall_ms_inside_submit_calls'], d['config'].get('device_planned_requests_per_step', 0), r['all_kernels_GBps']) + '  '.join('%s %.0f' % (k.replace('ve_', '').replace('_kernel', ''), v.get('achieved', 0)) for k, v in s.items() if isinstance(v, dict)))
     elif 'rror' in l: print(l.rstrip()[:300])
 "; }
 

@@ -42,6 +42,7 @@ int main(int argc, char **argv) {
     if (const char *e = std::getenv("ORDER_WEIGHTS")) net.order_weights = atoi(e);
     if (const char *e = std::getenv("MINFILL_ABOVE")) net.minfill_above = atof(e);
     if (const char *e = std::getenv("SWEEP_MIN")) net.sweep_min = atoi(e);
+    net.plan_cache = std::getenv("PLAN_CACHE") ? atoi(std::getenv("PLAN_CACHE")) : 0;  // (the repetitions below would turn into template copies)
     std::vector<int32_t> hint(n);
     for (int v = 0; v < n; ++v) hint[v] = v;
     net.set_hints(1, hint.data());
