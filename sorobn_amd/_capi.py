@@ -144,6 +144,12 @@ class Engine:
             raise MibnError(rc, f"mibn_create failed: {why}")
         self.planner_only = planner_only
         self.device = device
+        # experiment hook: MIBN_OPTS="name=value,..." sets engine options on every engine of the process (a parity run of the GPU
+        # suite under a non-default option, e.g. MIBN_OPTS=mfma_kernel=1 python -m pytest tests -m gpu)
+        for kv in os.environ.get("MIBN_OPTS", "").split(","):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                self.set_option(k.strip(), float(v))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -220,7 +220,7 @@ struct mibn_ctx {
         struct Timed {  // kid >= 0: one launch; -1: the wall time of a wave (kernel_ms); -2: the launches of one level on the two streams of
                         // option overlap, as ONE concurrent launch pair - events (e0, e1) of the level kernel's launch, (e2, e3) of the sweep
                         // kernel's (kNone: the level has no such launch); its duration is the span from the earlier start to the later end
-            int kid; size_t e0, e1; double bytes, items; uint64_t call; size_t e2 = kNone, e3 = kNone, e4 = kNone, e5 = kNone;  // (e4, e5: the segment kernel's)
+            int kid; size_t e0, e1; double bytes, items; uint64_t call; size_t e2 = kNone, e3 = kNone, e4 = kNone, e5 = kNone, e6 = kNone, e7 = kNone;  // (e4, e5: the segment kernel's; e6, e7: the MFMA kernel's)
             static constexpr size_t kNone = ~size_t(0);
         };
         std::vector<Timed> timed;
@@ -313,12 +313,14 @@ struct mibn_ctx {
     } comm;
     std::string err;
     mibn_stats stats{}, total{};               // last call / since creation
-    mibn_kernel_stat kstats[kNumKernels + 6];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
-    mibn_kernel_stat ktotal[kNumKernels + 6];  // + the device planner's pair of kernels + the concurrent launch pair of a level (option overlap)
+    mibn_kernel_stat kstats[kNumKernels + 7];  // per class (split_kinds) + the level kernel as a whole + the tiny kernel + the LDS-DMA sweep kernel
+    mibn_kernel_stat ktotal[kNumKernels + 7];  // + the device planner's pair of kernels + the concurrent launch pair of a level (option overlap)
     // options
     double arena_gb = 200.0;  // scratch budget of all lanes together (of the 288 GB)
     hipStream_t stream2 = nullptr;  // lane 1 (lane 0 = stream)
-    hipStream_t aux[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // option overlap, per lane: the sweep kernel's and the segment kernel's launches
+    hipStream_t aux[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // option overlap, per lane: the sweep kernel's, the segment kernel's and the MFMA kernel's launches
+    int mfma_kernel = 0;            // round 5: the one-table fp64-MFMA pair classes of a level as a launch of ve_mfma_kernel (128 VGPRs, four
+                                    // waves per SIMD) on a fourth stream instead of workgroups of ve_level_kernel (168 VGPRs, three)
     int seg_kernel = 1;             // the segments of a level as a launch of ve_segment_kernel (12 KB of LDS per workgroup) instead of workgroups
                                     // of ve_level_kernel (40 KB, 168 VGPRs)
     hipEvent_t epoch = nullptr;     // reference of the busy-time bookkeeping (re-recorded when the GPU is idle)
@@ -463,6 +465,8 @@ int mibn_create(int device, mibn_t **out) {
               hipStreamCreateWithFlags(&h->aux[0][1], hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->aux[1][0], hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->aux[1][1], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->aux[0][2], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->aux[1][2], hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
     // the sweep kernel keeps its 64 KiB tile, the T tables and the step descriptor in dynamic LDS (two workgroups per CU)
     ok = ok && hipFuncSetAttribute((const void *)ve_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSweepLdsBytes) == hipSuccess;
@@ -550,6 +554,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "gibbs_lds") h->gibbs_lds = std::max(0, std::min(2, (int)value));
     else if (n == "tiny") h->tiny = value != 0;
     else if (n == "tiny_zero_copy") h->tiny_zero_copy = value != 0;
+    else if (n == "mfma_kernel") h->mfma_kernel = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
     else if (n == "plan_lanes") h->plan_lanes = std::max(1, std::min(64, (int)value));  // requests per wave of the device planner's kernels
@@ -745,7 +750,7 @@ void ensure_pool(mibn_ctx *h) {
 
 // name of statistics slot k: the classes of work (split_kinds), then the kernels as launched
 const char *stat_name(int k) {
-    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : (k == kNumKernels + 2 ? "ve_sweep_dma_kernel" : (k == kNumKernels + 3 ? "order_kernel+emit_kernel" : (k == kNumKernels + 4 ? "ve_level_kernel||ve_sweep_dma_kernel" : "ve_segment_kernel")))));
+    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : (k == kNumKernels + 2 ? "ve_sweep_dma_kernel" : (k == kNumKernels + 3 ? "order_kernel+emit_kernel" : (k == kNumKernels + 4 ? "ve_level_kernel||ve_sweep_dma_kernel" : (k == kNumKernels + 5 ? "ve_segment_kernel" : "ve_mfma_kernel"))))));
 }
 
 // wait for a set's launches and book their HIP-event durations per kernel
@@ -773,9 +778,9 @@ int retire(mibn_ctx *h, mibn_ctx::Set &st) {
         if (t.kid == -2) {
             // one level = one concurrent launch pair: from the earlier start to the later end (timestamps against the epoch event)
             double lo = 1e300, hi = -1e300;
-            for (size_t e : {t.e0, t.e2, t.e4})
+            for (size_t e : {t.e0, t.e2, t.e4, t.e6})
                 if (e != mibn_ctx::Set::Timed::kNone) { float x = 0; HIP_TRY(h, hipEventElapsedTime(&x, h->epoch, st.ev[e])); lo = std::min(lo, (double)x); }
-            for (size_t e : {t.e1, t.e3, t.e5})
+            for (size_t e : {t.e1, t.e3, t.e5, t.e7})
                 if (e != mibn_ctx::Set::Timed::kNone) { float x = 0; HIP_TRY(h, hipEventElapsedTime(&x, h->epoch, st.ev[e])); hi = std::max(hi, (double)x); }
             for (mibn_kernel_stat *ks : {&h->kstats[kNumKernels + 4], &h->ktotal[kNumKernels + 4]}) {
                 if (ks == &h->kstats[kNumKernels + 4] && !mine) continue;
@@ -1226,7 +1231,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
     h->search_ms = 0;
     h->emit_ms = 0;
     h->stats = mibn_stats{};
-    for (int k = 0; k <= kNumKernels + 5; ++k) {
+    for (int k = 0; k <= kNumKernels + 6; ++k) {
         h->kstats[k] = mibn_kernel_stat{};
         std::snprintf(h->kstats[k].name, sizeof(h->kstats[k].name), "%s", stat_name(k));
     }
@@ -1584,18 +1589,19 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
             // launches of level L run side by side; a launch of level L + 1 waits for ALL launches of level L: the one on its own
             // stream by stream order, the others through their end events (`prev`: the ends of the previous level - not the running
             // `last`, or the launches of one level would serialise: ADVICE r3).
-            hipStream_t SS[3] = {S, h->aux[lane][0], h->aux[lane][1]};
+            constexpr int kNS = 4;  // (3 = S4: the MFMA kernel, option mfma_kernel)
+            hipStream_t SS[kNS] = {S, h->aux[lane][0], h->aux[lane][1], h->aux[lane][2]};
             constexpr size_t kNone = mibn_ctx::Set::Timed::kNone;
-            long last[3] = {-1, -1, -1}, prev[3] = {-1, -1, -1}, saw[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
+            long last[kNS], prev[kNS], saw[kNS][kNS];
+            for (int a = 0; a < kNS; ++a) { last[a] = prev[a] = -1; for (int b = 0; b < kNS; ++b) saw[a][b] = -1; }
             int cur_level = -1;
             mibn_ctx::Set::Timed pair{-2, kNone, kNone, 0.0, 0.0, h->call_id};  // the level in progress, as one concurrent launch group
             auto close_pair = [&]() {
-                if (pair.e0 != kNone || pair.e2 != kNone || pair.e4 != kNone) st.timed.push_back(pair);
+                if (pair.e0 != kNone || pair.e2 != kNone || pair.e4 != kNone || pair.e6 != kNone) st.timed.push_back(pair);
                 pair = mibn_ctx::Set::Timed{-2, kNone, kNone, 0.0, 0.0, h->call_id};
             };
             if (two) {  // (the uploads, the previous wave's kernels: the arena is theirs until then)
-                HIP_TRY(h, hipStreamWaitEvent(SS[1], st.ev[e_first], 0));
-                HIP_TRY(h, hipStreamWaitEvent(SS[2], st.ev[e_first], 0));
+                for (int j = 1; j < kNS; ++j) HIP_TRY(h, hipStreamWaitEvent(SS[j], st.ev[e_first], 0));
             }
             for (size_t li = 0; li < sc.launches.size();) {
                 // one launch of the level kernel per level (all its classes of work together) unless split_kinds, one of the
@@ -1604,10 +1610,14 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 size_t lj = li + 1;
                 const bool sweep = sc.launches[li].kid == kKidSweep;
                 const bool seg = h->seg_kernel && !h->split_kinds && sc.launches[li].kid == kKidSeg;
+                // (the two classes of ve_mfma_kernel are the last ones of a level in front of the sweep class: planner.cpp ClassOrder)
+                auto is_mfma1 = [&](int kid) { return h->mfma_kernel && !h->split_kinds && (kid == kKidFiber0 + 4 || kid == kKidFiber0 + 6 + 4); };
+                const bool mf = is_mfma1(sc.launches[li].kid);
                 double bytes = sc.launches[li].alg_bytes;
                 size_t grid = sc.launches[li].grid;
                 if (!h->split_kinds && !sweep && !seg)
-                    for (; lj < sc.launches.size() && sc.launches[lj].level == sc.launches[li].level && sc.launches[lj].kid != kKidSweep; ++lj) {
+                    for (; lj < sc.launches.size() && sc.launches[lj].level == sc.launches[li].level && sc.launches[lj].kid != kKidSweep &&
+                           is_mfma1(sc.launches[lj].kid) == mf; ++lj) {
                         bytes += sc.launches[lj].alg_bytes;
                         grid += sc.launches[lj].grid;
                     }
@@ -1615,35 +1625,36 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 A.wg_item = st.d_wg_item + L.wg_level;
                 A.wg_base = (uint32_t)(L.wg_first - L.wg_level);
                 size_t e0 = 0, e1 = 0;
-                const int si = two ? (sweep ? 1 : (seg ? 2 : 0)) : 0;
+                const int si = two ? (sweep ? 1 : (seg ? 2 : (mf ? 3 : 0))) : 0;
                 hipStream_t Sx = SS[si];
                 if (two) {
-                    if (L.level != cur_level) { cur_level = L.level; for (int j = 0; j < 3; ++j) prev[j] = last[j]; close_pair(); }
-                    for (int j = 0; j < 3; ++j)
+                    if (L.level != cur_level) { cur_level = L.level; for (int j = 0; j < kNS; ++j) prev[j] = last[j]; close_pair(); }
+                    for (int j = 0; j < kNS; ++j)
                         if (j != si && prev[j] > saw[si][j]) { HIP_TRY(h, hipStreamWaitEvent(Sx, st.ev[(size_t)prev[j]], 0)); saw[si][j] = prev[j]; }
                 }
                 if ((rc = next_event(h, st, e0, Sx))) return rc;
                 if (sweep && h->sweep_dma) hipLaunchKernelGGL(ve_sweep_dma_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, Sx, A);
                 else if (sweep) hipLaunchKernelGGL(ve_sweep_kernel, dim3((unsigned)grid), dim3(kSweepWG), kSweepLdsBytes, Sx, A);
                 else if (seg) hipLaunchKernelGGL(ve_segment_kernel, dim3((unsigned)grid), dim3(kWG), 0, Sx, A);
+                else if (mf) hipLaunchKernelGGL(ve_mfma_kernel, dim3((unsigned)grid), dim3(kWG), 0, Sx, A);
                 else hipLaunchKernelGGL(ve_level_kernel, dim3((unsigned)grid), dim3(kWG), 0, Sx, A);
                 if ((rc = next_event(h, st, e1, Sx))) return rc;
                 if (two) {
                     last[si] = (long)e1;
                     if (!h->split_kinds) {
-                        if (si == 1) { pair.e2 = e0; pair.e3 = e1; } else if (si == 2) { pair.e4 = e0; pair.e5 = e1; } else { pair.e0 = e0; pair.e1 = e1; }
+                        if (si == 1) { pair.e2 = e0; pair.e3 = e1; } else if (si == 2) { pair.e4 = e0; pair.e5 = e1; } else if (si == 3) { pair.e6 = e0; pair.e7 = e1; } else { pair.e0 = e0; pair.e1 = e1; }
                         pair.bytes += bytes;
                         pair.items += (double)grid;
                     }
                 }
-                st.timed.push_back({sweep ? (h->sweep_dma ? kNumKernels + 2 : kKidSweep) : (seg ? kNumKernels + 5 : (h->split_kinds ? L.kid : kNumKernels)), e0, e1, bytes, (double)grid, h->call_id});
+                st.timed.push_back({sweep ? (h->sweep_dma ? kNumKernels + 2 : kKidSweep) : (seg ? kNumKernels + 5 : (mf ? kNumKernels + 6 : (h->split_kinds ? L.kid : kNumKernels))), e0, e1, bytes, (double)grid, h->call_id});
                 n_wg += (double)grid;
                 li = lj;
             }
             {
                 if (two) {
                     close_pair();
-                    for (int j = 1; j < 3; ++j)  // the wave ends on S
+                    for (int j = 1; j < kNS; ++j)  // the wave ends on S
                         if (last[j] > saw[0][j]) HIP_TRY(h, hipStreamWaitEvent(S, st.ev[(size_t)last[j]], 0));
                 }
                 size_t e_last = 0;
@@ -1788,7 +1799,7 @@ extern "C" int mibn_total_stats(const mibn_t *h, mibn_stats *out) {
 extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 5 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 6 && k < cap; ++i)
         if (h->ktotal[i].launches > 0) out[k++] = h->ktotal[i];
     *n = k;
     return MIBN_OK;
@@ -1797,7 +1808,7 @@ extern "C" int mibn_total_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel
 extern "C" int mibn_last_kernel_stats(const mibn_t *h, int32_t cap, mibn_kernel_stat *out, int32_t *n) {
     if (!h || !out || !n) return MIBN_E_ARG;
     int k = 0;
-    for (int i = 0; i <= kNumKernels + 5 && k < cap; ++i)
+    for (int i = 0; i <= kNumKernels + 6 && k < cap; ++i)
         if (h->kstats[i].launches > 0) out[k++] = h->kstats[i];
     *n = k;
     return MIBN_OK;

@@ -183,7 +183,13 @@ MIBN_HD inline double order_simulate(const OrderNet &net, OrderScratch &S, const
 // `abort_above`: every factor an elimination creates is written once and read once later, so 16 bytes x the cells
 // created so far is a lower bound of the order's section-8(d) cost - once it passes the best sweep the search stops
 // (returns false: the order cannot win).  The order goes to S.cand.
-MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 &hidden, double abort_above) {
+// (Networks whose multi-state variables all have 2^l states - OrderNet::uniform_log2 - run the same search on integers: the score
+// miss * 64 + l * degree is exact in a few bits, so score, depth and id pack into one 64-bit key per vertex and the choice of
+// the next vertex is a branch-free minimum over the keys instead of a floating-point comparison with a tolerance and two
+// tie-breaks per vertex.  Same order as the general form, bit for bit: the scores are the same numbers and an exact tie is what
+// the tolerance of 1e-12 detects there.)
+template <bool kUniform>
+MIBN_HD inline bool order_greedy_impl(const OrderNet &net, OrderScratch &S, const B2 &hidden, double abort_above) {
     B2 *adj = S.adj;
     const B2 rel = S.rel;
     b2_each(rel, [&](int v) { adj[v] = B2{}; S.miss[v] = 0; S.ws[v] = 0; S.score[v] = 0; });
@@ -194,37 +200,54 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
     b2_each(rel, [&](int v) { adj[v].clr(v); });
     double *ws = S.ws, *score = S.score;
     int32_t *miss = S.miss;
+    uint64_t *key = reinterpret_cast<uint64_t *>(S.score);  // (kUniform: the packed keys live where the scores would)
+    const int l = net.uniform_log2;
+    // key = (miss * 64 + l * degree) << 16 | depth << 8 | id   (depth, id < 256: networks of <= 128 variables)
+    auto pack = [&](int x, int missing, int degree) { return ((uint64_t)(uint32_t)(missing * 64 + l * degree) << 16) | ((uint64_t)(uint32_t)net.depth[x] << 8) | (uint64_t)x; };
     B2 alive = hidden;  // the vertices not yet eliminated - a register pair, scanned in ascending order
     int n_alive = b2_count(hidden);
     b2_each(alive, [&](int x) {
         const B2 ax = adj[x];
         int missing = 0;  // (ordered) pairs of neighbours that are not adjacent
         b2_each(ax, [&](int y) { missing += __builtin_popcountll(ax.a & ~adj[y].a) + __builtin_popcountll(ax.b & ~adj[y].b) - 1; });
-        ws[x] = order_log2sum(net, ax);
         miss[x] = missing;
-        score[x] = missing * 64.0 + ws[x];
+        if (kUniform) {
+            const int deg = b2_count(ax);
+            ws[x] = (double)(l * deg);
+            key[x] = pack(x, missing, deg);
+        } else {
+            ws[x] = order_log2sum(net, ax);
+            score[x] = missing * 64.0 + ws[x];
+        }
     });
     S.n_cand = 0;
     const int total = n_alive;
     double created = 0;
     for (int it = 0; it < total; ++it) {
-        int best = -1, dbest = 0;
-        double wbest = 0;
-        b2_each(alive, [&](int x) {
-            const double wx = score[x];
-            const double d = wx - wbest;
-            if (best < 0 || wx < wbest - 1e-12) {
-                best = x;
-                wbest = wx;
-                dbest = net.depth[x];
-            } else if ((d < 0 ? -d : d) <= 1e-12) {
-                const int dx = net.depth[x];
-                if (dx < dbest || (dx == dbest && x < best)) { best = x; wbest = wx; dbest = dx; }
-            }
-        });
+        int best = -1;
+        if (kUniform) {
+            uint64_t kbest = ~0ull;
+            b2_each(alive, [&](int x) { const uint64_t k = key[x]; kbest = k < kbest ? k : kbest; });
+            best = (int)(kbest & 0xff);
+        } else {
+            int dbest = 0;
+            double wbest = 0;
+            b2_each(alive, [&](int x) {
+                const double wx = score[x];
+                const double d = wx - wbest;
+                if (best < 0 || wx < wbest - 1e-12) {
+                    best = x;
+                    wbest = wx;
+                    dbest = net.depth[x];
+                } else if ((d < 0 ? -d : d) <= 1e-12) {
+                    const int dx = net.depth[x];
+                    if (dx < dbest || (dx == dbest && x < best)) { best = x; wbest = wx; dbest = dx; }
+                }
+            });
+        }
         S.cand[S.n_cand++] = (uint8_t)best;
         alive.clr(best);
-        created += order_exp2(ws[best]);  // cells of the factor this elimination creates (its scope = the neighbours)
+        created += kUniform ? order_pow2((int)ws[best]) : order_exp2(ws[best]);  // cells of the factor this elimination creates (its scope = the neighbours)
         if (16.0 * net.chain_weight * created > abort_above) return false;
         const B2 nb = adj[best];
         b2_each(nb, [&](int y) {
@@ -238,7 +261,11 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
                 common.a = adj[y].a & adj[u].a & ~nb.a;
                 common.b = adj[y].b & adj[u].b & ~nb.b;
                 common.clr(best);
-                b2_each(common, [&](int z) { miss[z] -= 2; score[z] = miss[z] * 64.0 + ws[z]; });
+                b2_each(common, [&](int z) {
+                    miss[z] -= 2;
+                    if (kUniform) key[z] -= (uint64_t)128 << 16;  // (two ordered pairs fewer: the score drops by 2 * 64)
+                    else score[z] = miss[z] * 64.0 + ws[z];
+                });
             });
         });
         b2_each(nb, [&](int y) {
@@ -263,12 +290,24 @@ MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 
                 missing += __builtin_popcountll(nbm.a & na) + __builtin_popcountll(nbm.b & nb_) + __builtin_popcountll(ay.a & na) +
                            __builtin_popcountll(ay.b & nb_) - 1;
             });
-            ws[y] = order_log2sum(net, ay);
             miss[y] = missing;
-            score[y] = missing * 64.0 + ws[y];
+            if (kUniform) {
+                const int deg = b2_count(ay);
+                ws[y] = (double)(l * deg);
+                key[y] = pack(y, missing, deg);
+            } else {
+                ws[y] = order_log2sum(net, ay);
+                score[y] = missing * 64.0 + ws[y];
+            }
         });
     }
     return true;
+}
+
+MIBN_HD inline bool order_greedy(const OrderNet &net, OrderScratch &S, const B2 &hidden, double abort_above) {
+    // (depth and id take 8 bits each of a packed key; a score of a 128-vertex graph stays far below 2^31)
+    if (net.uniform_log2 >= 0 && net.n_vars <= 128) return order_greedy_impl<true>(net, S, hidden, abort_above);
+    return order_greedy_impl<false>(net, S, hidden, abort_above);
 }
 
 // Relevant set, hidden set and the factor scopes (S.f / S.fc of the relevant variables) of one request.

@@ -1034,7 +1034,11 @@ struct ClassOrder {
         for (int c = 2; c >= 0; --c) add(kKidFiber0 + c * 6 + 3);                          // one table, ncN
         for (int n = 0; n < 6; ++n) add(kKidFiber0 + 2 * 6 + n);                            // one table, runtime cx
         for (int c = 0; c < 2; ++c) add(kKidFiber0 + 18 + c * 6 + 5);                       // OUTER
-        for (int kid = 0; kid < kNumKernels; ++kid) add(kid);                               // the streaming classes
+        for (int kid = 0; kid < kNumKernels; ++kid)                                        // the streaming classes ...
+            if (kid != kKidFiber0 + 4 && kid != kKidFiber0 + 6 + 4 && kid != kKidSweep) add(kid);
+        add(kKidFiber0 + 4);      // ... the one-table fp64-MFMA pair classes last among them (contiguous: engine option mfma_kernel
+        add(kKidFiber0 + 6 + 4);  //     launches the two as ve_mfma_kernel), then the sweep class (a kernel of its own)
+        add(kKidSweep);
         for (int r = 0; r < kNumKernels; ++r) { kid_at[r] = order[(size_t)r]; rank_of[order[(size_t)r]] = r; }
     }
 };

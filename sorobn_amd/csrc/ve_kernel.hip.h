@@ -590,7 +590,7 @@ __device__ __forceinline__ void fiber_call(const uint32_t *sw, double *__restric
 // LDS-bound: SQ_LDS_IDX_ACTIVE ~ 90 % of the kernel time) and the transposition of the 128-byte fibers.
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <int NBIG, int KS>
+template <int NBIG, int KS, bool OCL = false>
 __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__restrict__ shT, int (*sh_hoff)[kTileMax],
                                                 uint32_t *__restrict__ shX, const double *__restrict__ pool,
                                                 double *__restrict__ slot, const int tid, const int h_begin, const int h_end) {
@@ -618,6 +618,9 @@ __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__re
     const int rs = (int)((sw[1] >> kRowStrideShift) & 0xff);  // 1, 4 or 16
     uint32_t la[NBIG][4];
     int tb[4], oc[4][4];  // T offset of row block rb; output offset of accumulator element v of row block rb (-1: none)
+    // OCL (ve_mfma_kernel: a register budget of 128): the sixteen output offsets of a lane are parked in LDS behind sh_cell, as
+    // outer_mfma_call does - a lane reads back only what it wrote: no barrier
+    int *sh_oc = sh_cell + 4 * kWG;  // [16][kWG]
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const int c = wave * 64 + (lrow % rs) + rs * rb + 4 * rs * (lrow / rs);  // the cell this lane loads for block rb
@@ -630,6 +633,7 @@ __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__re
             const int cell = wave * 64 + (i % rs) + rs * rb + 4 * rs * (i / rs);
             // (contiguous steps: cell*16 + lrow, i.e. 512 contiguous bytes per store instruction for rs >= 4)
             oc[rb][v] = cell < d.lo_cells ? sh_cell[3 * kWG + cell] + (int)d.nout[lrow] : -1;
+            if (OCL) sh_oc[(rb * 4 + v) * kWG + tid] = oc[rb][v];
         }
     }
 
@@ -657,8 +661,10 @@ __device__ __forceinline__ void fiber_mfma_call(const uint32_t *sw, double *__re
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb][ks], shT[ht + tb[rb] + lrow + 16 * (4 * ks + lk)], acc, 0, 0, 0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (oc[rb][v] >= 0) outp[ho + oc[rb][v]] = acc[v];
+            for (int v = 0; v < 4; ++v) {
+                const int o = OCL ? sh_oc[(rb * 4 + v) * kWG + tid] : oc[rb][v];
+                if (o >= 0) outp[ho + o] = acc[v];
+            }
         }
     };
     if (NBIG == 1 && MIBN_PIPELINE) {
@@ -1016,6 +1022,37 @@ __global__ __launch_bounds__(kWG, MIBN_MIN_WAVES) void ve_level_kernel(const Lev
 }
 #undef MIBN_FIBER_CASES
 #undef MIBN_MFMA_CASES
+
+// Round 5: the one-table fp64-MFMA pair classes (fiber<1, cx4 | cx16, nc16-mfma>: a quarter of the C3 bytes) as a kernel of their
+// own (option mfma_kernel, a fourth stream beside the level's other launches).  Inside ve_level_kernel they lived on that kernel's
+// register budget - 168 VGPRs for the GENERIC and two-table forms = three waves per SIMD - and its SQ counters said occupancy
+// (57 % of the wave cycles parked on s_waitcnt).  Alone, with the sixteen output offsets of a lane parked in LDS, they fit 128
+// registers without scratch: four waves per SIMD, the four 40 KB workgroups a CU's LDS takes.
+__global__ __launch_bounds__(kWG, 4) void ve_mfma_kernel(const LevelArgs A) {
+    __shared__ __attribute__((aligned(16))) double shT[kMaxT];
+    __shared__ __attribute__((aligned(16))) uint32_t shX[4 * 64 * kXRow];
+    __shared__ uint32_t sh_step[kMaxStepWords];
+    __shared__ int sh_hoff[kMaxIn][kTileMax];
+    const int tid = threadIdx.x;
+    const uint32_t wg = blockIdx.x + A.wg_base;
+    const uint32_t item_idx = (uint32_t)uni((int)A.wg_item[wg]);
+    Item it;
+    it.req = (uint32_t)uni((int)A.items[item_idx].req);
+    it.rel_off = (uint32_t)uni((int)A.items[item_idx].rel_off);
+    it.a = (uint32_t)uni((int)A.items[item_idx].a);
+    it.b = (uint32_t)uni((int)A.items[item_idx].b);
+    const uint64_t ao = A.arena_off[it.req], po = A.prog_off[it.req];
+    double *slot = A.arena + (((uint64_t)(uint32_t)uni((int)(ao >> 32)) << 32) | (uint32_t)uni((int)(ao & 0xffffffffu)));
+    const uint32_t *p = A.prog + (((uint64_t)(uint32_t)uni((int)(po >> 32)) << 32) | (uint32_t)uni((int)(po & 0xffffffffu))) + it.rel_off;
+    const int words = (int)p[6];
+    for (int i = tid; i < words; i += kWG) sh_step[i] = p[i];
+    __syncthreads();
+    const int h0 = (int)((wg - it.b) * it.a);
+    const int h1 = min((int)sh_step[3], h0 + (int)it.a);
+    const int cx = (int)(sh_step[1] & 0xffff);
+    if (cx == 4) fiber_mfma_call<1, 1, true>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1);
+    else fiber_mfma_call<1, 4, true>(sh_step, shT, sh_hoff, shX, A.pool, slot, tid, h0, h1);
+}
 
 // Round 4: the segments of a level as a kernel of their own (option seg_kernel, launched on a third stream beside the level's
 // other launches).  A segment is a chain of dependent tiny steps - a few global round trips per step, nothing to stream - and

@@ -11,6 +11,8 @@
 #   calib         PMC calibration on a known byte count (tools/ubench/sweep_real)
 #   threads       the few-planning-threads table (1 2 4 8 and the whole quota; THREADS="1 2" to choose)
 #   ab            interleaved A/B of bench argument sets: AB="--opt x=0;--opt x=1" REPS=2 (LIBS="a.so;b.so" to A/B builds)
+#   classes       tools/probe_classes.py at full launch size: one launch per (level, class of work), GB/s per class (PROBE_N=52429)
+#   parity        the GPU parity suite under non-default engine options: PARITY_OPTS="mfma_kernel=1" [PARITY_K="<pytest -k expr>"]
 #   planner       tools/bench_planner.py (host planning rate, one thread)
 #   smoke         __graft_entry__.smoke()
 TAG=${1:?tag}; shift
@@ -79,6 +81,11 @@ ab)
   for rep in $(seq 1 ${REPS:-2}); do for lib in "${LIBSET[@]}"; do for args in "${SETS[@]}"; do
     MIBN_LIB=$ROOT/sorobn_amd/$lib timeout 300 python bench.py --steps ${STEPS:-6} --warmup ${WARMUP:-2} --no-cpu --no-configs ${ADAPT:---no-adaptive} $args 2>&1 | line "$lib $args" | tee -a $OUT/${TAG}_ab.log
   done; done; done ;;
+classes)
+  PROBE_N=${PROBE_N:-52429} PROBE_OPTS=${PROBE_OPTS:-arena_gb=250} timeout 600 python tools/probe_classes.py 2>&1 | tee $OUT/${TAG}_probe_classes.log | tail -40 ;;
+parity)
+  MIBN_OPTS="${PARITY_OPTS:?}" timeout 1500 python -m pytest tests -m gpu -x -q -k "${PARITY_K:-golden or stream or c3 or grid or stratified or heavy or sweep or device_planner}" > $OUT/${TAG}_pytest_parity.log 2>&1
+  echo "pytest rc $? (MIBN_OPTS=$PARITY_OPTS)" >> $OUT/${TAG}_pytest_parity.log; tail -6 $OUT/${TAG}_pytest_parity.log | cut -c1-240 ;;
 planner)
   timeout 600 python tools/bench_planner.py 2>&1 | tee $OUT/${TAG}_planner.log | tail -12 ;;
 smoke)

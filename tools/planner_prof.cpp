@@ -11,6 +11,9 @@
 
 #include "../sorobn_amd/csrc/planner.h"
 using namespace mibn;
+#if defined(MIBN_PLAN_PROFILE)
+namespace mibn { extern double g_prof[8]; }
+#endif
 
 int main(int argc, char **argv) {
     const int R = 10, C = 10, K = 4;
@@ -121,6 +124,13 @@ int main(int argc, char **argv) {
         double tot = 0;
         for (int k = 0; k < 11; ++k) tot += (double)g_host_emit_prof.a[k];
         for (int k = 0; k < 11; ++k) std::printf("  emit phase %-24s %5.1f %%\n", names[k], 100.0 * (double)g_host_emit_prof.a[k] / tot);
+    }
+#endif
+#if defined(MIBN_PLAN_PROFILE)  // g++ ... -DMIBN_PLAN_PROFILE, one thread: plan_request's phases (planner.cpp PROF)
+    {
+        const double n = (double)B * reps;
+        std::printf("  per request: plan_request %.2f us = order search %.2f + emission %.2f + rest %.2f\n", g_prof[0] / n, g_prof[1] / n, g_prof[4] / n,
+                    (g_prof[0] - g_prof[1] - g_prof[4]) / n);
     }
 #endif
     std::printf("threads %d: %.1f ms for %lld requests = %.2f us/request/thread (x%d threads), %.0f req/s; %.1f steps, %.0f words, %.2f MB per request\n",
