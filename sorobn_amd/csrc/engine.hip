@@ -319,8 +319,9 @@ struct mibn_ctx {
     double arena_gb = 200.0;  // scratch budget of all lanes together (of the 288 GB)
     hipStream_t stream2 = nullptr;  // lane 1 (lane 0 = stream)
     hipStream_t aux[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // option overlap, per lane: the sweep kernel's, the segment kernel's and the MFMA kernel's launches
-    int mfma_kernel = 0;            // round 5: the one-table fp64-MFMA pair classes of a level as a launch of ve_mfma_kernel (128 VGPRs, four
-                                    // waves per SIMD) on a fourth stream instead of workgroups of ve_level_kernel (168 VGPRs, three)
+    int mfma_kernel = 1;            // round 5: the one-table fp64-MFMA pair classes of a level as a launch of ve_mfma_kernel (128 VGPRs, four
+                                    // waves per SIMD) on a fourth stream instead of workgroups of ve_level_kernel (168 VGPRs, three): 296.2 -> 300.4 k queries/s,
+                                    // all kernels 4.56 -> 4.63 TB/s, three interleaved repetitions each (profiles/r05_b_ab.log)
     int seg_kernel = 1;             // the segments of a level as a launch of ve_segment_kernel (12 KB of LDS per workgroup) instead of workgroups
                                     // of ve_level_kernel (40 KB, 168 VGPRs)
     hipEvent_t epoch = nullptr;     // reference of the busy-time bookkeeping (re-recorded when the GPU is idle)
