@@ -1035,6 +1035,9 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
 #ifndef MIBN_HOST_KEEPS_UP
 #define MIBN_HOST_KEEPS_UP 1.25  // adaptive policy: (requests the host plans per ms) x (kernel ms per request) at or above which the device planner is dropped
 #endif
+#ifndef MIBN_POLICY_WINDOW_MS
+#define MIBN_POLICY_WINDOW_MS 150.0  // adaptive policy: planning and retired kernel time a window must hold before it is judged (ranks of more than four planning threads)
+#endif
 #ifndef MIBN_HOST_BOUND_RATIO
 #define MIBN_HOST_BOUND_RATIO 1.15  // adaptive policy: planner wall time over GPU kernel time above which a stream of calls counts as host-bound
 #endif
@@ -1278,7 +1281,11 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
             h->seen_plan_ms = h->total.plan_ms;
             h->seen_kernel_ms = h->total.kernel_ms;
             h->seen_requests = h->retired_requests;
-        } else if (dp > 20.0 && dk > 20.0) {
+        } else if (dp > 20.0 && dk > 20.0 && (h->pool->size() <= 4 || (dp > MIBN_POLICY_WINDOW_MS && dk > MIBN_POLICY_WINDOW_MS))) {
+            // (a rank that is not starved judges windows of at least MIBN_POLICY_WINDOW_MS of planning AND of retired kernel time - two
+            //  to three calls: the kernel time of a call is booked when its launches retire, up to two calls late, and a window of one
+            //  call saw "100 ms of planning, 136 ms of kernels" as often as "100 against 68" on a steadily host-bound stream - n_evidence
+            //  = 16 in round 5's session D: the two host-bound windows in a row the switch asks for came once in twelve calls)
             const double dreq = h->retired_requests - h->seen_requests;
             // The device planner goes again where the host ALONE would keep up: the requests its workers plan per ms (measured
             // beside the device planner) x the kernel time per request must cover a request with a margin - the margin also

@@ -3,7 +3,7 @@
     python tools/make_pmc_json.py profiles/r02_u_rocprofv3_summary.txt
 
 FETCH_SIZE / WRITE_SIZE come from separate rocprofv3 --pmc passes of the bench command (tools/gpu_profile.sh).  On gfx950
-FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM section): doubled for ve_level_kernel, whose
+FETCH_SIZE tallies a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM section): doubled for ve_level_kernel and ve_mfma_kernel, whose
 waves read 512 contiguous bytes per instruction.  The sweep kernels read runs of 64 bytes, which the counter tallies in
 full - register-staged loads and LDS-DMA alike: calibrated on a known byte count (tools/gpu_r03_session.sh,
 profiles/r03_*_pmc_calibration.log: FETCH_SIZE 8.582 GB for 8.590 GB read, WRITE_SIZE 8.608 / 8.590), so no correction there.  The algorithmic bytes per launch of the same command are taken from
@@ -39,7 +39,7 @@ for name in sorted(set(fetch) & set(write)):
                  "alg_bytes_per_launch_same_run": alg_per_launch}
 # the concurrent launches of a level as one unit (bench.py's roofline names it when option overlap is on): the counters of its
 # kernels summed (the PMC passes serialise the kernels, so every kernel's bytes are its own)
-grp = [n for n in per if n in ("ve_level_kernel", "ve_sweep_dma_kernel", "ve_segment_kernel") and per[n]["alg_bytes_per_launch_same_run"]]
+grp = [n for n in per if n in ("ve_level_kernel", "ve_sweep_dma_kernel", "ve_segment_kernel", "ve_mfma_kernel") and per[n]["alg_bytes_per_launch_same_run"]]
 if len(grp) >= 2:
     tot_t = sum(per[n]["traffic_bytes_per_launch"] * per[n]["launches_under_the_counters"] for n in grp)
     tot_a = sum(per[n]["alg_bytes_per_launch_same_run"] * per[n]["launches_under_the_counters"] for n in grp)
