@@ -120,6 +120,8 @@ struct EmitNet {
     int32_t small_cells = 1024;
     int64_t big_iters = 4096;
     double log2_small = 10, log2_big = 12;  // log2 of the two, computed once on the host (host and device must agree to the bit)
+    int32_t uniform_log2 = -1;            // l >= 0: every multi-state variable has 2^l states and the others one (OrderNet::uniform_log2): a
+                                          // scope's log2 cells is l x its popcount, exactly the sum the loop over its variables computes
     int32_t prune = 1, outer = 1, fuse = 1, chain = 1, sweep = 5, sweep_min = 2, sweep_canon = 1;
     int32_t tile_h = 0, sweep_iters = kSweepItersDefault;
     int64_t tile_bytes = 512 << 10;
@@ -1135,6 +1137,7 @@ MIBN_HD inline void emit_scratch_carve(EmitScratch &S, char *base, int n_vars) {
 }
 
 MIBN_HD inline double emit_scope_log2(const EmitNet &net, const Bits &b) {
+    if (net.uniform_log2 >= 0) return (double)(net.uniform_log2 * b.count());  // (scopes hold multi-state variables only: emit_begin)
     double s = 0;
     b.for_each([&](int v) { s += net.log2card[v]; });
     return s;

@@ -153,6 +153,7 @@ EmitNet Network::emit_view() const {
     e.big_iters = big_iters;
     e.log2_small = std::log2((double)small_cells);
     e.log2_big = std::log2((double)big_iters);
+    e.uniform_log2 = uniform_log2;
     e.prune = prune; e.outer = outer; e.fuse = fuse; e.chain = chain; e.sweep = sweep; e.sweep_min = sweep_min; e.sweep_canon = sweep_canon;
     e.tile_h = tile_h;
     e.sweep_iters = sweep_iters;

@@ -4,6 +4,7 @@ library (loads, exports every symbol of include/mibn.h, refuses to compute witho
 import copy
 import ctypes
 import os
+import subprocess
 import pickle
 import re
 
@@ -1054,3 +1055,20 @@ def test_bulk_encode_matches_encode():
         assert qv.tolist() == qs and ev.tolist() == es and ec.tolist() == cs
         assert q_off.tolist() == np.concatenate([[0], np.cumsum([len(q) for q, _ in reqs])]).tolist()
         assert e_off.tolist() == np.concatenate([[0], np.cumsum([len(e) for _, e in reqs])]).tolist()
+
+
+def test_planner_output_is_pinned(tmp_path):
+    """The planner's optimisations of rounds 4 and 5 (static slot sets, integer min-fill keys, the small-step shortcut, popcount scope
+    sizes) must not move a word: tools/plan_fingerprint.cpp plans seeded request streams on 12 synthetic networks x 6 option sets and
+    prints one hash of programs + work items + statistics + schedule per pair; tools/plan_fingerprint.expected.txt is that output for
+    the committed planner.  (A deliberate change of the planner's choices or of the class order re-pins the file.)"""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = tmp_path / "plan_fingerprint"
+    r = subprocess.run(["g++", "-O2", "-mpopcnt", "-std=c++17", os.path.join(ROOT, "tools", "plan_fingerprint.cpp"),
+                        os.path.join(ROOT, "sorobn_amd", "csrc", "planner.cpp"), "-lpthread", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600).stdout
+    want = open(os.path.join(ROOT, "tools", "plan_fingerprint.expected.txt")).read()
+    assert out.splitlines() == want.splitlines()
