@@ -253,7 +253,7 @@ struct mibn_ctx {
     double retired_requests = 0, seen_requests = 0;  // requests whose kernel time has been booked (the unit of kernel_ms in the policy's windows)
     double host_rate = 0;                            // requests per ms the host's workers planned beside the device planner (smoothed; 0: not measured)
     // device order search (order_kernel)
-    int plan_lanes = 32;             // requests per wave of order_kernel / emit_kernel (1..64)
+    int plan_lanes = 0;              // requests per wave of order_kernel / emit_kernel (1..64); 0 = by the rank's planning threads: plan_lanes_now()
     int plan_waves = 16;             // waves per workgroup of the two (1..16): see order_kernel
     int gpu_search = 0;              // option: 1 = search elimination orders on the device (networks of <= 128 variables)
     hipStream_t search_stream = nullptr;
@@ -558,7 +558,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "mfma_kernel") h->mfma_kernel = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
-    else if (n == "plan_lanes") h->plan_lanes = std::max(1, std::min(64, (int)value));  // requests per wave of the device planner's kernels
+    else if (n == "plan_lanes") h->plan_lanes = std::max(0, std::min(64, (int)value));  // requests per wave of the device planner's kernels
     else if (n == "emit_share") { h->emit_share_opt = value > 0 ? std::min(1.0, value) : -1; if (value > 0) h->emit_share = h->emit_share_opt; }  // the device's share of a chunk (<= 0: follows the measured rates)
     else if (n == "emit_words") h->emit_words = (uint32_t)std::max(1024, std::min(1 << 20, (int)value));  // words of a request's device program slot
     else if (n == "gpu_search") h->gpu_search = std::max(0, std::min(2, (int)value));  // elimination-order search on the device
@@ -853,6 +853,16 @@ int pinned(mibn_ctx *h, mibn_ctx::Staging &sg, size_t bytes) {
     return MIBN_OK;
 }
 
+// Requests per wave of the device planner's kernels.  The lanes of a wave run different requests, every data-dependent branch
+// diverges, so a wave's time grows with its lanes in use: fewer lanes in more waves plan faster and take more of the chip from the
+// VE kernels.  A rank of one or two planning threads is bound by its planning capacity (host + device), not by its kernels: 24
+// lanes (230 -> 246 k queries/s at one and two threads); from four threads on the kernels' share of the chip counts for more: 32
+// (258 / 254 k at 24 / 32 lanes and four threads, 263 / 269 k at six; profiles/r05_f_planlanes.log, r05_g_planlanes.log).
+static int plan_lanes_now(const mibn_ctx *h) {
+    if (h->plan_lanes > 0) return h->plan_lanes;
+    return h->pool && h->pool->size() <= 2 ? 24 : 32;
+}
+
 // Device order search for requests [b0, b1): uploads their query / evidence variables and launches order_kernel on a
 // high-priority stream of its own (it must not queue behind the level kernels of the previous chunk); the orders (128
 // bytes per request) and their lengths land in h->search_out.  Asynchronous: search_wait() before they are read.  The
@@ -905,7 +915,7 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
         A.order_len = len_out + s0;
         A.scratch = h->d_order_scratch;
         A.zero = nullptr;
-        A.lanes = h->plan_lanes;
+        A.lanes = plan_lanes_now(h);
         {
             const int64_t per_wg = (int64_t)A.lanes * h->plan_waves;
             hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, h->search_stream, A);
@@ -993,8 +1003,8 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         O.order_len = h->d_order_len + s0;
         O.scratch = h->d_order_scratch;
         O.zero = s0 == 0 ? h->d_emit_cursor : nullptr;
-        O.lanes = h->plan_lanes;
-        const int64_t per_wg = (int64_t)h->plan_lanes * h->plan_waves;
+        O.lanes = plan_lanes_now(h);
+        const int64_t per_wg = (int64_t)O.lanes * h->plan_waves;
         hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, P, O);
         EmitArgs A;
         {   // the pointers of the device copy, the options of the moment
@@ -1022,7 +1032,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         A.tag_cap = (uint32_t)tag_cap;
         A.scratch = h->d_emit_scratch;
         A.scratch_stride = scratch_stride;
-        A.lanes = h->plan_lanes;
+        A.lanes = plan_lanes_now(h);
         hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, P, A);
         HIP_TRY(h, hipGetLastError());
     }
