@@ -50,6 +50,7 @@ struct OrderArgs {
     int32_t *order_len;    // [B]
     OrderScratch *scratch; // [B]
     uint32_t *zero;        // a counter the launch resets (emit_kernel's item cursor: no memset on the planning stream), or null
+    const int32_t *perm;   // [B] or null: lane position -> request of the slice (requests of similar size share a wave: plan_on_device_launch)
     int32_t lanes;         // requests per wave (the other lanes of the 64 leave at once: the lanes of a wave run different requests -
                            // every data-dependent branch diverges - so a wave's time grows with the lanes in use; fewer lanes in more
                            // waves finish sooner, as long as the chip has SIMDs to spare: option plan_lanes)
@@ -68,9 +69,10 @@ __global__ __launch_bounds__(1024, MIBN_ORDER_WAVES_PER_EU) void order_kernel(co
     if (A.zero && blockIdx.x == 0 && threadIdx.x == 0) *A.zero = 0;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
     if (lane >= A.lanes) return;
-    const int64_t b = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
-    if (b >= A.B) return;
-    OrderScratch &S = A.scratch[b];
+    const int64_t pos = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
+    if (pos >= A.B) return;
+    const int64_t b = A.perm ? A.perm[pos] : pos;
+    OrderScratch &S = A.scratch[pos];
     const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
     order_search(A.net, S, (int)(A.q_off[b + 1] - q0), A.q_vars + q0, (int)(A.e_off[b + 1] - e0), A.e_vars + e0,
                  (A.flags & MIBN_Q_NOPRUNE) != 0);
@@ -106,6 +108,7 @@ struct EmitArgs {
     uint32_t tag_cap;
     char *scratch;                           // [B][scratch_stride] planning state (EmitScratch)
     size_t scratch_stride;
+    const int32_t *perm;                     // [B] or null (see OrderArgs)
     int32_t lanes;                           // requests per wave (see OrderArgs)
 };
 
@@ -116,8 +119,9 @@ __device__ unsigned long long g_emit_prof[12];  // 100 MHz ticks per phase, summ
 __global__ __launch_bounds__(1024, MIBN_EMIT_WAVES_PER_EU) void emit_kernel(const EmitArgs A) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
     if (lane >= A.lanes) return;
-    const int64_t b = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
-    if (b >= A.B) return;
+    const int64_t pos = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
+    if (pos >= A.B) return;
+    const int64_t b = A.perm ? A.perm[pos] : pos;
     EmitMeta m;
     m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
     m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(1024, MIBN_EMIT_WAVES_PER_EU) void emit_kernel(cons
 #endif
 #endif
     EmitScratch S;
-    emit_scratch_carve(S, A.scratch + (size_t)b * A.scratch_stride, A.net.n_vars);
+    emit_scratch_carve(S, A.scratch + (size_t)pos * A.scratch_stride, A.net.n_vars);
     const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
     const int nq = (int)(A.q_off[b + 1] - q0), ne = (int)(A.e_off[b + 1] - e0);
     int err = emit_begin(A.net, S, nq, A.q_vars + q0, ne, A.e_vars + e0, A.e_codes + e0, (A.flags & MIBN_Q_NOPRUNE) != 0);
@@ -255,6 +259,11 @@ struct mibn_ctx {
     // device order search (order_kernel)
     int plan_lanes = 0;              // requests per wave of order_kernel / emit_kernel (1..64); 0 = by the rank's planning threads: plan_lanes_now()
     int plan_waves = 16;             // waves per workgroup of the two (1..16): see order_kernel
+    int plan_sort = 0;               // experiment (off): the requests of a slice dealt to the lanes in descending order of their relevant-set size, so
+                                     // that the lanes of a wave run loops of similar length.  Measured (profiles/r05_h_plansort.log): 24 lanes per
+                                     // wave, one / two planning threads 247 -> 226 / 252 -> 231 k queries/s (the planner's kernels 178 -> 198 ms per
+                                     // pair: the expensive requests end up in the same workgroups and on the same CUs); 32 lanes, four threads
+                                     // 262 -> 265 k.  The stream's own order mixes the sizes, and that is the better balance.
     int gpu_search = 0;              // option: 1 = search elimination orders on the device (networks of <= 128 variables)
     hipStream_t search_stream = nullptr;
     char *d_order_net = nullptr;     // the OrderNet arrays
@@ -558,6 +567,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "mfma_kernel") h->mfma_kernel = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
+    else if (n == "plan_sort") h->plan_sort = value != 0;
     else if (n == "plan_lanes") h->plan_lanes = std::max(0, std::min(64, (int)value));  // requests per wave of the device planner's kernels
     else if (n == "emit_share") { h->emit_share_opt = value > 0 ? std::min(1.0, value) : -1; if (value > 0) h->emit_share = h->emit_share_opt; }  // the device's share of a chunk (<= 0: follows the measured rates)
     else if (n == "emit_words") h->emit_words = (uint32_t)std::max(1024, std::min(1 << 20, (int)value));  // words of a request's device program slot
@@ -915,6 +925,7 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
         A.order_len = len_out + s0;
         A.scratch = h->d_order_scratch;
         A.zero = nullptr;
+        A.perm = nullptr;
         A.lanes = plan_lanes_now(h);
         {
             const int64_t per_wg = (int64_t)A.lanes * h->plan_waves;
@@ -948,7 +959,8 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
     hipStream_t P = h->search_stream;
     const size_t nq = (size_t)(q_off[b1] - q_off[b0]), ne = (size_t)(e_off[b1] - e_off[b0]);
     const size_t off_bytes = (size_t)(n + 1) * 8;
-    const size_t in_bytes = 3 * off_bytes + (nq + 2 * ne) * 4 + (size_t)n + 64;
+    const size_t perm_off = (3 * off_bytes + (nq + 2 * ne) * 4 + (size_t)n + 63) & ~(size_t)63;
+    const size_t in_bytes = perm_off + (size_t)n * 4 + 64;
     const size_t stride = h->emit_words;
     const size_t tag_cap = (size_t)n * 64;
     const size_t scratch_stride = emit_scratch_bytes(h->net.n_vars);
@@ -975,6 +987,28 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
     std::memcpy(pv, q_vars + q_off[b0], nq * 4);
     if (ne) { std::memcpy(pv + nq * 4, e_vars + e_off[b0], ne * 4); std::memcpy(pv + (nq + ne) * 4, e_codes + e_off[b0], ne * 4); }
     std::memcpy(pv + (nq + 2 * ne) * 4, skip + b0, (size_t)n);
+    // lane position -> request, slice by slice: descending size of the relevant set (query, evidence and their ancestors: what the order
+    // search and the emission loop over), a counting sort on 129 keys
+    int32_t *perm = reinterpret_cast<int32_t *>(pin + perm_off);
+    const bool sorted = h->plan_sort && h->net.n_vars <= 128 && !h->net.anc2.empty();
+    if (sorted) {
+        std::vector<uint8_t> key((size_t)std::min(n, kPlanSlice));
+        for (int64_t s0 = 0; s0 < n; s0 += kPlanSlice) {
+            const int64_t m = std::min(kPlanSlice, n - s0);
+            int32_t count[130] = {0};
+            for (int64_t i = 0; i < m; ++i) {
+                const int64_t b = b0 + s0 + i;
+                B2 rel;
+                for (int64_t k = q_off[b]; k < q_off[b + 1]; ++k) { const int v = q_vars[k]; rel.set(v); rel.a |= h->net.anc2[v].a; rel.b |= h->net.anc2[v].b; }
+                for (int64_t k = e_off[b]; k < e_off[b + 1]; ++k) { const int v = e_vars[k]; rel.set(v); rel.a |= h->net.anc2[v].a; rel.b |= h->net.anc2[v].b; }
+                const int c = 128 - b2_count(rel);  // (descending)
+                key[(size_t)i] = (uint8_t)c;
+                ++count[c + 1];
+            }
+            for (int c = 0; c < 129; ++c) count[c + 1] += count[c];
+            for (int64_t i = 0; i < m; ++i) perm[s0 + count[key[(size_t)i]]++] = (int32_t)i;
+        }
+    }
     // No copies on the planning stream: its kernels read the request arrays from, and write their results to, pinned host
     // memory.  (A DMA copy on this stream queued behind the previous call's result download - which waits for that call's
     // kernels - on the copy engine: the planner started when the chunk in flight had finished, never beside it.)
@@ -1003,6 +1037,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         O.order_len = h->d_order_len + s0;
         O.scratch = h->d_order_scratch;
         O.zero = s0 == 0 ? h->d_emit_cursor : nullptr;
+        O.perm = sorted ? reinterpret_cast<const int32_t *>(d + perm_off) + s0 : nullptr;
         O.lanes = plan_lanes_now(h);
         const int64_t per_wg = (int64_t)O.lanes * h->plan_waves;
         hipLaunchKernelGGL(order_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, P, O);
@@ -1032,6 +1067,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         A.tag_cap = (uint32_t)tag_cap;
         A.scratch = h->d_emit_scratch;
         A.scratch_stride = scratch_stride;
+        A.perm = O.perm;
         A.lanes = plan_lanes_now(h);
         hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((m + per_wg - 1) / per_wg)), dim3(64 * h->plan_waves), 0, P, A);
         HIP_TRY(h, hipGetLastError());
