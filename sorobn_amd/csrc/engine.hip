@@ -259,11 +259,13 @@ struct mibn_ctx {
     // device order search (order_kernel)
     int plan_lanes = 0;              // requests per wave of order_kernel / emit_kernel (1..64); 0 = by the rank's planning threads: plan_lanes_now()
     int plan_waves = 16;             // waves per workgroup of the two (1..16): see order_kernel
-    int plan_sort = 0;               // experiment (off): the requests of a slice dealt to the lanes in descending order of their relevant-set size, so
-                                     // that the lanes of a wave run loops of similar length.  Measured (profiles/r05_h_plansort.log): 24 lanes per
-                                     // wave, one / two planning threads 247 -> 226 / 252 -> 231 k queries/s (the planner's kernels 178 -> 198 ms per
-                                     // pair: the expensive requests end up in the same workgroups and on the same CUs); 32 lanes, four threads
-                                     // 262 -> 265 k.  The stream's own order mixes the sizes, and that is the better balance.
+    int plan_sort = 0;               // experiment (off): the requests of a slice dealt to the lanes by descending relevant-set size - 1: consecutive
+                                     // ranks share a wave; 2: round-robin over the workgroups (every CU the same mix, homogeneous waves); 3: round-
+                                     // robin over the waves (every wave the same sum).  Measured at 24 lanes per wave, two planning threads
+                                     // (profiles/r05_h/i/j_*.log): 250 k queries/s unsorted, 231 k (1), 231 k (2), 249 k (3) - homogeneous waves
+                                     // are the slow ones: the lanes of a wave diverge almost completely, a wave's time is the SUM of its lanes',
+                                     // and the stream's own order already mixes the sizes; balancing the sums exactly (3) shortens the
+                                     // planner's kernels by 2 % and moves nothing.  32 lanes, four threads: 259 / 265 / 265 / 258 k.
     int gpu_search = 0;              // option: 1 = search elimination orders on the device (networks of <= 128 variables)
     hipStream_t search_stream = nullptr;
     char *d_order_net = nullptr;     // the OrderNet arrays
@@ -567,7 +569,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "mfma_kernel") h->mfma_kernel = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
-    else if (n == "plan_sort") h->plan_sort = value != 0;
+    else if (n == "plan_sort") h->plan_sort = (int)value;
     else if (n == "plan_lanes") h->plan_lanes = std::max(0, std::min(64, (int)value));  // requests per wave of the device planner's kernels
     else if (n == "emit_share") { h->emit_share_opt = value > 0 ? std::min(1.0, value) : -1; if (value > 0) h->emit_share = h->emit_share_opt; }  // the device's share of a chunk (<= 0: follows the measured rates)
     else if (n == "emit_words") h->emit_words = (uint32_t)std::max(1024, std::min(1 << 20, (int)value));  // words of a request's device program slot
@@ -1006,7 +1008,26 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
                 ++count[c + 1];
             }
             for (int c = 0; c < 129; ++c) count[c + 1] += count[c];
-            for (int64_t i = 0; i < m; ++i) perm[s0 + count[key[(size_t)i]]++] = (int32_t)i;
+            if (h->plan_sort == 1) {
+                for (int64_t i = 0; i < m; ++i) perm[s0 + count[key[(size_t)i]]++] = (int32_t)i;
+            } else {
+                // plan_sort = 2: the sorted requests dealt round-robin over the workgroups - every workgroup (= CU) gets the same mix of
+                // sizes, and inside it the waves are homogeneous (rank r -> workgroup r mod G, slot r div G)
+                // (plan_sort = 3: the same over the WAVES - rank r -> wave r mod W: every wave gets the same sum of sizes, what counts if the
+                //  lanes of a wave serialise)
+                const int64_t per = h->plan_sort == 3 ? (int64_t)plan_lanes_now(h) : (int64_t)plan_lanes_now(h) * h->plan_waves, G = (m + per - 1) / per;
+                std::vector<int32_t> rank_of((size_t)m);
+                for (int64_t i = 0; i < m; ++i) rank_of[(size_t)count[key[(size_t)i]]++] = (int32_t)i;  // rank -> request
+                std::vector<int64_t> fill((size_t)G, 0);
+                // (the last workgroup may be short: a slot beyond the slice is skipped by giving the rank to the next workgroup with room)
+                int64_t g = 0;
+                for (int64_t r = 0; r < m; ++r) {
+                    for (int tries = 0; tries < G; ++tries, g = (g + 1) % G) {
+                        const int64_t pos = g * per + fill[(size_t)g];
+                        if (fill[(size_t)g] < per && pos < m) { perm[s0 + pos] = rank_of[(size_t)r]; ++fill[(size_t)g]; g = (g + 1) % G; break; }
+                    }
+                }
+            }
         }
     }
     // No copies on the planning stream: its kernels read the request arrays from, and write their results to, pinned host
