@@ -407,10 +407,10 @@ def c3_pandas(bn, n=131_072, sub_batch=32768):
                     "variables, cell, p - the query variable changes from request to request); batch[i] builds the Series query() returns"}
 
 
-def c3_variant(eng, to_var, n_evidence, calls=6, warmup_calls=8, batch=32768):
+def c3_variant(eng, to_var, n_evidence, calls=6, warmup_calls=10, batch=32768):
     """A short stepped run of the C3 stream with another number of evidence nodes, or on another engine ("also report the
     n_evidence in {1, 8, 16} variants"; VERDICT r3: the device-planned 2-thread rank): `calls` pipelined engine calls of `batch`
-    requests after `warmup_calls` (eight: the adaptive policy judges windows of two to three calls and moves the device's share of the planning in
+    requests after `warmup_calls` (ten: the adaptive policy judges windows of two to three calls and moves the device's share of the planning in
     steps - round 5's session C measured 421 k queries/s for n_evidence = 16 two calls after the switch and 518 k with the share it
     converges to), N = 1.  -> queries/s, MB per query, all-kernels GB/s, planner wall vs GPU busy time."""
     import netspec
@@ -896,7 +896,7 @@ def main():
                     for kv in a.opt:
                         k, v = kv.split("=")
                         eng2.set_option(k, float(v))
-                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=8, warmup_calls=8, batch=32768)
+                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=8, warmup_calls=16, batch=32768)  # (a fresh engine: its buffers, the share controller)
                     eng2.close()
                 except Exception as e:  # noqa: BLE001
                     out["configs"][name] = {"error": repr(e)}

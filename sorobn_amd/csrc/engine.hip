@@ -870,9 +870,11 @@ int pinned(mibn_ctx *h, mibn_ctx::Staging &sg, size_t bytes) {
 // VE kernels.  A rank of one or two planning threads is bound by its planning capacity (host + device), not by its kernels: 24
 // lanes (230 -> 246 k queries/s at one and two threads); from four threads on the kernels' share of the chip counts for more: 32
 // (258 / 254 k at 24 / 32 lanes and four threads, 263 / 269 k at six; profiles/r05_f_planlanes.log, r05_g_planlanes.log).
+// (Calls of 32 768 requests - such a rank's shard of a 2^18-request step on eight GPUs - are bound by the kernels again, whatever the lanes:
+//  250.3 / 251.5 k at 24 / 32 lanes and two threads, 240 / 250 k at one: 32 there.  profiles/r05_k_calls32k.log)
 static int plan_lanes_now(const mibn_ctx *h) {
     if (h->plan_lanes > 0) return h->plan_lanes;
-    return h->pool && h->pool->size() <= 2 ? 24 : 32;
+    return h->pool && h->pool->size() <= 2 && h->chunk > 32768 ? 24 : 32;
 }
 
 // Device order search for requests [b0, b1): uploads their query / evidence variables and launches order_kernel on a
@@ -1364,7 +1366,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 h->gpu_emit = 0;
                 h->auto_emit = false;
                 h->host_bound_streak = 0;
-            } else if (dp > MIBN_HOST_BOUND_RATIO * dk && ++h->host_bound_streak >= 2) {  // (twice in a row: the kernel time of a call is booked when its
+            } else if (dp > MIBN_HOST_BOUND_RATIO * dk && ++h->host_bound_streak >= (h->pool->size() <= 4 ? 2 : 1)) {  // (the long windows of a rank that is not starved need no second look)  // (twice in a row: the kernel time of a call is booked when its
                                                                           // launches retire, up to two calls late - one window can mislead)
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
                 // not cover give up the min-fill search for ever more expensive requests instead
