@@ -297,15 +297,15 @@ def f_configs(device, with_cpu=True):
     bn33.predict_proba(X1.iloc[:8])
     dt, pp = best_of(lambda: bn33.predict_proba(X1))
     out["F1_predict_proba_grid"] = {"rows_per_s": len(X1) / dt, "rows": len(X1), "seconds": dt, "network": "3x3 grid, K=4, nine observed columns",
-                                    "checksum": float(pp.sum()), "bound": "host: pandas MultiIndex look-up of the rows in the joint (the device computes the "
-                                    "262 144-cell joint once, 2 MB: HBM roofline n/a)"}
+                                    "checksum": float(pp.sum()), "bound": "host: the rows' labels encoded column by column (Index.get_indexer) + one gather from the dense joint (the device "
+                                    "computes the 262 144-cell joint once, 2 MB: HBM roofline n/a); the reference looks the rows up in a pandas MultiIndex"}
     grid = netspec.build(netspec.grid_spec(10, 10, 4, seed=0), sorobn_amd.BayesNet).use_device(device)
     Xg = frame(100_000, ["011", "055", "090"], 4, 1)
     grid.predict_proba(Xg.iloc[:4])
     dt, _ = best_of(lambda: grid.predict_proba(Xg))
     out["F1_predict_proba_grid10x10_3_columns"] = {"rows_per_s": len(Xg) / dt, "rows": len(Xg), "seconds": dt,
                                                    "reference": "cannot run: predict_proba builds the full joint (4^100 rows)",
-                                                   "bound": "host pandas look-up; the elimination of the 97 unobserved variables is one exact query"}
+                                                   "bound": "host label encoding + gather; the elimination of the 97 unobserved variables is one exact query"}
     # F2 likelihood weighting (bayes_net.py:621-663, forward sampling 518-575) on Asia
     asia = netspec.build({n["spec"]["name"]: n["spec"] for n in __import__("golden_util").load("examples.json")}["asia"], sorobn_amd.BayesNet).use_device(device)
     ev2 = {"Smoker": True, "Dispnea": True}
@@ -407,12 +407,13 @@ def c3_pandas(bn, n=131_072, sub_batch=32768):
                     "variables, cell, p - the query variable changes from request to request); batch[i] builds the Series query() returns"}
 
 
-def c3_variant(eng, to_var, n_evidence, calls=6, warmup_calls=10, batch=32768):
+def c3_variant(eng, to_var, n_evidence, calls=12, warmup_calls=10, batch=32768):
     """A short stepped run of the C3 stream with another number of evidence nodes, or on another engine ("also report the
     n_evidence in {1, 8, 16} variants"; VERDICT r3: the device-planned 2-thread rank): `calls` pipelined engine calls of `batch`
     requests after `warmup_calls` (ten: the adaptive policy judges windows of two to three calls and moves the device's share of the planning in
     steps - round 5's session C measured 421 k queries/s for n_evidence = 16 two calls after the switch and 518 k with the share it
-    converges to), N = 1.  -> queries/s, MB per query, all-kernels GB/s, planner wall vs GPU busy time."""
+    converges to; the timed region starts with an idle GPU, so the planning of its first call is not hidden: twelve calls
+    and more keep that ramp below a tenth), N = 1.  -> queries/s, MB per query, all-kernels GB/s, planner wall vs GPU busy time."""
     import netspec
     from sorobn_amd import sharding
     n = (calls + warmup_calls) * batch
@@ -896,7 +897,7 @@ def main():
                     for kv in a.opt:
                         k, v = kv.split("=")
                         eng2.set_option(k, float(v))
-                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=8, warmup_calls=16, batch=32768)  # (a fresh engine: its buffers, the share controller)
+                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=24, warmup_calls=16, batch=32768)  # (a fresh engine: its buffers, the share controller)
                     eng2.close()
                 except Exception as e:  # noqa: BLE001
                     out["configs"][name] = {"error": repr(e)}

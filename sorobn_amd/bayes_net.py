@@ -840,11 +840,45 @@ class BayesNet:
             return self.predict_proba(pd.DataFrame([X])).iloc[0]
         names = self._all_names()
         observed = [n for n in names if n in set(X.columns)]
+        if len(observed) > 1:
+            fast = self._predict_proba_rows(X, observed, f"P({', '.join(names)})")
+            if fast is not None:
+                return fast
         fjd = self.backend.joint_series(observed)
         fjd.name = f"P({', '.join(names)})"
         if len(observed) > 1:
             return fjd[pd.MultiIndex.from_frame(X[observed])]
         return fjd
+
+    def _predict_proba_rows(self, X, observed, name):
+        """`fjd[pd.MultiIndex.from_frame(X[observed])]` without the pandas look-up: the rows' labels are encoded column by column
+        (`Index.get_indexer` on the sorted label domains), the dense joint is gathered at the raveled codes, and the result carries
+        the index pandas' look-up returns - `fjd.index.take(positions)`: the joint's own levels with the rows' codes.  A row that
+        is not in the joint (a label outside a domain, probability zero) raises KeyError like the look-up does.  Returns None where
+        the columns cannot be encoded in bulk (unhashable / mixed labels): the caller takes the pandas path."""
+        be = self.backend
+        f = be.flat
+        try:
+            ids = [f.id[n] for n in observed]
+            codes = []
+            for n, v in zip(observed, ids):
+                c = f.dom_index[v].get_indexer(X[n])
+                codes.append(c)
+        except (KeyError, TypeError, ValueError, pd.errors.InvalidIndexError):
+            return None
+        shape = [int(f.card[v]) for v in ids]
+        bad = np.zeros(len(X), bool)
+        for c in codes:
+            bad |= c < 0
+        dense = be.marginal(observed)
+        flat = np.ravel_multi_index([np.where(bad, 0, c) for c in codes], shape) if len(X) else np.zeros(0, np.int64)
+        vals = dense[flat]
+        bad |= ~(vals > 0)
+        if bad.any():
+            rows = X[observed][bad].head(5).itertuples(index=False, name=None)
+            raise KeyError(f"{[tuple(r) for r in rows]} not in index")
+        idx = pd.MultiIndex(levels=[f.dom_index[v] for v in ids], codes=codes, names=list(observed), verify_integrity=False)
+        return pd.Series(vals, index=idx, name=name)
 
     def predict_log_proba(self, X):
         """bayes_net.py:964-973."""

@@ -1370,7 +1370,13 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                                                                           // launches retire, up to two calls late - one window can mislead)
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
                 // not cover give up the min-fill search for ever more expensive requests instead
-                if (h->order_net_ok && h->emit_net_ok && !h->gpu_emit) { h->gpu_emit = 1; h->auto_emit = true; }  // the whole planning, not only the search
+                if (h->order_net_ok && h->emit_net_ok && !h->gpu_emit) {  // the whole planning, not only the search
+                    h->gpu_emit = 1;
+                    h->auto_emit = true;
+                    h->host_rate = 0;  // (measured afresh beside the device planner: a rate left over from another workload - the line's
+                                       //  n_evidence = 1 variant plans 1 000 requests per ms, n_evidence = 16 500 - made "the host alone would
+                                       //  keep up" drop the device planner one window after every switch: round 5's session ZZ)
+                }
                 else if (h->order_net_ok && !h->emit_net_ok && !h->gpu_search) { h->gpu_search = 1; h->auto_search = true; }
                 else if (!h->order_net_ok) h->net.minfill_above = std::min(h->net.minfill_above * 8.0, 1e18);
             } else if (dp <= MIBN_HOST_BOUND_RATIO * dk) {
