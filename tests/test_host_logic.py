@@ -541,8 +541,9 @@ def test_result_conventions(asia):
         pd.testing.assert_series_equal(before[k], asia.P[k])
 
 
-def test_reference_unit_tests_replayed():
-    """test_bayes_net.py:158-226, 295-312 with the strict Series equality the reference uses."""
+def check_reference_unit_tests_replayed(attach):
+    """test_bayes_net.py:116-153, 158-226, 295-312 with the strict Series equality the reference uses; `attach(bn)` binds the backend - the CPU
+    plan simulator here, nothing on the GPU box (tests/test_gpu_parity.py::test_reference_unit_tests_replayed_on_the_gpu)."""
     edges = pd.DataFrame({"parent": ["A", "B"], "child": "C"})
     bn = sorobn_amd.BayesNet(*edges.itertuples(index=False, name=None))
     bn.P["A"] = pd.Series({True: 0.7, False: 0.3})
@@ -553,7 +554,7 @@ def test_reference_unit_tests_replayed():
                        "p": [1, 0, 0, 1, 0.5, 0.5, 0.001, 0.999]})
     bn.P["C"] = PC.set_index(["B", "A", "C"])["p"]
     bn.prepare()
-    simengine.attach(bn)
+    attach(bn)
     pd.testing.assert_series_equal(bn.query("C", event={"B": False, "A": True}),
                                    pd.Series([0.5, 0.5], name="P(C)", index=pd.Index([False, True], name="C")))
     bn = sorobn_amd.BayesNet(("A", "C"), ("B", "C"))
@@ -566,7 +567,7 @@ def test_reference_unit_tests_replayed():
     bn.prepare()
     P = bn.P["C"]
     assert isinstance(P, pd.Series) and P.index.names == ["A", "B", "C"] and P.groupby(["A", "B"]).sum().eq(1).all()
-    simengine.attach(bn)
+    attach(bn)
     pd.testing.assert_series_equal(bn.query("C", event={"A": True, "B": False}),
                                    pd.Series([0.5, 0.5], name="P(C)", index=pd.Index([False, True], name="C")))
     bn = sorobn_amd.BayesNet(("Weather", "Mood"))
@@ -574,7 +575,7 @@ def test_reference_unit_tests_replayed():
     bn.P["Mood"] = pd.DataFrame({"Weather": ["Sunny", "Sunny", "Rainy", "Rainy"],
                                  "Mood": ["Happy", "Sad", "Happy", "Sad"], "p": [0.9, 0.1, 0.4, 0.6]})
     bn.prepare()
-    simengine.attach(bn)
+    attach(bn)
     r = bn.query("Mood", event={"Weather": "Sunny"})
     assert r["Happy"] == pytest.approx(0.9) and r["Sad"] == pytest.approx(0.1)
     # independent variables, integer labels, no structure (test_bayes_net.py:116-153)
@@ -582,11 +583,15 @@ def test_reference_unit_tests_replayed():
     bn.P["A"] = pd.Series({1: .2, 2: .3, 3: .5})
     bn.P["B"] = pd.Series({1: .4, 2: .2, 3: .4})
     bn.prepare()
-    simengine.attach(bn)
+    attach(bn)
     for k in (1, 2, 3):
         a = bn.query("A", event={"B": k})
         assert a.index.tolist() == [1, 2, 3] and a.index.dtype == np.int64
         assert a.to_numpy() == pytest.approx([.2, .3, .5], abs=1e-15)
+
+
+def test_reference_unit_tests_replayed():
+    check_reference_unit_tests_replayed(simengine.attach)
 
 
 def test_prepare_errors_and_column_order():
