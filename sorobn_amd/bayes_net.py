@@ -454,16 +454,51 @@ class Backend:
             q_off, qv, e_off, evs, ecs = self.encode_many(requests)
             out, out_off = eng.query_batch(q_off, qv, e_off, evs, ecs)
             return PosteriorBatch(self, [q for q, _ in requests], out, np.asarray(out_off, np.int64))
+        # names / labels -> ids / codes on a helper thread, one sub-batch ahead: the engine calls below release the GIL (ctypes), so
+        # the encoding of sub-batch k + 1 runs while the planner works on k and the host waits for the kernels of k - 1
+        import queue
+        import threading
+        todo = queue.Queue(maxsize=2)
+
+        def produce():
+            try:
+                for a in range(0, n, sub_batch):
+                    chunk = requests[a:a + sub_batch]
+                    _, qv, _, evs, ecs = self.encode_many(chunk)
+                    todo.put((len(chunk), qv, evs, ecs))
+            except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread (the reference's KeyError for an unknown name)
+                todo.put(e)
+            todo.put(None)
+
+        worker = threading.Thread(target=produce, daemon=True)
+        worker.start()
         parts, pending, cells = [], None, []
-        for a in range(0, n, sub_batch):
-            chunk = requests[a:a + sub_batch]
-            _, qv, _, evs, ecs = self.encode_many(chunk)
-            b = len(chunk)
-            h = eng.submit_fixed(qv.reshape(b, nq0), evs.reshape(b, ne0), ecs.reshape(b, ne0))
-            if pending is not None:
-                parts.append(eng.wait(pending))
-            pending = h
-            cells.append(np.prod(eng.card[qv.reshape(b, nq0)].astype(np.int64), axis=1))
+        try:
+            while True:
+                item = todo.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                b, qv, evs, ecs = item
+                h = eng.submit_fixed(qv.reshape(b, nq0), evs.reshape(b, ne0), ecs.reshape(b, ne0))
+                if pending is not None:
+                    parts.append(eng.wait(pending))
+                pending = h
+                cells.append(np.prod(eng.card[qv.reshape(b, nq0)].astype(np.int64), axis=1))
+        except BaseException:
+            if pending is not None:  # (a call in flight writes into its pinned result buffer: collect it before the error leaves)
+                try:
+                    eng.wait(pending)
+                except Exception:  # noqa: BLE001
+                    pass
+            while worker.is_alive():  # let the producer finish (its queue may be full)
+                try:
+                    todo.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            raise
+        worker.join()
         parts.append(eng.wait(pending))
         out_off = np.zeros(n + 1, np.int64)
         np.cumsum(np.concatenate(cells), out=out_off[1:])
