@@ -30,6 +30,7 @@ import graphlib
 import itertools
 import operator
 import os
+import sys
 import types
 
 import numpy as np
@@ -46,6 +47,10 @@ def _default_device():
         if os.environ.get(key, "") != "":
             return int(os.environ[key])
     return 0
+
+
+class _Ragged(Exception):
+    """exact_many: a request whose arity differs from the first one's (the pipeline takes fixed-arity sub-batches)."""
 
 
 _get_index = operator.attrgetter("index")
@@ -443,17 +448,31 @@ class Backend:
         """The exact path over a list of (query tuple, event dict) -> `PosteriorBatch`.  Encoded in bulk, sent to the engine in
         sub-batches of `sub_batch` requests with two calls in flight (mibn_submit_batch / mibn_wait: sub-batch k + 1 is encoded
         and planned while the kernels of k run) when the batch is fixed-arity; a ragged batch goes as one blocking call."""
-        requests = [((q,) if isinstance(q, str) else tuple(q), e) for q, e in requests]
+        def checked(chunk):
+            """Query tuples normalised (a bare name is a 1-tuple) and the request checks of `query` (bayes_net.py:840-845)."""
+            chunk = [((q,) if isinstance(q, str) else tuple(q), e) for q, e in chunk]
+            for q, e in chunk:
+                if not q:
+                    raise ValueError("At least one query variable has to be specified")
+                if not e.keys().isdisjoint(q):
+                    raise ValueError("A query variable cannot be part of the event")
+            return chunk
+
         n = len(requests)
         eng = self.engine
         if n == 0:
             return PosteriorBatch(self, [], np.zeros(0), np.zeros(1, np.int64))
-        nq0, ne0 = len(requests[0][0]), len(requests[0][1])
-        fixed = hasattr(eng, "submit_fixed") and n > sub_batch and all(len(q) == nq0 and len(e) == ne0 for q, e in requests)
-        if not fixed:
+        if not (hasattr(eng, "submit_fixed") and n > sub_batch):
+            requests = checked(requests)
             q_off, qv, e_off, evs, ecs = self.encode_many(requests)
             out, out_off = eng.query_batch(q_off, qv, e_off, evs, ecs)
             return PosteriorBatch(self, [q for q, _ in requests], out, np.asarray(out_off, np.int64))
+        # a long batch: sub-batches through the two-deep pipeline.  Checked, normalised and encoded sub-batch by sub-batch on a helper
+        # thread (a malformed request in sub-batch k raises after the sub-batches before it have run; nothing is returned); the
+        # pipeline takes fixed-arity batches - the arity of the first request - and a ragged one falls back to ONE blocking call
+        q00 = requests[0][0]
+        nq0, ne0 = (1 if isinstance(q00, str) else len(q00)), len(requests[0][1])
+        queries = []
         # names / labels -> ids / codes on a helper thread, one sub-batch ahead: the engine calls below release the GIL (ctypes), so
         # the encoding of sub-batch k + 1 runs while the planner works on k and the host waits for the kernels of k - 1
         import queue
@@ -463,8 +482,11 @@ class Backend:
         def produce():
             try:
                 for a in range(0, n, sub_batch):
-                    chunk = requests[a:a + sub_batch]
+                    chunk = checked(requests[a:a + sub_batch])
+                    if not all(len(q) == nq0 and len(e) == ne0 for q, e in chunk):
+                        raise _Ragged()
                     _, qv, _, evs, ecs = self.encode_many(chunk)
+                    queries.extend(q for q, _ in chunk)
                     todo.put((len(chunk), qv, evs, ecs))
             except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread (the reference's KeyError for an unknown name)
                 todo.put(e)
@@ -497,12 +519,17 @@ class Backend:
                     todo.get(timeout=0.05)
                 except queue.Empty:
                     pass
+            if isinstance(sys.exc_info()[1], _Ragged):  # requests of different arity: the general CSR call, once
+                requests = checked(requests)
+                q_off, qv, e_off, evs, ecs = self.encode_many(requests)
+                out, out_off = eng.query_batch(q_off, qv, e_off, evs, ecs)
+                return PosteriorBatch(self, [q for q, _ in requests], out, np.asarray(out_off, np.int64))
             raise
         worker.join()
         parts.append(eng.wait(pending))
         out_off = np.zeros(n + 1, np.int64)
         np.cumsum(np.concatenate(cells), out=out_off[1:])
-        return PosteriorBatch(self, [q for q, _ in requests], np.concatenate([p.reshape(-1) for p in parts]), out_off)
+        return PosteriorBatch(self, queries, np.concatenate([p.reshape(-1) for p in parts]), out_off)
 
     def gibbs_sampling(self, *query, event, n_iterations, n_chains=1, seed=0):
         q, ev, codes = self.encode(query, event)
@@ -777,13 +804,7 @@ class BayesNet:
         the Series `query(*q_i, event=e_i)` returns (identical: name, index, level order, row order, values).  Names and labels are
         encoded in bulk, the device works through sub-batches with two calls in flight, and the Series are built on access;
         `.to_frame()` gives every answer as one pandas object."""
-        requests = [((q,) if isinstance(q, str) else tuple(q), e) for q, e in requests]
-        for q, e in requests:
-            if not q:
-                raise ValueError("At least one query variable has to be specified")
-            if not e.keys().isdisjoint(q):
-                raise ValueError("A query variable cannot be part of the event")
-        return self.backend.exact_many(requests, sub_batch=sub_batch)
+        return self.backend.exact_many(requests if isinstance(requests, list) else list(requests), sub_batch=sub_batch)
 
     def query_frame(self, *query, events: pd.DataFrame) -> pd.DataFrame:
         """The fixed-query batch in pandas' own shape (an extension; the reference answers one event per call, bayes_net.py:796):

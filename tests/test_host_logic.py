@@ -1077,3 +1077,37 @@ def test_planner_output_is_pinned(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600).stdout
     want = open(os.path.join(ROOT, "tools", "plan_fingerprint.expected.txt")).read()
     assert out.splitlines() == want.splitlines()
+
+
+def test_query_many_pipeline_on_the_simulator():
+    """Backend.exact_many's long-batch path (sub-batches checked / encoded on a helper thread, two engine calls in flight) with the plan
+    simulator behind a submit_fixed / wait pair: the same answers as the one-call path, a ragged batch falls back to one CSR call, a
+    malformed or unknown request raises on the caller's thread after the call in flight has been collected."""
+    spec = netspec.grid_spec(4, 4, 3, seed=2)
+    bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
+    eng = bn.backend.engine
+    waited = []
+    eng.submit_fixed = lambda q, e, c: eng.query_fixed(q, e, c)
+    eng.wait = lambda h: (waited.append(len(h)), h)[1]
+    q, ev, ec = netspec.c3_requests(16, 3, 70, 2, seed=4)
+    reqs = [((f"{a:03d}",), {f"{v:03d}": int(c) for v, c in zip(vs, cs)}) for a, vs, cs in zip(q.tolist(), ev.tolist(), ec.tolist())]
+    one_call = bn.query_many(reqs)                      # 70 requests <= the default sub-batch: one call
+    assert not waited
+    piped = bn.query_many(reqs, sub_batch=16)           # five sub-batches through the pipeline
+    assert waited == [16, 16, 16, 16, 6] and np.array_equal(piped.out, one_call.out) and np.array_equal(piped.out_off, one_call.out_off)
+    for i in (0, 15, 16, 69):
+        pd.testing.assert_series_equal(piped[i], bn.query(*reqs[i][0], event=reqs[i][1]), check_exact=True)
+    bare = [(r[0][0], r[1]) for r in reqs]              # bare names instead of 1-tuples
+    assert np.array_equal(bn.query_many(bare, sub_batch=16).out, one_call.out)
+    ragged = list(reqs)
+    ragged[40] = (("000", "015"), {"005": 1})           # another arity in the third sub-batch: one CSR call for everything
+    del waited[:]
+    rg = bn.query_many(ragged, sub_batch=16)
+    assert len(rg) == 70 and len(rg.dense(40)) == 9 and np.array_equal(rg.dense(41), one_call.dense(41))
+    pd.testing.assert_series_equal(rg[40], bn.query("000", "015", event={"005": 1}), check_exact=True)
+    for bad, exc in (((("no such node",), {"000": 0}), KeyError), ((("003",), {"003": 1}), ValueError), (((), {"003": 1}), ValueError)):
+        broken = list(reqs)
+        broken[50] = bad
+        with pytest.raises(exc):
+            bn.query_many(broken, sub_batch=16)
+    assert np.array_equal(bn.query_many(reqs, sub_batch=16).out, one_call.out)  # the backend is as usable as before
