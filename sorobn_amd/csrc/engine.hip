@@ -65,7 +65,10 @@ struct OrderArgs {
 #ifndef MIBN_EMIT_WAVES_PER_EU
 #define MIBN_EMIT_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(1024, MIBN_ORDER_WAVES_PER_EU) void order_kernel(const OrderArgs A) {
+#ifndef MIBN_PLAN_WG
+#define MIBN_PLAN_WG 1024  // largest workgroup of the planner's kernels (option plan_waves x 64 must not exceed it)
+#endif
+__global__ __launch_bounds__(MIBN_PLAN_WG, MIBN_ORDER_WAVES_PER_EU) void order_kernel(const OrderArgs A) {
     if (A.zero && blockIdx.x == 0 && threadIdx.x == 0) *A.zero = 0;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
     if (lane >= A.lanes) return;
@@ -116,7 +119,7 @@ struct EmitArgs {
 __device__ unsigned long long g_emit_prof[12];  // 100 MHz ticks per phase, summed over the lanes (see MIBN_TICK in emit_core.h)
 #endif
 
-__global__ __launch_bounds__(1024, MIBN_EMIT_WAVES_PER_EU) void emit_kernel(const EmitArgs A) {
+__global__ __launch_bounds__(MIBN_PLAN_WG, MIBN_EMIT_WAVES_PER_EU) void emit_kernel(const EmitArgs A) {
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
     if (lane >= A.lanes) return;
     const int64_t pos = ((int64_t)blockIdx.x * waves + wave) * A.lanes + lane;
