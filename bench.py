@@ -22,8 +22,12 @@ Rank 0 prints ONE JSON line with the driver's contract fields plus
                   host cores on the first requests of the same stream, no cost filter, under a wall budget: one process
                   (cores 1 - the reference is single-threaded) and an N-process aggregate with N stated; the C port of
                   the oracle is reported next to it as `cpu_port`
-  `configs`       the other BASELINE.json configurations measured in the same process after the C3 region: C1 (alarm,
-                  single query latency), C2 (Asia, 100 k batched queries), C5 (Gibbs, 100 k updates x chains)
+  `configs`       measured in the same process after the C3 region: C1 (alarm, single query latency), C2 (Asia, 100 k batched queries),
+                  C5 (Gibbs, 100 k updates x chains), each beside the reference where it runs; `C3_n_evidence_{1,8,16}`;
+                  `C3_two_planner_threads`, `C3_planner_threads_{1,4}` (fresh engines with that many planning workers: the ranks of
+                  an 8-GPU node with a small CPU quota) and `projected_8gpu` computed from them; `C3_query_many_pandas` (Python
+                  request objects in, one pandas object out); `F1` - `F4`, the section-8(f) rows (predict_proba, likelihood
+                  weighting, fit, Chow-Liu) with the unmodified reference timed beside each
 `--config c5` times the Gibbs configuration instead (a step = 100 k single-site updates x 128 chains per GPU + the
 int64 histogram reduce).
 """
