@@ -56,7 +56,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def pmc_ratio(kernel):
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+    # (the newest session: by round, a round's closing session - "..._final_..." - last)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), key=lambda p: (os.path.basename(p)[:3], "_final_" in p, os.path.basename(p))):
         try:
             d = json.load(open(f))
         except Exception:
