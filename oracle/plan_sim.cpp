@@ -660,6 +660,7 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     net.sweep = g_sweep;
     net.sweep_min = g_sweep_min;
     net.set_hints(n_hints, hints);
+    net.plan_cache = 0;  // PLANNING is what is timed: the second pass over the same requests must not be answered from templates of the first
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
     for (int64_t b = 0; b <= B; ++b) { q_off[b] = b * nq; e_off[b] = b * ne; out_off[b] = b * 4; }
     BatchPlan bp;
