@@ -256,3 +256,36 @@ def test_id_exchange_publishes_an_error_marker(tmp_path):
     with pytest.raises(RuntimeError, match="rank 0 could not create the RCCL id"):
         exchange_id(1, 2, None, path=path, timeout_s=30)
     assert __import__("time").time() - t0 < 5
+
+
+def test_projected_8gpu_block_is_reproducible_from_the_line():
+    """DESIGN section 7's 8-GPU projection must follow from the driver's JSON - `bench.project_8gpu` interpolates the
+    measured few-threads rates at (this box's CPU quota / 8) planning threads and multiplies by eight; checked on a made-up line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    line = {"value": 300_000.0, "configs": {"C3_planner_threads_1": {"queries_per_s": 240_000.0}, "C3_two_planner_threads": {"queries_per_s": 250_000.0},
+                                            "C3_planner_threads_4": {"queries_per_s": 260_000.0}}}
+    quota = bench.host_cpu_quota()
+    p = bench.project_8gpu(line)
+    assert p["host_cpu_quota"] == quota and p["planner_threads_per_rank_on_8_gpus_same_quota"] == quota / 8
+    t = quota / 8
+    pts = {1.0: 240e3, 2.0: 250e3, 4.0: 260e3, max(quota, 5.0): 300e3}
+    xs = sorted(pts)
+    if t <= xs[0]:
+        want = pts[xs[0]] * (t if t < 1 else 1.0)
+    elif t >= xs[-1]:
+        want = pts[xs[-1]]
+    else:
+        lo = max(x for x in xs if x <= t)
+        hi = min(x for x in xs if x >= t)
+        want = pts[lo] if hi == lo else pts[lo] + (pts[hi] - pts[lo]) * (t - lo) / (hi - lo)
+    assert abs(p["per_rank_queries_per_s"] - want) < 1e-6 * want
+    assert abs(p["node_queries_per_s"] - 8 * want) < 1e-6 * want and abs(p["scaling_vs_this_line"] - 8 * want / 300e3) < 1e-9
+    assert "PROJECTION" in p["note"]
+
+
+def test_gpu_session_script_parses():
+    r = subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", "gpu_session.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(["bash", "-n", os.path.join(ROOT, "tools", "gpu_profile.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
