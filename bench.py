@@ -63,6 +63,8 @@ def pmc_ratio(kernel):
         except Exception:
             continue
         k = d.get("per_kernel", {}).get(kernel)
+        if k is None and kernel.startswith("level:"):  # (sessions before round 6 named the level's concurrent launches after two of its kernels)
+            k = d.get("per_kernel", {}).get("ve_level_kernel||ve_sweep_dma_kernel")
         if k and k.get("alg_bytes_per_launch_same_run"):
             best = (f, k)
     if not best:
@@ -795,8 +797,8 @@ def main():
                                                 "ms_per_launch": d["ms"] / la, "launches": la, "traffic": None, "traffic_over_alg": pmc_ratio(n)[0],
                                                 "share_of_kernel_time": d["ms"] / agg["kernel_ms"]}
         if "||" in dom:
-            out["roofline"]["note"] = ("option overlap (default): the launches of a level - one of ve_level_kernel, one of ve_sweep_dma_kernel, one of "
-                                       "ve_segment_kernel, items of different requests - run CONCURRENTLY on three streams; the unit whose duration means anything "
+            out["roofline"]["note"] = ("option overlap (default): the launches of a level - one each of ve_level_kernel, ve_mfma_kernel, ve_sweep_dma_kernel and "
+                                       "ve_segment_kernel, items of different requests - run CONCURRENTLY on four streams; the unit whose duration means anything "
                                        "is the level (from the earliest start to the latest end of its launches, HIP events): `kernel` names it, `launches` = levels; "
                                        "rocprofv3's kernel trace gives the same unit as the connected components of the kernels' intervals "
                                        "(tools/rocprof_summary.py, profiles/r04_o_rocprofv3_summary.txt).  The kernels' own event durations (per_kernel) then include "
@@ -920,9 +922,43 @@ def main():
                 out["configs"].update(f_configs(device, with_cpu=not a.no_cpu))
             except Exception as e:  # noqa: BLE001
                 out["configs"]["F_rows"] = {"error": repr(e)}
+        out["summary"] = summary_of(out)  # LAST key: what a 2 000-byte tail of the line still shows
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()
+
+
+def summary_of(out):
+    """The figures a reader of the line's END needs (the driver records the last 2 000 bytes of a ~20 KB line):
+    compact keys, rounded numbers, < 1 500 bytes.  q = queries/s, gb = gpu_bound, dev = device-planned requests per call."""
+    cf = out.get("configs", {}) if isinstance(out.get("configs"), dict) else {}
+
+    def g(name, key, nd=0):
+        v = cf.get(name, {}).get(key) if isinstance(cf.get(name), dict) else None
+        return None if v is None else (round(v, nd) if nd else (int(round(v)) if isinstance(v, float) else v))
+
+    def variant(name):
+        return {"q": g(name, "queries_per_s"), "gb": g(name, "gpu_bound"), "GBps": g(name, "all_kernels_GBps"), "dev": g(name, "device_planned_requests_per_call")}
+
+    r = out["roofline"]
+    ser = r.get("per_kernel_serialised", {}) if isinstance(r.get("per_kernel_serialised"), dict) else {}
+    s = {"q": int(round(out["value"])), "ms": round(out["ms_per_step"], 1), "frac": round(r["frac"], 3), "all_GBps": int(round(r["all_kernels_GBps"])),
+         "MB_q": round(r["alg_bytes_per_query"] / 1e6, 2), "gb": out["pipeline_clocks_ms_per_step"]["gpu_bound"],
+         "ser_frac": {k.replace("ve_", "").replace("_kernel", ""): round(v["frac"], 3) for k, v in ser.items() if isinstance(v, dict) and "frac" in v},
+         "C1_ms": g("C1_alarm_single_query", "ms_per_query", 3), "C2_q": g("C2_asia_100k", "queries_per_s"),
+         "C5_ms": g("C5_gibbs_128_chains_x_100k", "wall_ms", 1), "C5_err": g("C5_gibbs_128_chains_x_100k", "max_abs_err_vs_exact", 5),
+         "nev1": variant("C3_n_evidence_1"), "nev8": variant("C3_n_evidence_8"), "nev16": variant("C3_n_evidence_16"),
+         "thr1": variant("C3_planner_threads_1"), "thr2": variant("C3_two_planner_threads"), "thr4": variant("C3_planner_threads_4"),
+         "pandas_q": g("C3_query_many_pandas", "queries_per_s")}
+    if "projected_8gpu" in out:
+        s["proj8"] = round(out["projected_8gpu"]["scaling_vs_this_line"], 2)
+    if "cpu_baseline" in out:
+        s["ref_q_1core"] = round(out["cpu_baseline"].get("value", 0.0), 4)
+    if "max_abs_marginal_err_vs_reference" in out:
+        s["err_ref"] = out["max_abs_marginal_err_vs_reference"]["value"]
+    if "shared_prefix" in r:
+        s["MB_q_indep"] = round(r["shared_prefix"].get("independent_alg_bytes_per_query", 0.0) / 1e6, 2)
+    return s
 
 
 def run_c5(a, rank, world, local_rank, device, backend):
@@ -974,7 +1010,12 @@ def run_c5(a, rank, world, local_rank, device, backend):
                           "parallelism": f"dp{world} (chain shards of one Philox stream, int64 histogram reduce)"},
                "roofline": {"bound": "latency/LDS (CPTs resident in LDS): HBM roofline n/a", "achieved": None, "peak": None,
                             "unit": None, "frac": None, "traffic": None},
-               "max_abs_err_vs_exact": float(np.max(np.abs(est - exact)))}
+               "max_abs_err_vs_exact": float(np.max(np.abs(est - exact))),
+               # the pooled int64 histogram of the timed steps (seeds 1000 + step): any split of the chains over ranks reproduces the
+               # unsharded one bit for bit (mibn_gibbs_shard: the Philox key is the global chain index) - the dry run checks exactly that
+               "histogram": [int(x) for x in hist], "chains_total": total_chains, "seeds": [1000 + s for s in range(a.warmup, a.warmup + a.steps)],
+               "reduce": {"none": "none", "rccl": "RCCL via the C-ABI (mibn_comm_reduce_i64), no PyTorch",
+                          "files": "DRY RUN (MIBN_BENCH_BACKEND=files): the reduce through files"}[transport]}
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.close()

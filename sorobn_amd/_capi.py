@@ -282,6 +282,12 @@ class Engine:
         self._check(self._L.mibn_wait(self._h, handle["ticket"]))
         return handle["out"][:handle["n"]].reshape(handle["B"], -1) if handle["B"] else handle["out"][:0].reshape(0, 0)
 
+    def wait_flat(self, handle):
+        """wait() for a call whose query tables differ in size from request to request (a 2-state and a 3-state query
+        variable in one fixed-arity batch): the posteriors back to back, request i at the offsets the caller derives from the cards."""
+        self._check(self._L.mibn_wait(self._h, handle["ticket"]))
+        return handle["out"][:handle["n"]]
+
     def drain(self):
         self._check(self._L.mibn_drain(self._h))
 

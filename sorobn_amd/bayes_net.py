@@ -359,7 +359,9 @@ class Backend:
         if shape is None:
             keep = np.flatnonzero(dense > 0)
             if len(keep) == len(dense):
-                return pd.Series(dense, index=levels, name=name)
+                # (a view of the cached Index - renaming the answer's index must not reach the cache - and, for an answer that is a
+                # slice of a batch's buffer, its own numbers: ADVICE r5)
+                return pd.Series(dense if dense.base is None else dense.copy(), index=levels.view(), name=name)
             return pd.Series(dense[keep], index=levels[keep], name=name)
         if order is not None:
             dense = np.ascontiguousarray(dense.reshape(shape).transpose(order)).reshape(-1)
@@ -478,19 +480,31 @@ class Backend:
         import queue
         import threading
         todo = queue.Queue(maxsize=2)
+        stop = threading.Event()  # set by the consumer when it gives up: the producer does not encode the rest of a 1 M-request batch
+        # query tables of different sizes in one fixed-arity batch (a 2-state and a 3-state query variable): the engine's flat
+        # wait; an engine without one (the test doubles) takes such a batch through the general CSR call
+        wait_flat = getattr(eng, "wait_flat", None)
 
         def produce():
             try:
                 for a in range(0, n, sub_batch):
+                    if stop.is_set():
+                        break
                     chunk = checked(requests[a:a + sub_batch])
                     if not all(len(q) == nq0 and len(e) == ne0 for q, e in chunk):
                         raise _Ragged()
                     _, qv, _, evs, ecs = self.encode_many(chunk)
+                    cells = np.prod(eng.card[qv.reshape(len(chunk), nq0)].astype(np.int64), axis=1)
+                    if wait_flat is None and len(cells) and cells.min() != cells.max():
+                        raise _Ragged()
                     queries.extend(q for q, _ in chunk)
-                    todo.put((len(chunk), qv, evs, ecs))
+                    todo.put((len(chunk), qv, evs, ecs, cells))
             except BaseException as e:  # noqa: BLE001 - re-raised on the calling thread (the reference's KeyError for an unknown name)
                 todo.put(e)
             todo.put(None)
+
+        def collect(h):
+            return (wait_flat(h) if wait_flat is not None else eng.wait(h)).reshape(-1)
 
         worker = threading.Thread(target=produce, daemon=True)
         worker.start()
@@ -502,16 +516,19 @@ class Backend:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                b, qv, evs, ecs = item
+                b, qv, evs, ecs, c = item
                 h = eng.submit_fixed(qv.reshape(b, nq0), evs.reshape(b, ne0), ecs.reshape(b, ne0))
                 if pending is not None:
-                    parts.append(eng.wait(pending))
+                    prev, pending = pending, h  # (cleared before the wait: an error inside it must not wait on the same ticket again)
+                    parts.append(collect(prev))
                 pending = h
-                cells.append(np.prod(eng.card[qv.reshape(b, nq0)].astype(np.int64), axis=1))
+                cells.append(c)
         except BaseException:
-            if pending is not None:  # (a call in flight writes into its pinned result buffer: collect it before the error leaves)
+            stop.set()
+            last, pending = pending, None
+            if last is not None:  # (a call in flight writes into its pinned result buffer: collect it before the error leaves)
                 try:
-                    eng.wait(pending)
+                    eng.wait(last)
                 except Exception:  # noqa: BLE001
                     pass
             while worker.is_alive():  # let the producer finish (its queue may be full)
@@ -526,10 +543,10 @@ class Backend:
                 return PosteriorBatch(self, [q for q, _ in requests], out, np.asarray(out_off, np.int64))
             raise
         worker.join()
-        parts.append(eng.wait(pending))
+        parts.append(collect(pending))
         out_off = np.zeros(n + 1, np.int64)
         np.cumsum(np.concatenate(cells), out=out_off[1:])
-        return PosteriorBatch(self, queries, np.concatenate([p.reshape(-1) for p in parts]), out_off)
+        return PosteriorBatch(self, queries, np.concatenate(parts), out_off)
 
     def gibbs_sampling(self, *query, event, n_iterations, n_chains=1, seed=0):
         q, ev, codes = self.encode(query, event)
@@ -784,7 +801,9 @@ class BayesNet:
         """
         self._check_request(query, event)
         if algorithm == "exact":
-            if "_variable_elimination" not in self.__dict__:  # (not re-bound on this object, e.g. by accelerate())
+            # (the hook the reference's query() dispatches to, bayes_net.py:848, is honoured: not re-bound on this object - e.g. by
+            # accelerate() - and not overridden by a subclass)
+            if "_variable_elimination" not in self.__dict__ and type(self)._variable_elimination is BayesNet._variable_elimination:
                 return self.backend.exact_query(query, event)  # the finished Series, built directly (Backend._tail)
             answer = self._variable_elimination(*query, event=event)
         elif algorithm == "gibbs":

@@ -766,7 +766,7 @@ void ensure_pool(mibn_ctx *h) {
 
 // name of statistics slot k: the classes of work (split_kinds), then the kernels as launched
 const char *stat_name(int k) {
-    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : (k == kNumKernels + 2 ? "ve_sweep_dma_kernel" : (k == kNumKernels + 3 ? "order_kernel+emit_kernel" : (k == kNumKernels + 4 ? "ve_level_kernel||ve_sweep_dma_kernel" : (k == kNumKernels + 5 ? "ve_segment_kernel" : "ve_mfma_kernel"))))));
+    return k < kNumKernels ? kernel_name(k) : (k == kNumKernels ? "ve_level_kernel" : (k == kNumKernels + 1 ? "tiny_kernel" : (k == kNumKernels + 2 ? "ve_sweep_dma_kernel" : (k == kNumKernels + 3 ? "order_kernel+emit_kernel" : (k == kNumKernels + 4 ? "level:ve_level_kernel||ve_mfma_kernel||ve_sweep_dma_kernel||ve_segment_kernel" : (k == kNumKernels + 5 ? "ve_segment_kernel" : "ve_mfma_kernel"))))));
 }
 
 // wait for a set's launches and book their HIP-event durations per kernel

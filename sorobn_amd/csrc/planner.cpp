@@ -806,8 +806,8 @@ struct PlanCache {
     bool on = true;
     // The first kProbe requests of every window are looked up (and recorded); a quarter of them hitting keeps the cache on for the
     // rest of the window.  Round 5: the window of a worker whose probes fail doubles from kMinWindow to kMaxWindow (a stream that never
-    // repeats a shape - C3 - ends up probing 0.4 % of its requests, 1.6 % before) and falls back to kMinWindow with the first probe
-    // that hits - a stream of few shapes whose store was empty at the first probe (the n_evidence = 1 variant: 9 900 shapes, thirty-two
+    // repeats a shape - C3 - ends up probing 0.4 % of its requests, 1.6 % before) and falls back to kMinWindow with the first window
+    // in which at least a quarter of the probes hit (a sparse-hit stream keeps doubling: its templates would not pay) - a stream of few shapes whose store was empty at the first probe (the n_evidence = 1 variant: 9 900 shapes, thirty-two
     // workers of 1 600 requests per call) used to wait 32 768 requests PER WORKER - twenty calls - for its second chance.
     static constexpr uint64_t kMinWindow = 1024, kMaxWindow = 65536, kProbe = 256;
     uint64_t window = kMinWindow;
@@ -844,6 +844,7 @@ PlanCache &plan_cache(const TemplateStore *ts) {
         c.version = ts->version;
         c.seen = c.probe_hits = 0;
         c.on = true;
+        c.window = PlanCache::kMinWindow;  // (another network / option set starts from the short window again)
     }
     return c;
 }

@@ -143,6 +143,36 @@ def test_bench_dry_run_of_config_4():
     assert len(echo) >= 2 and all("device" in l and "pci" in l for l in echo), r.stderr[-2000:]  # rank / device / links, once per rank
 
 
+@pytest.mark.gpu
+def test_bench_dry_run_of_config_5():
+    """BASELINE config 5's launch path rehearsed like config 4's: `python bench.py --gpus 2 --config c5` under
+    MIBN_BENCH_BACKEND=files - spawn, librccl probe, vote, rank 0's real ncclGetUniqueId, the id exchange, 2 x 128 chains of ONE Philox
+    stream through mibn_gibbs_shard, the int64 histogram reduce onto rank 0 (through files: RCCL refuses two ranks on one device).  The
+    pooled histogram is bit for bit the one of the unsharded call with 256 chains, and the estimate agrees with the exact posterior."""
+    env = dict(os.environ, MIBN_BENCH_BACKEND="files")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c5", "--steps", "1", "--warmup", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(next(l for l in r.stdout.splitlines() if l.startswith('{"metric"')))
+    assert out["n_gpus"] == 2 and out["chains_total"] == 256 and out["seeds"] == [1000] and out["reduce"].startswith("DRY RUN")
+    assert out["max_abs_err_vs_exact"] < 5e-3, out["max_abs_err_vs_exact"]
+    import numpy as np
+    import netspec
+    import sorobn_amd
+    bn5 = netspec.build(netspec.grid_spec(5, 10, 8, seed=0), sorobn_amd.BayesNet).use_device(0)
+    be = bn5.backend
+    rng = np.random.default_rng(1)
+    ev5 = {f"{k:03d}": int(rng.integers(0, 8)) for k in (0, 9, 40, 49, 22)}
+    q, evs, codes = be.encode(("025",), ev5)
+    cycle = sorted([v for v in range(len(be.flat.names)) if v not in set(evs)], key=lambda v: be.flat.names[v])
+    whole = be.engine.gibbs(q, evs, codes, 256, 100_000, seed=1000, cycle=cycle)
+    assert [int(x) for x in whole] == out["histogram"]
+    echo = [l for l in r.stderr.splitlines() if l.startswith("[mibn comm] rank ")]
+    assert len(echo) >= 2, r.stderr[-2000:]
+
+
 def test_collective_vote_without_a_communicator(tmp_path):
     """sharding.all_agree: the ranks of a launch agree on a boolean through marker files (it decides whether a communicator
     can be built at all): one rank's failure is everybody's verdict, and a stale marker of an earlier launch - same tag,

@@ -141,12 +141,16 @@ def test_golden_huge_cardinalities(amd, small_cells, tiling, fuse):
     print(f"huge cardinalities, small_cells {small_cells} tiling {tiling} fuse {fuse}: classes run = {sorted(seen)}")
 
 
+@pytest.mark.parametrize("mfma_kernel", [1, 0])
 @pytest.mark.parametrize("small_cells,tiling,fuse", [(1024, (4096, 0), 1), (3, (4, 1), 1), (20, (64, 2), 1), (3, (4, 1), 0)])
-def test_golden_small_grids(amd, small_cells, tiling, fuse):
+def test_golden_small_grids(amd, small_cells, tiling, fuse, mfma_kernel):
+    """(mfma_kernel = 0, VERDICT r5 item 4a: the forcing options put the MFMA pair classes on the small grids; with the option off they run
+    inside ve_level_kernel instead of ve_mfma_kernel - both twins against the reference's answers.)"""
     for entry in gu.load("grids_small.json"):
         spec = gu.grid_spec_from_recipe(entry)
         bn = netspec.build(spec, amd.BayesNet)
         bn.backend.engine.set_option("tiny", 0)  # (the small-network kernel has its own test below)
+        bn.backend.engine.set_option("mfma_kernel", mfma_kernel)
         bn.backend.engine.set_option("small_cells", small_cells)
         bn.backend.engine.set_option("big_iters", tiling[0])
         bn.backend.engine.set_option("tile_h", tiling[1])
@@ -507,8 +511,10 @@ def test_schedule_and_effort_options_do_not_change_answers(amd):
     be.engine.set_option("stagger", 1)
     # round 2: the sweep kernel on its own stream, other workgroup sizes of its launches, the chunking of a call - the same
     # programs in another schedule: bit for bit
+    # (round 6: "mfma_kernel" 0 sends the one-table MFMA pair classes back through their twin inside ve_level_kernel - the same tile code,
+    # fiber_mfma_call, with the output offsets in registers instead of LDS)
     for name, value, back in (("overlap", 0, 1), ("streams", 2, 1), ("sweep_iters", 4, 8), ("sweep_iters", 2, 8), ("sweep_adapt", 0, 4096),
-                              ("first_chunk", 0, 1), ("first_chunk", 2, 1), ("chunk_sets", 3, 2), ("chunk", 4096, 32768)):
+                              ("first_chunk", 0, 1), ("first_chunk", 2, 1), ("chunk_sets", 3, 2), ("chunk", 4096, 32768), ("mfma_kernel", 0, 1)):
         be.engine.set_option(name, value)
         assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), base), (name, value)
         be.engine.set_option(name, back)

@@ -1111,3 +1111,71 @@ def test_query_many_pipeline_on_the_simulator():
         with pytest.raises(exc):
             bn.query_many(broken, sub_batch=16)
     assert np.array_equal(bn.query_many(reqs, sub_batch=16).out, one_call.out)  # the backend is as usable as before
+
+
+def test_query_many_pipeline_mixed_query_cardinalities():
+    """a long fixed-arity batch whose query variable alternates between a 2-state and a 3-state node.  The pipelined
+    path used to reshape every sub-batch's posteriors to [B, cells]; now an engine with `wait_flat` (the real one) returns them back to
+    back, and an engine without it (a test double) takes the batch through the general CSR call.  Both against the one-call path."""
+    rng = np.random.default_rng(5)
+    bn = sorobn_amd.BayesNet(("a", "b"), ("a", "c"), ("b", "d"), ("c", "d"))
+    bn.P["a"] = pd.Series([0.3, 0.7], index=[0, 1])
+    bn.P["b"] = pd.Series(rng.dirichlet(np.ones(3), size=2).reshape(-1), index=pd.MultiIndex.from_product([[0, 1], [0, 1, 2]], names=["a", "b"]))
+    bn.P["c"] = pd.Series(rng.dirichlet(np.ones(2), size=2).reshape(-1), index=pd.MultiIndex.from_product([[0, 1], [0, 1]], names=["a", "c"]))
+    bn.P["d"] = pd.Series(rng.dirichlet(np.ones(3), size=6).reshape(-1),
+                          index=pd.MultiIndex.from_product([[0, 1, 2], [0, 1], [0, 1, 2]], names=["b", "c", "d"]))
+    bn.prepare()
+    bn = simengine.attach(bn)
+    eng = bn.backend.engine
+    reqs = [(("c",) if i % 2 else ("b",), {"a": int(i % 2)}) for i in range(22)]  # cells 3, 2, 3, 2, ...: 5 per pair - not divisible by a sub-batch of 4
+    one_call = bn.query_many(reqs)
+    assert [len(one_call.dense(i)) for i in range(4)] == [3, 2, 3, 2]
+
+    def submit(q, e, c):  # what the real engine does: the posteriors of a sub-batch back to back
+        B = len(q)
+        out, off = eng.query_batch(np.arange(B + 1) * q.shape[1], q.reshape(-1), np.arange(B + 1) * e.shape[1], e.reshape(-1), c.reshape(-1))
+        return out
+    eng.submit_fixed = submit
+    flat_calls = []
+    eng.wait_flat = lambda h: (flat_calls.append(len(h)), h)[1]
+    eng.wait = lambda h: h
+    piped = bn.query_many(reqs, sub_batch=4)
+    assert flat_calls == [10, 10, 10, 10, 10, 5] and np.array_equal(piped.out, one_call.out) and np.array_equal(piped.out_off, one_call.out_off)
+    for i in (0, 1, 21):
+        pd.testing.assert_series_equal(piped[i], bn.query(*reqs[i][0], event=reqs[i][1]), check_exact=True)
+    del eng.wait_flat  # an engine without the flat wait: the mixed batch goes as one CSR call
+    eng.submit_fixed = lambda q, e, c: eng.query_fixed(q, e, c)
+    again = bn.query_many(reqs, sub_batch=4)
+    assert np.array_equal(again.out, one_call.out) and np.array_equal(again.out_off, one_call.out_off)
+
+
+def test_answers_do_not_alias_the_caches():
+    """renaming the index of an answer must not reach the cached tail of the next answer, and writing into a Series
+    taken from a PosteriorBatch must not reach the batch's buffer."""
+    spec = netspec.grid_spec(3, 3, 3, seed=1)
+    bn = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
+    ans = bn.query("004", event={"000": 1})
+    ans.index.name = "renamed"
+    assert bn.query("004", event={"000": 1}).index.name == "004"
+    batch = bn.query_many([(("004",), {"000": 1}), (("005",), {"001": 2})])
+    s = batch[0]
+    before = batch.dense(0).copy()
+    s.iloc[0] = 99.0
+    assert np.array_equal(batch.dense(0), before) and batch[0].iloc[0] == before[0]
+
+
+def test_subclass_override_of_the_dispatch_hook_is_honoured():
+    """`_variable_elimination` is the hook the reference's query() dispatches to (bayes_net.py:848); the exact fast
+    path of query() must step aside for a subclass that overrides it at class level, not only for an instance-level rebind."""
+    calls = []
+
+    class Traced(sorobn_amd.BayesNet):
+        def _variable_elimination(self, *query, event):
+            calls.append(query)
+            return super()._variable_elimination(*query, event=event)
+
+    spec = netspec.grid_spec(3, 3, 3, seed=1)
+    bn = simengine.attach(netspec.build(spec, Traced))
+    plain = simengine.attach(netspec.build(spec, sorobn_amd.BayesNet))
+    pd.testing.assert_series_equal(bn.query("004", event={"000": 1}), plain.query("004", event={"000": 1}), check_exact=True)
+    assert calls == [("004",)]

@@ -15,6 +15,8 @@
 #   parity        the GPU parity suite under non-default engine options: PARITY_OPTS="mfma_kernel=1" [PARITY_K="<pytest -k expr>"]
 #   planner       tools/bench_planner.py (host planning rate, one thread)
 #   smoke         __graft_entry__.smoke()
+#   planlanes     the device planner alone (--sync, whole chunks on the device) at PLAN_LANES="1 4 16 32 64" requests per wave: kernel ms per chunk
+#   plansq        SQ counters of the device planner's kernels (one pass, --sync, whole chunks on the device; PLAN_OPTS="--opt wave_plan=1")
 TAG=${1:?tag}; shift
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
@@ -88,6 +90,23 @@ parity)
   echo "pytest rc $? (MIBN_OPTS=$PARITY_OPTS)" >> $OUT/${TAG}_pytest_parity.log; tail -6 $OUT/${TAG}_pytest_parity.log | cut -c1-240 ;;
 planner)
   timeout 600 python tools/bench_planner.py 2>&1 | tee $OUT/${TAG}_planner.log | tail -12 ;;
+planlanes)
+  for l in ${PLAN_LANES:-1 4 16 32 64}; do
+    timeout 300 python bench.py --steps 2 --warmup 1 --global-batch 32768 --batch 32768 --sync --no-cpu --no-configs --no-adaptive --opt gpu_emit=1 --opt emit_share=1 --opt trace=1 --opt plan_lanes=$l ${PLAN_OPTS:-} 2>&1 | grep "mibn plan\] chunk" | tail -2 | sed "s/^/lanes $l ${PLAN_OPTS:-}: /" | tee -a $OUT/${TAG}_planlanes.log
+  done ;;
+plansq)
+  ( cd /tmp; timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS -d $OUT/${TAG}_plansq -o sq -- python $ROOT/bench.py --steps 2 --warmup 1 --global-batch 32768 --batch 32768 --sync --no-cpu --no-configs --no-adaptive --opt gpu_emit=1 --opt emit_share=1 ${PLAN_OPTS:-} > $OUT/${TAG}_plansq.log 2>&1 )
+  python3 - "$(find $OUT/${TAG}_plansq -name '*.db' | head -1)" <<'PY' | tee $OUT/${TAG}_plansq_counters.txt
+import sqlite3, sys
+cur = sqlite3.connect(sys.argv[1]).cursor()
+by = {}
+for n, c, k, v in cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name"):
+    if "order_kernel" in n or "emit_kernel" in n or "plan" in n: by.setdefault(n.split("(")[0].split("::")[-1], {})[c] = (k, v)
+for n, d in by.items():
+    wc = d.get("SQ_WAVE_CYCLES", (0, 1))[1] or 1
+    print("%-24s launches %5d  " % (n[:24], d.get("SQ_WAVE_CYCLES", (0, 0))[0]) + "  ".join("%s %.3f" % (c.replace("SQ_", ""), v / wc) for c, (k, v) in sorted(d.items()) if c != "SQ_WAVE_CYCLES") + "  (fractions of SQ_WAVE_CYCLES)  wave cycles %.3g" % wc)
+PY
+  find $OUT -name "*.db" -delete ;;
 smoke)
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/${TAG}_smoke.log ;;
 *) echo "unknown stage $STAGE" ;;

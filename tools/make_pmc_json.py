@@ -44,7 +44,7 @@ if len(grp) >= 2:
     tot_t = sum(per[n]["traffic_bytes_per_launch"] * per[n]["launches_under_the_counters"] for n in grp)
     tot_a = sum(per[n]["alg_bytes_per_launch_same_run"] * per[n]["launches_under_the_counters"] for n in grp)
     levels = max(per[n]["launches_under_the_counters"] for n in grp)
-    per["ve_level_kernel||ve_sweep_dma_kernel"] = {"launches_under_the_counters": levels, "fetch_correction": "per kernel, see its entries",
+    per["level:ve_level_kernel||ve_mfma_kernel||ve_sweep_dma_kernel||ve_segment_kernel"] = {"launches_under_the_counters": levels, "fetch_correction": "per kernel, see its entries",
                                                    "traffic_bytes_per_launch": tot_t / levels, "alg_bytes_per_launch_same_run": tot_a / levels,
                                                    "members": grp}
 out = {"source": path + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of the bench command)",

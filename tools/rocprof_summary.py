@@ -47,7 +47,7 @@ def level_groups(db):
     if short:
         extra = [f"idle gaps between consecutive levels (< 0.5 ms: {len(short)} of {len(gaps)}): total {sum(short) / 1e3:.3f} ms = {100 * sum(short) / 1e3 / tot:.2f} % of the "
                  f"VE busy time, median {short[len(short) // 2]:.1f} us, mean {sum(short) / len(short):.1f} us, 90th percentile {short[int(0.9 * len(short))]:.1f} us"]
-    return extra + [f"levels (connected components of the VE kernels' intervals = ve_level_kernel||ve_sweep_dma_kernel[||ve_segment_kernel||ve_mfma_kernel]): {len(comps)} "
+    return extra + [f"levels (connected components of the VE kernels' intervals = level:ve_level_kernel||ve_mfma_kernel||ve_sweep_dma_kernel||ve_segment_kernel): {len(comps)} "
             f"groups, total {tot:.3f} ms = GPU busy time of the VE kernels, avg {tot / len(comps):.3f} ms per level; the sum of the individual "
             f"kernel durations is {single:.3f} ms ({single / tot:.2f} x: concurrent launches share the chip)"]
 
