@@ -213,6 +213,44 @@ OrderNet Network::order_view() const {
     return o;
 }
 
+// The network and the options of the moment, packed for the wave planner (wave_plan.h: one request per wave, this struct in LDS).
+bool Network::wave_view(WNet &w) const {
+    if (n_vars < 1 || n_vars > kWVars || uniform_log2 < 0 || (int)hint_sorted.size() > kWHints || (int)scope_flat.size() > kWCsr) return false;
+    if ((int64_t)pool.size() >= (1ll << 32)) return false;
+    const OrderNet ov = order_view();
+    const EmitNet ev = emit_view();
+    std::memset(&w, 0, sizeof(w));
+    w.n_vars = n_vars;
+    w.n_hints = (int32_t)hint_sorted.size();
+    w.uniform_log2 = uniform_log2;
+    w.csr_n = (int32_t)scope_flat.size();
+    w.multi = multi2;
+    w.small_cells = ev.small_cells; w.prune = ev.prune; w.outer = ev.outer; w.fuse = ev.fuse; w.chain = ev.chain; w.sweep = ev.sweep;
+    w.sweep_min = ev.sweep_min; w.sweep_canon = ev.sweep_canon; w.tile_h = ev.tile_h; w.sweep_iters = ev.sweep_iters;
+    w.big_iters = ev.big_iters; w.tile_bytes = ev.tile_bytes;
+    w.log2_small = ev.log2_small; w.log2_big = ev.log2_big;
+    w.minfill_above = ov.minfill_above; w.chain_weight = ov.chain_weight; w.big_cells = ov.big_cells;
+    for (int v = 0; v < n_vars; ++v) {
+        if (card[v] > 65535 || depth[v] > 255 || pool_off[v] < 0) return false;
+        w.scope[v] = scope2[v];
+        w.fam[v] = fam2[v];
+        w.card[v] = (uint16_t)card[v];
+        w.depth[v] = (uint8_t)depth[v];
+        w.topo_asc[v] = (uint8_t)topo_asc[v];
+        w.topo_desc[v] = (uint8_t)topo_desc[v];
+        w.pool_off[v] = (uint32_t)pool_off[v];
+        w.scope_off[v] = (uint16_t)scope_off32[v];
+        for (size_t h = 0; h < hint_sorted.size(); ++h) w.hint_sorted[h][v] = (uint8_t)hint_sorted[h][v];
+    }
+    w.scope_off[n_vars] = (uint16_t)scope_off32[n_vars];
+    for (size_t k = 0; k < scope_flat.size(); ++k) {
+        if (cstride_flat[k] < 0 || cstride_flat[k] >= (1ll << 31)) return false;
+        w.scope_var[k] = (uint8_t)scope_flat[k];
+        w.scope_stride[k] = (int32_t)cstride_flat[k];
+    }
+    return true;
+}
+
 void Network::set_hints(int32_t n_hints, const int32_t *priorities) {
     hints.clear();
     hint_sorted.clear();

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "emit_core.h"
+#include "wave_plan.h"
 
 namespace mibn {
 
@@ -46,6 +47,7 @@ struct Network {
     std::vector<int64_t> cstride_flat;
     std::vector<uint64_t> anc_flat;
     EmitNet emit_view() const;
+    bool wave_view(WNet &w) const;               // the wave planner's packed copy (wave_plan.h); false: the network or an option is outside what it covers
     int nw = 1;
     int small_cells = 1024;  // FIBER: inputs up to this size are folded into the LDS table
     int64_t big_iters = 4096;  // a step with at least this many lane-iterations is a level of its own (tiled, FIBER form if it fits)
