@@ -648,6 +648,73 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     return (int64_t)prog.size();
 }
 
+// The wave-cooperative device planner (csrc/wave_plan.h) compiled for the host - one lane runs every iteration of its lane loops
+// (wave_prims.h) - on one request: the program in `out` (words returned; -3: the network / options are outside what it covers; -4: the
+// request exceeds a device limit, kEmitErrDevice; -5: another emission error), its work items in `tags_out` (four words each),
+// {bytes, flops, steps, max cells, arena cells, work items} in `stats`.  tests/test_wave_planner.py holds it against plan_sim_program.
+extern "C" int64_t wave_plan_program(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                                     const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
+                                     int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars, const int32_t *ecodes,
+                                     int32_t no_prune, uint32_t *out, int64_t cap, uint32_t *tags_out, int64_t tags_cap, double *stats) {
+    Network net;
+    g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
+    if (!g_err.empty()) return -1;
+    net.small_cells = g_small_cells;
+    net.big_iters = g_big_iters;
+    net.tile_h = g_tile_h;
+    net.fuse = g_fuse;
+    net.chain = g_chain;
+    net.sweep = g_sweep;
+    net.sweep_min = g_sweep_min;
+    net.prune = g_prune;
+    net.set_hints(n_hints, hints);
+    std::unique_ptr<WNet> wn(new WNet);
+    if (!net.wave_view(*wn)) return -3;
+    std::unique_ptr<WState> ws(new WState);
+    std::vector<uint32_t> slot((size_t)cap + kMaxStepWords);
+    WResult R;
+    wave_plan_request(*wn, *ws, net.anc2.data(), nq, qvars, ne, evars, ecodes, no_prune != 0, 0, slot.data(), (uint32_t)slot.size(), R);
+    if (R.err == kEmitErrDevice) return -4;
+    if (R.err) { g_err = emit_error_message(R.err); return -5; }
+    if ((int64_t)R.words > cap || (int64_t)R.n_tags > tags_cap) return -2;
+    std::memcpy(out, slot.data(), (size_t)R.words * 4);
+    std::memcpy(tags_out, ws->e.tags, (size_t)R.n_tags * sizeof(Tag));
+    stats[0] = R.alg_bytes; stats[1] = R.alg_flops; stats[2] = R.n_steps; stats[3] = R.max_step_cells; stats[4] = (double)R.arena_cells; stats[5] = (double)R.n_tags;
+    return (int64_t)R.words;
+}
+
+// the host planner's program of the same request with its work items and statistics, in the same shape (the reference of the above)
+extern "C" int64_t plan_sim_program_tags(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
+                                         const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,
+                                         int32_t nq, const int32_t *qvars, int32_t ne, const int32_t *evars, const int32_t *ecodes,
+                                         int32_t no_prune, uint32_t *out, int64_t cap, uint32_t *tags_out, int64_t tags_cap, double *stats) {
+    Network net;
+    g_err = net.set(n_vars, card, scope_off, scope_vars, value_off, values);
+    if (!g_err.empty()) return -1;
+    net.small_cells = g_small_cells;
+    net.big_iters = g_big_iters;
+    net.tile_h = g_tile_h;
+    net.fuse = g_fuse;
+    net.chain = g_chain;
+    net.sweep = g_sweep;
+    net.sweep_min = g_sweep_min;
+    net.prune = g_prune;
+    net.set_hints(n_hints, hints);
+    Request rq;
+    rq.nq = nq; rq.qvars = qvars; rq.ne = ne; rq.evars = evars; rq.ecodes = ecodes; rq.out_off = 0; rq.no_prune = no_prune != 0;
+    std::vector<uint32_t> prog;
+    PlanStats st;
+    g_err = plan_request(net, rq, prog, st);
+    if (!g_err.empty()) return -6;
+    std::vector<Tag> tags;
+    tag_program(net.emit_view(), prog.data(), [&](const Tag &t) { tags.push_back(t); });
+    if ((int64_t)prog.size() > cap || (int64_t)tags.size() > tags_cap) return -2;
+    std::memcpy(out, prog.data(), prog.size() * 4);
+    std::memcpy(tags_out, tags.data(), tags.size() * sizeof(Tag));
+    stats[0] = st.alg_bytes; stats[1] = st.alg_flops; stats[2] = st.n_steps; stats[3] = st.max_step_cells; stats[4] = (double)st.arena_cells; stats[5] = (double)tags.size();
+    return (int64_t)prog.size();
+}
+
 // host-side planning throughput probe (no execution): plans B fixed-shape requests on `threads` threads
 extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int64_t *scope_off, const int32_t *scope_vars,
                                  const int64_t *value_off, const double *values, int32_t n_hints, const int32_t *hints,

@@ -26,6 +26,7 @@
 #include "tiny_kernel.hip.h"
 #include "sweep_kernel.hip.h"
 #include "ve_kernel.hip.h"
+#include "wave_plan_kernel.hip.h"
 
 using namespace mibn;
 
@@ -88,12 +89,6 @@ __global__ __launch_bounds__(MIBN_PLAN_WG, MIBN_ORDER_WAVES_PER_EU) void order_k
 // order (order_kernel's output, never copied to the host) into its step program, written straight into the request's slot
 // of the chunk's device program buffer, and cuts it into work items.  The host only lays out the schedule of the chunk
 // (build_schedule, from the work items): a rank needs no planning threads.
-struct EmitMeta {  // per request
-    uint32_t words, n_tags, tag_first;
-    int32_t err;  // kEmitErr* (any error: the host plans the chunk itself)
-    double alg_bytes, alg_flops, n_steps, max_step_cells;
-    int64_t arena_cells;
-};
 struct EmitArgs {
     EmitNet net;
     const int64_t *q_off, *e_off, *out_off;  // [B + 1]; out_off relative to the chunk's first request
@@ -298,6 +293,11 @@ struct mibn_ctx {
     double emit_share_opt = -1;
     BatchPlan emit_dev, emit_host;   // the two parts of a chunk before they are joined
     uint32_t emit_words = 6144;      // words of a request's program slot (doubles after a chunk that did not fit)
+    // wave-cooperative device planner (wave_plan_kernel)
+    int wave_plan = 1;               // option: 1 = chunks the device plans go through wave_plan_kernel where the network is covered (wave_plan.h)
+    WNet *wnet_host = nullptr;       // the packed network + options as uploaded last
+    WNet *d_wnet = nullptr;
+    bool wnet_ok = false;
     double emit_ms = 0;              // host wall time spent waiting for the device planner (last call)
     uint64_t emit_chunks = 0, emit_fallbacks = 0;
     hipEvent_t gap_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // trace: ends of the last waves (GPU idle time between waves)
@@ -512,6 +512,8 @@ void mibn_destroy(mibn_t *h) {
         (void)hipFree(h->d_order_len);
         (void)hipFree(h->d_order_scratch);
         (void)hipFree(h->d_emit_net);
+        (void)hipFree(h->d_wnet);
+        delete h->wnet_host;
         (void)hipFree(h->d_emit_scratch);
         (void)hipFree(h->d_emit_cursor);
         if (h->emit_in.p) (void)hipHostFree(h->emit_in.p);
@@ -571,6 +573,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "tiny_zero_copy") h->tiny_zero_copy = value != 0;
     else if (n == "mfma_kernel") h->mfma_kernel = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
+    else if (n == "wave_plan") h->wave_plan = value != 0;  // 0: the device plans with order_kernel + emit_kernel (one request per lane)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
     else if (n == "plan_sort") h->plan_sort = (int)value;
     else if (n == "plan_lanes") h->plan_lanes = std::max(0, std::min(64, (int)value));  // requests per wave of the device planner's kernels
@@ -972,13 +975,32 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
     const size_t tag_cap = (size_t)n * 64;
     const size_t scratch_stride = emit_scratch_bytes(h->net.n_vars);
     const int64_t slice = std::min(n, kPlanSlice);
+    // the wave-cooperative planner (wave_plan_kernel) where the network and the options of the moment are covered: its packed copy of
+    // them is rebuilt per chunk (10 KB) and uploaded when it has changed
+    bool wave = false;
+    if (h->wave_plan && h->order_net_ok) {
+        if (!h->wnet_host) { h->wnet_host = new WNet; std::memset(h->wnet_host, 0, sizeof(WNet)); h->wnet_ok = false; }
+        WNet *fresh = new WNet;
+        if (h->net.wave_view(*fresh)) {
+            if (!h->d_wnet) HIP_TRY(h, hipMalloc(&h->d_wnet, sizeof(WNet)));
+            if (!h->wnet_ok || std::memcmp(fresh, h->wnet_host, sizeof(WNet)) != 0) {
+                HIP_TRY(h, hipMemcpy(h->d_wnet, fresh, sizeof(WNet), hipMemcpyHostToDevice));
+                std::memcpy(h->wnet_host, fresh, sizeof(WNet));
+                h->wnet_ok = true;
+            }
+            wave = true;
+        }
+        delete fresh;
+    }
     if ((rc = pinned(h, h->emit_in, in_bytes))) return rc;
     if ((rc = pinned(h, h->emit_out, (size_t)n * sizeof(EmitMeta) + tag_cap * sizeof(Tag) + 64))) return rc;
+    if (!h->d_emit_cursor) HIP_TRY(h, hipMalloc(&h->d_emit_cursor, 64));
+    if (!wave) {
     if ((rc = ensure(h, h->d_orders, h->orders_cap, (size_t)n * 128))) return rc;
     if ((rc = ensure(h, h->d_order_len, h->order_len_cap, (size_t)n))) return rc;
     if ((rc = ensure(h, h->d_order_scratch, h->order_scratch_cap, (size_t)slice))) return rc;
-    if (!h->d_emit_cursor) HIP_TRY(h, hipMalloc(&h->d_emit_cursor, 64));
-    if ((size_t)slice * scratch_stride > h->emit_scratch_cap) {
+    }
+    if (!wave && (size_t)slice * scratch_stride > h->emit_scratch_cap) {
         if (h->d_emit_scratch) { HIP_TRY(h, hipFree(h->d_emit_scratch)); h->d_emit_scratch = nullptr; h->emit_scratch_cap = 0; }
         const size_t want = (size_t)std::max<int64_t>(slice, std::min<int64_t>(h->chunk, kPlanSlice)) * scratch_stride;
         HIP_TRY(h, hipMalloc(&h->d_emit_scratch, want));
@@ -1042,7 +1064,30 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
     const char *d = pin;
     EmitMeta *meta_out = reinterpret_cast<EmitMeta *>(h->emit_out.p);
     Tag *tags_out = reinterpret_cast<Tag *>(h->emit_out.p + (size_t)n * sizeof(EmitMeta) + 64);
-    for (int64_t s0 = 0; s0 < n; s0 += kPlanSlice) {
+    if (wave) {
+        WavePlanArgs A;
+        A.net = h->d_wnet;
+        A.anc = h->order_net_dev.anc;
+        A.q_off = reinterpret_cast<const int64_t *>(d);
+        A.e_off = reinterpret_cast<const int64_t *>(d + off_bytes);
+        A.out_off = reinterpret_cast<const int64_t *>(d + 2 * off_bytes);
+        A.q_vars = reinterpret_cast<const int32_t *>(d + 3 * off_bytes);
+        A.e_vars = A.q_vars + nq;
+        A.e_codes = A.e_vars + ne;
+        A.skip = reinterpret_cast<const char *>(A.e_codes + ne);
+        A.B = n;
+        A.flags = flags;
+        A.prog = st.d_prog;
+        A.prog_stride = (uint32_t)stride;
+        A.meta = meta_out;
+        A.tags = tags_out;
+        A.tag_cursor = h->d_emit_cursor;
+        A.tag_cap = (uint32_t)tag_cap;
+        hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, P, h->d_emit_cursor);
+        hipLaunchKernelGGL(wave_plan_kernel, dim3((unsigned)((n + kWaveWG - 1) / kWaveWG)), dim3(64 * kWaveWG), 0, P, A);
+        HIP_TRY(h, hipGetLastError());
+    }
+    for (int64_t s0 = 0; !wave && s0 < n; s0 += kPlanSlice) {
         const int64_t m = std::min(kPlanSlice, n - s0);
         OrderArgs O;
         O.net = h->order_net_dev;
@@ -1143,10 +1188,11 @@ int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, do
     ck.tag_count.assign(n, 0);
     ck.tags.resize(1);
     ck.tags[0].assign(tags, tags + n_tags);
-    bool refused = false;
+    bool refused = false, beyond = false;
     for (int64_t i = 0; i < n; ++i) {
         const EmitMeta &m = meta[i];
         if (m.err == kEmitErrWords) { refused = true; continue; }
+        if (m.err == kEmitErrDevice) { refused = true; beyond = true; continue; }  // (beyond what wave_plan_kernel covers: the host plans the chunk)
         if (m.err) { h->err = "request " + std::to_string(b0 + i) + ": " + emit_error_message(m.err); return MIBN_E_LIMIT; }
         ck.prog_off[i] = (uint64_t)i * stride;
         ck.local_off[i] = ck.prog_off[i];
@@ -1162,7 +1208,7 @@ int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, do
     }
     ck.total_words = (size_t)n * stride;
     if (refused) {
-        h->emit_words = std::min<uint32_t>(h->emit_words * 2, 1u << 20);
+        if (!beyond) h->emit_words = std::min<uint32_t>(h->emit_words * 2, 1u << 20);
         ++h->emit_fallbacks;
         return 1;
     }

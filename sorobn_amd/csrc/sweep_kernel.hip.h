@@ -682,7 +682,11 @@ __device__ __forceinline__ int sweep_readout_cell(const int e, const int kout) {
 // two runs of 512 consecutive LDS cells (K = 5: run rho = d3 + 4 d4, fa = d3, pair = d4; K = 4: rho = d2 + 4 d3, fa = d3,
 // pair = d2); the DMA fills the same cells per wave, so nothing between the barrier after stage K - 2 and the landing of
 // the next tile needs the other waves.
-template <int K, bool OWN, bool DEAD = false>
+// LOADER (round 6, tools/ubench/sweep_real.hip only - VERDICT r5 item 2): a NINTH wave issues every tile's LDS-DMA into a ring of two
+// 64 KiB slots while the eight stage waves work on the other slot - the fill decoupled from the stage waves (one workgroup per CU:
+// 137.5 KiB of LDS).  The loader joins the tile's two workgroup barriers: behind the first (the stage waves have left the previous
+// tile's slot) it issues the next tile's 64 DMA instructions, behind the second it waits for them.
+template <int K, bool OWN, bool DEAD = false, bool LOADER = false>
 __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *__restrict__ T, const uint32_t *stw, const int k_rt,
                                                 const int rb_rt, const double *__restrict__ F, double *__restrict__ outp,
                                                 const long Rcells, const int t_begin, const int t_end, const int kout,
@@ -737,18 +741,40 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
         }
     };
     const int n_tiles = t_end - t_begin;
+    double *__restrict__ const Lbase = L;
+    if constexpr (LOADER) {
+        static_assert(!LOADER || (K == 5 && OWN && !DEAD), "the loader experiment covers the canonical five-variable pass");
+        if (tid >= WG) {  // the loader wave: instruction j fills LDS cells [128 j, 128 j + 128) of the slot (lane l: cells 128 j + 2 l, + 1)
+            auto fill = [&](const int tile, const int slot) {
+                const uint32_t lb = (uint32_t)uni((int)(lds_l + 8u * (uint32_t)(slot * kSweepTileCells)));
+                const double *__restrict__ Ft = F + (long)tile * Rt + ((2 * lane) & (Rt - 1));
+#pragma unroll 8
+                for (int j = 0; j < kSweepTileCells / 128; ++j) dma16(Ft + (long)((128 * j + 2 * lane) >> rb) * Rcells, lb + (uint32_t)(8 * 128 * j));
+            };
+            fill(t_begin, 0);
+            for (int i = 0; i < n_tiles; ++i) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (i + 1 < n_tiles) fill(t_begin + i + 1, (i + 1) & 1);
+                __syncthreads();
+            }
+            return;
+        }
+    }
     MIBN_PROF_INIT
-    dma_tile(t_begin);
+    if constexpr (!LOADER) dma_tile(t_begin);
     sweep_build_tables(tb, tid);  // (its loads retire behind the first tile's: the tile has landed when T is built)
     for (int i = 0; i < n_tiles; ++i) {
         const int tile = t_begin + i;
+        if constexpr (LOADER) L = Lbase + (i & 1) * kSweepTileCells;
         MIBN_PROF_TICK(0)
         // this wave's share of the tile has landed.  Wave-owned tail: the DMA was issued BEFORE the eight 16-byte stores of the
         // last stage (sweep_last_stage_out) and the vector-memory operations of a wave retire in order, so "at most eight
         // operations outstanding" means the DMA is done - the wave does not sit out the write acknowledgements of its stores
         // (DEAD: a wave may have stored less - or nothing - after its DMA: it drains)
         static_assert(MIBN_SWEEP_VMCNT == 0 || MIBN_SWEEP_VMCNT == kSweepOwnTailStores, "the wait must leave exactly the tail's stores in flight");
-        if (OWN && !DEAD && MIBN_SWEEP_VMCNT == kSweepOwnTailStores && i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kSweepOwnTailStores) : "memory");
+        if constexpr (LOADER) {}  // (the stage waves issue no loads: the loader has waited for the tile)
+        else if (OWN && !DEAD && MIBN_SWEEP_VMCNT == kSweepOwnTailStores && i > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kSweepOwnTailStores) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MIBN_PROF_TICK(1)
         __syncthreads();  // ... and everybody else's (first tile: T is complete)
@@ -830,7 +856,7 @@ __device__ __forceinline__ void sweep_tiles_dma(double *__restrict__ L, double *
             bool par = false;
 #pragma unroll
             for (int c = 0; c < 3; ++c) par = par || (c < nctrl && (cw[c] & 0xff) == 8);
-            auto dma_next = [&]() { if (i + 1 < n_tiles) dma_tile(tile + 1); };
+            auto dma_next = [&]() { if constexpr (!LOADER) { if (i + 1 < n_tiles) dma_tile(tile + 1); } };
             if constexpr (DEAD) {
                 if (par) sweep_last_stage_out_dead<true>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dead, dma_next);  // (uniform)
                 else sweep_last_stage_out_dead<false>(L, T, ot, tid, tile * Rt, s1, cw, nctrl, dead, dma_next);
@@ -905,6 +931,40 @@ __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_dma_kernel(const LevelAr
     else if (canon && k == 3) sweep_tiles_dma<3, false>(L, T, stw, 3, 7, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else if (canon && k == 2) sweep_tiles_dma<2, false>(L, T, stw, 2, 9, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
     else sweep_tiles_dma<0, false>(L, T, stw, k, rb, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+}
+
+// the loader experiment as a kernel (canonical five-variable passes only; tools/ubench/sweep_real.hip): 512 stage lanes + a loader wave,
+// two tile slots + T + the step descriptor = 137.5 KiB of LDS, one workgroup per CU
+constexpr int kSweepLoaderWG = kSweepWG + 64;
+constexpr int kSweepLoaderLdsBytes = 2 * kSweepTileCells * 8 + kSweepMaxT * 8 + kMaxStepWords * 4;
+__global__ __launch_bounds__(kSweepLoaderWG) void ve_sweep_loader_kernel(const LevelArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double sweep_lds[];
+    double *__restrict__ L = sweep_lds;
+    double *__restrict__ T = sweep_lds + 2 * kSweepTileCells;
+    uint32_t *sh_step = reinterpret_cast<uint32_t *>(sweep_lds + 2 * kSweepTileCells + kSweepMaxT);
+    const int tid = threadIdx.x;
+    const uint32_t wg = blockIdx.x + A.wg_base;
+    const Item it = A.items[A.wg_item[wg]];
+    double *__restrict__ slot = A.arena + A.arena_off[it.req];
+    const uint32_t *p = A.prog + A.prog_off[it.req] + it.rel_off;
+    const int words = (int)p[6];
+    for (int i = tid; i < words; i += kSweepLoaderWG) sh_step[i] = p[i];
+    __syncthreads();
+    const int k = uni((int)((sh_step[0] >> 16) & 0xff)), rb = uni((int)((sh_step[0] >> 24) & 0xff));
+    const int tiles = uni((int)sh_step[3]);
+    const int kout = uni((int)(sh_step[7] & 0xffff)), t_total = uni((int)(sh_step[7] >> 16));
+    const uint32_t surv = (uint32_t)uni((int)sh_step[8]);
+    const long Rcells = (long)tiles << rb;
+    const uint32_t *stw = sh_step + kHdrWords + 2;
+    const uint32_t *smw = stw + k * kSweepStageWords;
+    const double *__restrict__ F = slot + ((uint64_t)sh_step[kHdrWords] | ((uint64_t)sh_step[kHdrWords + 1] << 32));
+    double *__restrict__ outp = slot + ((uint64_t)sh_step[4] | ((uint64_t)sh_step[5] << 32));
+    const SweepTables tb{T, stw, smw, A.pool, slot, k, t_total};
+    const int t_begin = (int)((wg - it.b) * it.a);
+    const int t_end = min(tiles, t_begin + (int)it.a);
+    const bool canon = (sh_step[1] >> 16) & kFlagSweepCanon;
+    if (canon && k == 5 && kout == 5 && surv == 0x43210u) sweep_tiles_dma<5, true, false, true>(L, T, stw, 5, 3, F, outp, Rcells, t_begin, t_end, kout, surv, tid, tb);
+    (void)rb;
 }
 
 __global__ __launch_bounds__(kSweepWG, 4) void ve_sweep_kernel(const LevelArgs A) {

@@ -27,11 +27,11 @@
 
 namespace mibn {
 
+// (hipcc parses a kernel's body in its host pass too: there the functions below are __host__ __device__ over the host primitives)
+#define WV_HD MIBN_HD inline
 #if defined(__HIP_DEVICE_COMPILE__)
-#define WV_HD __device__ inline
 #define WV_LANE0 if (wv::lane() == 0)
 #else
-#define WV_HD inline
 #define WV_LANE0 if (true)
 #endif
 

@@ -1,0 +1,107 @@
+// wave_plan_kernel: the wave-cooperative device planner (wave_plan.h) as a kernel - included by engine.hip (the product) and by
+// tools/ubench/wave_plan_bench.hip (the kernel alone on a recorded request stream).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/mibn.h"
+#include "wave_plan.h"
+
+using namespace mibn;
+
+struct EmitMeta {  // per request
+    uint32_t words, n_tags, tag_first;
+    int32_t err;  // kEmitErr* (any error: the host plans the chunk itself)
+    double alg_bytes, alg_flops, n_steps, max_step_cells;
+    int64_t arena_cells;
+};
+
+// ---------------------------------------------------------------------------------------------- wave-cooperative device planner
+// Round 6 (csrc/wave_plan.h): ONE request per wave - order search and emission in one launch, the request's planning state in LDS
+// (order_kernel / emit_kernel above keep theirs in scratch and global memory, one request per lane, and wait for it 86 % of their
+// cycles: profiles/r06_a_plansq_counters.txt).  Four waves = four requests per workgroup share the network tables (WNet, 10 KB of
+// LDS); 58 KB per workgroup, two workgroups per CU.  The programs, the per-request results and the work items go where emit_kernel
+// writes them, word for word what the host plans (gpu_emit = 2 compares every word).
+struct WavePlanArgs {
+    const WNet *net;
+    const B2 *anc;                           // [n_vars] ancestor sets
+    const int64_t *q_off, *e_off, *out_off;  // [B + 1]; out_off relative to the chunk's first request
+    const int32_t *q_vars, *e_vars, *e_codes;
+    const char *skip;                        // [B] evidence outside the domain: zero steps
+    int64_t B;
+    uint32_t flags;
+    uint32_t *prog;                          // [B][prog_stride]
+    uint32_t prog_stride;
+    EmitMeta *meta;                          // [B]
+    Tag *tags;                               // [tag_cap]
+    uint32_t *tag_cursor;
+    uint32_t tag_cap;
+};
+constexpr int kWaveWG = 4;  // waves (requests) per workgroup
+constexpr int kWaveMaxQ = 16, kWaveMaxE = 64;  // query / evidence variables of a request (more: the host plans the chunk)
+struct WaveReq { int32_t q[kWaveMaxQ], e[kWaveMaxE], c[kWaveMaxE]; };
+
+__global__ void reset_cursor_kernel(uint32_t *cursor) { *cursor = 0; }
+
+__global__ __launch_bounds__(64 * kWaveWG) void wave_plan_kernel(const WavePlanArgs A) {
+    __shared__ WNet N;
+    __shared__ WState W[kWaveWG];
+    __shared__ WaveReq RQ[kWaveWG];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(A.net);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&N);
+        for (unsigned i = threadIdx.x; i < sizeof(WNet) / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t b = (int64_t)blockIdx.x * kWaveWG + wave;
+    if (b >= A.B) return;
+    EmitMeta m;
+    m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
+    m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
+    m.arena_cells = 0;
+    uint32_t *slot = A.prog + (size_t)b * A.prog_stride;
+    if (A.skip[b]) {
+        if (lane == 0) { slot[0] = 0; A.meta[b] = m; }
+        return;
+    }
+    const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
+    const int nq = (int)(A.q_off[b + 1] - q0), ne = (int)(A.e_off[b + 1] - e0);
+    if (nq > kWaveMaxQ || ne > kWaveMaxE) {
+        m.err = kEmitErrDevice;
+        if (lane == 0) A.meta[b] = m;
+        return;
+    }
+    // the request's variables: read once (the arrays are in pinned host memory), kept in LDS
+    WaveReq &rq = RQ[wave];
+    if (lane < nq) rq.q[lane] = A.q_vars[q0 + lane];
+    if (lane < ne) { rq.e[lane] = A.e_vars[e0 + lane]; rq.c[lane] = A.e_codes[e0 + lane]; }
+    wv::sync();
+    WState &S = W[wave];
+    WResult R;
+    wave_plan_request(N, S, A.anc, nq, rq.q, ne, rq.e, rq.c, (A.flags & MIBN_Q_NOPRUNE) != 0, A.out_off[b], slot, A.prog_stride, R);
+    int err = R.err;
+    if (!err) {
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(A.tag_cursor, R.n_tags);
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        if (first + R.n_tags <= A.tag_cap) {
+            // (the lanes copy the items a dword each)
+            static_assert(sizeof(Tag) % 4 == 0, "work items are copied dword by dword");
+            constexpr uint32_t kTagWords = sizeof(Tag) / 4;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(S.e.tags);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(A.tags + first);
+            for (uint32_t i = (uint32_t)lane; i < R.n_tags * kTagWords; i += 64) dst[i] = src[i];
+            m.n_tags = R.n_tags;
+            m.tag_first = first;
+        } else {
+            err = kEmitErrWords;
+        }
+    }
+    m.err = err;
+    m.words = R.words;
+    m.alg_bytes = R.alg_bytes; m.alg_flops = R.alg_flops; m.n_steps = R.n_steps; m.max_step_cells = R.max_step_cells;
+    m.arena_cells = R.arena_cells;
+    if (lane == 0) A.meta[b] = m;
+}
+

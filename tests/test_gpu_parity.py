@@ -546,20 +546,38 @@ def test_device_planner_writes_the_host_programs(amd):
     host = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
     host_stats = be.engine.stats()
     # mode 1: the device plans a share of every chunk, the host's workers the rest meanwhile (the share follows the two rates)
-    for mode, chunk, share in ((2, 4096, -1), (1, 32768, -1), (1, 2048, 0.3), (1, 32768, 1.0)):
-        be.engine.set_option("gpu_emit", mode)
-        be.engine.set_option("chunk", chunk)
-        be.engine.set_option("emit_share", share)
-        dev = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
-        st = be.engine.stats()
-        assert abs(st["alg_bytes"] - host_stats["alg_bytes"]) <= 1e-9 * host_stats["alg_bytes"] and st["n_steps"] == host_stats["n_steps"]
-        assert np.array_equal(dev, host), (mode, chunk, share)
+    # wave_plan 1 (round 6, default): wave_plan_kernel - one request per wave, csrc/wave_plan.h; 0: order_kernel + emit_kernel - one request
+    # per lane, the host's code itself.  Both write the host's programs word for word.
+    for wave_plan in (1, 0):
+        be.engine.set_option("wave_plan", wave_plan)
+        for mode, chunk, share in ((2, 4096, -1), (1, 32768, -1), (1, 2048, 0.3), (1, 32768, 1.0)):
+            be.engine.set_option("gpu_emit", mode)
+            be.engine.set_option("chunk", chunk)
+            be.engine.set_option("emit_share", share)
+            dev = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
+            st = be.engine.stats()
+            assert abs(st["alg_bytes"] - host_stats["alg_bytes"]) <= 1e-9 * host_stats["alg_bytes"] and st["n_steps"] == host_stats["n_steps"]
+            assert np.array_equal(dev, host), (wave_plan, mode, chunk, share)
     be.engine.set_option("chunk", 32768)
     be.engine.set_option("emit_share", -1)
+    be.engine.set_option("wave_plan", 1)
+    be.engine.set_option("gpu_emit", 2)
+    for n_ev in (1, 8, 16):  # (other shapes of the stream: short orders, long min-fill orders - checked word for word by mode 2)
+        q2, ev2, ec2 = netspec.c3_requests(100, 4, 2048, n_ev, seed=3)
+        want = None
+        for mode in (0, 2):
+            be.engine.set_option("gpu_emit", mode)
+            got = be.engine.query_fixed(to_var[q2][:, None], to_var[ev2], ec2)
+            if want is None:
+                want = got
+            assert np.array_equal(got, want), n_ev
+    be.engine.set_option("gpu_emit", 1)
+    be.engine.set_option("wave_plan", 0)
     for lanes, waves in ((64, 1), (5, 3), (32, 16)):  # the geometry of the planner's launches: requests per wave, waves per workgroup
         be.engine.set_option("plan_lanes", lanes)
         be.engine.set_option("plan_waves", waves)
         assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), host), (lanes, waves)
+    be.engine.set_option("wave_plan", 1)
     names = [k["name"] for k in be.engine.kernel_stats()]
     assert "order_kernel+emit_kernel" in names and "ve_sweep_dma_kernel" in names
     be.engine.set_option("gpu_emit", 2)

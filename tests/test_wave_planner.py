@@ -1,0 +1,132 @@
+"""The wave-cooperative device planner (sorobn_amd/csrc/wave_plan.h) compiled for the host - oracle/libplan_sim.so, one lane runs every
+iteration of its lane loops (wave_prims.h) - against the host planner (emit_core.h / order_search.h): programs, work items and
+statistics word for word, on every golden network it covers (multi-state variables of ONE power-of-two cardinality) with the
+forcing options of the GPU parity tests, on the C3 stream and its n_evidence variants, and once more with every lane loop
+REVERSED (libplan_sim_rev.so: iterations that depend on each other would show).  CPU only: the same source is what
+wave_plan_kernel runs on the GPU, where `gpu_emit = 2` repeats the comparison on the device's own output (tests/test_gpu_parity.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import netspec
+import sorobn_amd
+from sorobn_amd.flatten import flatten
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_libs = {}
+
+
+def lib(name):
+    if name not in _libs:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", name])
+        L = C.CDLL(os.path.join(ROOT, "oracle", name))
+        for fn in (L.wave_plan_program, L.plan_sim_program_tags):
+            fn.restype = C.c_int64
+        _libs[name] = L
+    return _libs[name]
+
+
+def both_programs(L, f, q, ev, codes, options, no_prune=0):
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    hints = np.ascontiguousarray(np.stack(f.hints).reshape(-1) if f.hints else [0], np.int32)
+    q = np.ascontiguousarray(q, np.int32)
+    ev_ = np.ascontiguousarray(ev if len(ev) else [0], np.int32)
+    co_ = np.ascontiguousarray(codes if len(codes) else [0], np.int32)
+    small_cells, tiling, fuse, chain, sweep, sweep_min = options
+    L.plan_sim_set_small_cells(int(small_cells))
+    L.plan_sim_set_tiling(int(tiling[0]), int(tiling[1]))
+    L.plan_sim_set_fuse(int(fuse))
+    L.plan_sim_set_chain(int(chain))
+    L.plan_sim_set_sweep(int(sweep))
+    L.plan_sim_set_sweep_min(int(sweep_min))
+    L.plan_sim_set_prune(1)
+    res = []
+    for fn in (L.plan_sim_program_tags, L.wave_plan_program):
+        out, tags, stats = np.zeros(1 << 16, np.uint32), np.zeros(4 * 256, np.uint32), np.zeros(6)
+        n = fn(C.c_int32(len(f.card)), p(f.card, C.c_int32), p(f.scope_off, C.c_int64), p(f.scope_vars, C.c_int32), p(f.value_off, C.c_int64),
+               p(f.values, C.c_double), C.c_int32(len(f.hints)), p(hints, C.c_int32), C.c_int32(len(q)), p(q, C.c_int32), C.c_int32(len(ev)),
+               p(ev_, C.c_int32), p(co_, C.c_int32), C.c_int32(no_prune), p(out, C.c_uint32), C.c_int64(len(out)), p(tags, C.c_uint32), C.c_int64(256),
+               p(stats, C.c_double))
+        res.append((int(n), out[:max(0, int(n))].copy(), tags[:4 * int(stats[5])].copy(), stats.copy()))
+    return res
+
+
+def same(host, wave):
+    return host[0] == wave[0] and np.array_equal(host[1], wave[1]) and np.array_equal(host[2], wave[2]) and np.array_equal(host[3], wave[3])
+
+
+DEFAULT = (1024, (4096, 0), 1, 1, 5, 2)
+FORCING = [DEFAULT, (1, (2, 1), 1, 1, 5, 2), (3, (4, 1), 1, 1, 5, 2), (6, (8, 3), 1, 1, 5, 2), (20, (64, 2), 1, 1, 5, 2), (3, (4, 1), 0, 1, 5, 2),
+           (3, (4, 1), 1, 0, 5, 2), (3, (4, 1), 1, 1, 0, 2), (1024, (4096, 0), 1, 1, 5, 3), (1024, (4096, 0), 1, 1, 3, 2)]
+
+
+@pytest.mark.parametrize("libname", ["libplan_sim.so", "libplan_sim_rev.so"])
+def test_wave_planner_writes_the_host_programs_on_the_c3_streams(libname):
+    L = lib(libname)
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    f = flatten(netspec.build(spec, sorobn_amd.BayesNet))
+    to_var = np.array([f.id[f"{i:03d}"] for i in range(100)], np.int32)
+    n_checked, beyond = 0, 0
+    for n_ev, n_req, options in ((4, 700, DEFAULT), (1, 300, DEFAULT), (8, 300, DEFAULT), (16, 400, DEFAULT), (4, 200, (1024, (4096, 0), 0, 1, 5, 2)),
+                                 (4, 200, (1024, (4096, 0), 1, 0, 5, 2)), (4, 200, (1024, (4096, 0), 1, 1, 0, 2)), (4, 200, (64, (256, 0), 1, 1, 5, 2)),
+                                 (4, 200, (1024, (4096, 0), 1, 1, 5, 3))):
+        q, ev, ec = netspec.c3_requests(100, 4, n_req, n_ev, seed=5 + n_ev)
+        for i in range(n_req):
+            host, wave = both_programs(L, f, [to_var[q[i]]], to_var[ev[i]], ec[i], options)
+            if wave[0] == -4 and options != DEFAULT:  # (beyond a device limit - without the multi-variable passes a request has twice the
+                beyond += 1                           #  work items: reported, the host plans that chunk; never with the default options)
+                continue
+            assert host[0] > 0 and same(host, wave), (n_ev, i, options, host[0], wave[0])
+            n_checked += 1
+    # two query variables, the no-prune flag (full_joint_dist / predict_proba)
+    q, ev, ec = netspec.c3_requests(100, 4, 120, 3, seed=9)
+    for i in range(120):
+        host, wave = both_programs(L, f, [to_var[q[i]], to_var[(q[i] + 7) % 100 if (q[i] + 7) % 100 not in ev[i] else (q[i] + 8) % 100]], to_var[ev[i]], ec[i], DEFAULT,
+                                   no_prune=i % 2)
+        if host[0] > 0:
+            assert same(host, wave), i
+            n_checked += 1
+    assert beyond <= 0.1 * n_checked, (beyond, n_checked)
+    print(f"{libname}: {n_checked} C3 requests, programs / work items / statistics word for word; {beyond} beyond a device limit under non-default options")
+
+
+@pytest.mark.parametrize("libname", ["libplan_sim.so", "libplan_sim_rev.so"])
+def test_wave_planner_on_the_golden_networks_it_covers(libname):
+    """Every golden network: covered (one power-of-two cardinality) -> the host's programs under every forcing option set; not covered
+    (mixed cardinalities, three-state grids) -> the build of its packed network says so (-3) and the engine keeps the old kernels."""
+    L = lib(libname)
+    nets = [(net["spec"], net["requests"]) for fname in ("examples.json", "random_dags.json", "wide_cards.json", "many_nodes.json") for net in gu.load(fname)]
+    nets += [(gu.grid_spec_from_recipe(e), e["requests"]) for e in gu.load("grids_small.json")]
+    covered, skipped, checked = 0, 0, 0
+    for spec, requests in nets:
+        bn = netspec.build(spec, sorobn_amd.BayesNet)
+        f = flatten(bn)
+        be = sorobn_amd.bayes_net.Backend.__new__(sorobn_amd.bayes_net.Backend)
+        be.flat = f
+        cards = {int(c) for c in f.card if c > 1}
+        uniform = len(f.card) <= 128 and len(cards) == 1 and (next(iter(cards)) & (next(iter(cards)) - 1)) == 0
+        for r in requests[:40]:
+            try:
+                q, ev, codes = be.encode(tuple(r["query"]), {k: v for k, v in r["event"]})
+            except KeyError:
+                continue
+            if any(c < 0 for c in codes):
+                continue  # (a label outside the domain: the engine answers without planning)
+            for options in FORCING:
+                host, wave = both_programs(L, f, q, ev, codes, options)
+                if not uniform:
+                    assert wave[0] == -3, (spec["name"], wave[0])
+                    continue
+                assert host[0] > 0 and wave[0] != -3, (spec["name"], host[0], wave[0])
+                if wave[0] == -4:  # beyond a device limit: reported, the host plans - never a different program
+                    continue
+                assert same(host, wave), (spec["name"], r["query"], options)
+                checked += 1
+        covered += uniform
+        skipped += not uniform
+    assert covered >= 8 and checked >= 2000, (covered, skipped, checked)
+    print(f"{libname}: {covered} networks covered ({checked} request x option sets word for word), {skipped} outside the wave planner's coverage")

@@ -101,7 +101,7 @@ import sqlite3, sys
 cur = sqlite3.connect(sys.argv[1]).cursor()
 by = {}
 for n, c, k, v in cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name"):
-    if "order_kernel" in n or "emit_kernel" in n or "plan" in n: by.setdefault(n.split("(")[0].split("::")[-1], {})[c] = (k, v)
+    if "order_kernel" in n or "emit_kernel" in n or "wave_plan" in n: by.setdefault(n.split("(")[0].split("::")[-1], {})[c] = (k, v)
 for n, d in by.items():
     wc = d.get("SQ_WAVE_CYCLES", (0, 1))[1] or 1
     print("%-24s launches %5d  " % (n[:24], d.get("SQ_WAVE_CYCLES", (0, 0))[0]) + "  ".join("%s %.3f" % (c.replace("SQ_", ""), v / wc) for c, (k, v) in sorted(d.items()) if c != "SQ_WAVE_CYCLES") + "  (fractions of SQ_WAVE_CYCLES)  wave cycles %.3g" % wc)

@@ -152,5 +152,6 @@ int main(int argc, char **argv) {
     };
     run("ve_sweep_kernel (r2)", ve_sweep_kernel, kSweepWG, kSweepLdsBytes);
     run("ve_sweep_dma_kernel", ve_sweep_dma_kernel, 512, kSweepLdsBytes);
+    if (dead < 0) run("ve_sweep_loader_kernel", ve_sweep_loader_kernel, kSweepLoaderWG, kSweepLoaderLdsBytes);  // round 6: a loader wave + two tile slots
     return 0;
 }

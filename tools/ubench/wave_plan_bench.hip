@@ -1,0 +1,134 @@
+// Micro-benchmark (GPU box, round 6): wave_plan_kernel - the wave-cooperative device planner, one request per wave, planning state in
+// LDS (csrc/wave_plan.h) - ALONE on a recorded request stream of the 10 x 10 four-state grid (the C3 stream's shape: 1 query + NE
+// evidence nodes), against the host planner's programs WORD FOR WORD, with the time per chunk.  What VERDICT r5 item 1 asked to see
+// before the kernel went into engine.hip; profiles/r06_a_planlanes.log has the one-request-per-lane kernels on the same stream.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -o tools/ubench/wave_plan_bench tools/ubench/wave_plan_bench.hip sorobn_amd/csrc/planner.cpp -lpthread
+//   ./wave_plan_bench [requests = 32768] [evidence nodes = 4] [requests checked against the host = 2048]
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../sorobn_amd/csrc/planner.h"
+#include "../../sorobn_amd/csrc/wave_plan_kernel.hip.h"
+
+#define CHECK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char **argv) {
+    const int64_t B = argc > 1 ? atoll(argv[1]) : 32768;
+    const int NE = argc > 2 ? atoi(argv[2]) : 4;
+    const int64_t n_check = std::min<int64_t>(B, argc > 3 ? atoll(argv[3]) : 2048);
+    const int R = 10, C = 10, K = 4, n = R * C;
+    std::vector<int32_t> card(n, K), scope_vars;
+    std::vector<int64_t> scope_off{0}, value_off{0};
+    std::vector<double> values;
+    std::mt19937_64 rng(1);
+    std::uniform_real_distribution<double> U(0.1, 1.0);
+    for (int v = 0; v < n; ++v) {
+        const int r = v / C, c = v % C;
+        if (r) scope_vars.push_back(v - C);
+        if (c) scope_vars.push_back(v - 1);
+        scope_vars.push_back(v);
+        scope_off.push_back((int64_t)scope_vars.size());
+        int64_t cells = K;
+        if (r) cells *= K;
+        if (c) cells *= K;
+        for (int64_t i = 0; i < cells; ++i) values.push_back(U(rng));
+        value_off.push_back((int64_t)values.size());
+    }
+    Network net;
+    std::string e = net.set(n, card.data(), scope_off.data(), scope_vars.data(), value_off.data(), values.data());
+    if (!e.empty()) { printf("%s\n", e.c_str()); return 1; }
+    std::vector<int32_t> hint(n);
+    for (int v = 0; v < n; ++v) hint[v] = v;
+    net.set_hints(1, hint.data());
+    WNet *wn = new WNet;
+    if (!net.wave_view(*wn)) { printf("network outside the wave planner's coverage\n"); return 1; }
+    std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
+    std::vector<int32_t> qv(B), ev((size_t)NE * B), ec((size_t)NE * B);
+    std::vector<char> skip(B, 0);
+    for (int64_t b = 0; b < B; ++b) {
+        int pick[40];
+        for (int k = 0; k < NE + 1;) {
+            const int v = (int)(rng() % n);
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup = dup || pick[j] == v;
+            if (!dup) pick[k++] = v;
+        }
+        qv[b] = pick[0];
+        for (int k = 0; k < NE; ++k) { ev[NE * b + k] = pick[1 + k]; ec[NE * b + k] = (int)(rng() % K); }
+    }
+    for (int64_t b = 0; b <= B; ++b) { q_off[b] = b; e_off[b] = NE * b; out_off[b] = 4 * b; }
+    const uint32_t stride = 6144;
+    const size_t tag_cap = (size_t)B * 64;
+    WNet *d_net; B2 *d_anc; int64_t *d_qo, *d_eo, *d_oo; int32_t *d_qv, *d_ev, *d_ec; char *d_skip; uint32_t *d_prog, *d_cursor; EmitMeta *d_meta; Tag *d_tags;
+    CHECK(hipMalloc(&d_net, sizeof(WNet))); CHECK(hipMemcpy(d_net, wn, sizeof(WNet), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_anc, n * sizeof(B2))); CHECK(hipMemcpy(d_anc, net.anc2.data(), n * sizeof(B2), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_qo, (B + 1) * 8)); CHECK(hipMemcpy(d_qo, q_off.data(), (B + 1) * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_eo, (B + 1) * 8)); CHECK(hipMemcpy(d_eo, e_off.data(), (B + 1) * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_oo, (B + 1) * 8)); CHECK(hipMemcpy(d_oo, out_off.data(), (B + 1) * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_qv, B * 4)); CHECK(hipMemcpy(d_qv, qv.data(), B * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_ev, (size_t)NE * B * 4 + 4)); CHECK(hipMemcpy(d_ev, ev.data(), (size_t)NE * B * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_ec, (size_t)NE * B * 4 + 4)); CHECK(hipMemcpy(d_ec, ec.data(), (size_t)NE * B * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_skip, B)); CHECK(hipMemset(d_skip, 0, B));
+    CHECK(hipMalloc(&d_prog, (size_t)B * stride * 4 + 4096)); CHECK(hipMalloc(&d_cursor, 64)); CHECK(hipMalloc(&d_meta, B * sizeof(EmitMeta)));
+    CHECK(hipMalloc(&d_tags, tag_cap * sizeof(Tag)));
+    WavePlanArgs A;
+    A.net = d_net; A.anc = d_anc; A.q_off = d_qo; A.e_off = d_eo; A.out_off = d_oo; A.q_vars = d_qv; A.e_vars = d_ev; A.e_codes = d_ec; A.skip = d_skip;
+    A.B = B; A.flags = 0; A.prog = d_prog; A.prog_stride = stride; A.meta = d_meta; A.tags = d_tags; A.tag_cursor = d_cursor; A.tag_cap = (uint32_t)tag_cap;
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const unsigned grid = (unsigned)((B + kWaveWG - 1) / kWaveWG);
+    float best_ms = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, 0, d_cursor);
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(wave_plan_kernel, dim3(grid), dim3(64 * kWaveWG), 0, 0, A);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipGetLastError());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("launch %d: %lld requests, %d evidence nodes: %.3f ms = %.2f us per request (whole chip), %.0f requests/s\n", rep, (long long)B, NE, ms, ms * 1e3 / B, B / ms * 1e3);
+        fflush(stdout);
+        best_ms = std::min(best_ms, ms);
+    }
+    // against the host planner, word for word
+    std::vector<EmitMeta> meta(B);
+    CHECK(hipMemcpy(meta.data(), d_meta, B * sizeof(EmitMeta), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> dev((size_t)n_check * stride);
+    CHECK(hipMemcpy(dev.data(), d_prog, dev.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<Tag> tags(tag_cap);
+    CHECK(hipMemcpy(tags.data(), d_tags, tag_cap * sizeof(Tag), hipMemcpyDeviceToHost));
+    int64_t bad = 0, errs = 0;
+    double words = 0, steps = 0;
+    for (int64_t b = 0; b < B; ++b) { errs += meta[b].err != 0; words += meta[b].words; steps += meta[b].n_steps; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t b = 0; b < n_check; ++b) {
+        Request rq;
+        rq.nq = 1; rq.qvars = &qv[b]; rq.ne = NE; rq.evars = &ev[NE * b]; rq.ecodes = &ec[NE * b]; rq.out_off = out_off[b];
+        std::vector<uint32_t> hp;
+        PlanStats st;
+        const std::string pe = plan_request(net, rq, hp, st);
+        if (!pe.empty()) { printf("host planner: %s\n", pe.c_str()); return 1; }
+        std::vector<Tag> ht;
+        tag_program(net.emit_view(), hp.data(), [&](const Tag &t) { ht.push_back(t); });
+        const EmitMeta &m = meta[b];
+        bool same = m.err == 0 && m.words == hp.size() && std::memcmp(dev.data() + (size_t)b * stride, hp.data(), hp.size() * 4) == 0 && m.alg_bytes == st.alg_bytes &&
+                    m.n_steps == st.n_steps && m.arena_cells == st.arena_cells && m.n_tags == ht.size() &&
+                    std::memcmp(tags.data() + m.tag_first, ht.data(), ht.size() * sizeof(Tag)) == 0;
+        if (!same && ++bad <= 5) {
+            size_t d = 0;
+            while (d < hp.size() && dev[(size_t)b * stride + d] == hp[d]) ++d;
+            printf("request %lld: err %d words %u / %zu first difference at word %zu, steps %.0f / %.0f, tags %u / %zu\n", (long long)b, m.err, m.words, hp.size(), d, m.n_steps, st.n_steps, m.n_tags, ht.size());
+        }
+    }
+    const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (double)n_check;
+    printf("%lld of %lld checked requests differ from the host planner's programs / work items / statistics; %lld of %lld requests report an error; mean %.0f words, %.1f steps\n",
+           (long long)bad, (long long)n_check, (long long)errs, (long long)B, words / B, steps / B);
+    printf("wave_plan_kernel: %.3f ms per %lld requests = %.3f us per request with the whole chip; the host planner + tagging on one core of this box: %.1f us per request\n", best_ms, (long long)B,
+           best_ms * 1e3 / B, host_us);
+    return bad != 0 || errs != 0;
+}
