@@ -230,6 +230,11 @@ bool Network::wave_view(WNet &w) const {
     w.big_iters = ev.big_iters; w.tile_bytes = ev.tile_bytes;
     w.log2_small = ev.log2_small; w.log2_big = ev.log2_big;
     w.minfill_above = ov.minfill_above; w.chain_weight = ov.chain_weight; w.big_cells = ov.big_cells;
+    // (the byte model runs on integers: 8 x the chain weight must be one, and the cost of an order stays below 2^53)
+    if (!(ov.chain_weight == 1.0 || ov.chain_weight == 0.5 || ov.chain_weight == 0.25 || ov.chain_weight == 0.125)) return false;
+    w.big_log2 = -1;
+    for (int e = 0; e < 40; ++e)
+        if (ov.big_cells == (double)(1ull << e)) w.big_log2 = e;
     for (int v = 0; v < n_vars; ++v) {
         if (card[v] > 65535 || depth[v] > 255 || pool_off[v] < 0) return false;
         w.scope[v] = scope2[v];

@@ -35,15 +35,33 @@ namespace mibn {
 #define WV_LANE0 if (true)
 #endif
 
+// Phase timers (tools/ubench/wave_plan_bench.hip -DMIBN_WAVE_PROF): a tick books the time since the previous one to phase k, per wave.
+#if defined(MIBN_WAVE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+struct WProf { unsigned long long t, a[24]; };
+#define WV_PROF_ARG , WProf &prof_
+#define WV_PROF_PASS , prof_
+#define WV_TICK(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_.a[k] += t_ - prof_.t; prof_.t = t_; }
+#elif defined(MIBN_WAVE_PROF)
+struct WProf { unsigned long long t, a[24]; };
+#define WV_PROF_ARG , WProf &prof_
+#define WV_PROF_PASS , prof_
+#define WV_TICK(k)
+#else
+#define WV_PROF_ARG
+#define WV_PROF_PASS
+#define WV_TICK(k)
+#endif
+
 constexpr int kEmitErrDevice = 7;  // the request exceeds a device limit below: the host plans the chunk (like kEmitErrWords)
 constexpr int kWVars = 128;
 constexpr int kWHints = 4;
-constexpr int kWCsr = 768;     // scope entries of all CPTs together
+constexpr int kWCsr = 512;     // scope entries of all CPTs together
 constexpr int kWAxes = 24;     // axes of a factor / of a step before merging
-constexpr int kWEnt = 24;      // created factors alive at once (+ the inputs of the step in flight)
+constexpr int kWEnt = 20;      // created factors alive at once (+ the inputs of the step in flight)
 constexpr int kWSims = 4;      // candidate orders simulated side by side
 constexpr int kWSimEnt = 24;   // factors alive at once in a simulation
 constexpr int kWTags = 64;     // work items of a request
+constexpr int kWBlocks = 32;   // free blocks of the arena (the host's list holds Arena::kMaxBlocks = 64: a request that would need more goes to the host)
 constexpr int kWIns = 160;     // factor handles of one product
 
 // a B2 as it is stored in LDS / in unions (B2 itself has member initialisers: no trivial constructor)
@@ -63,6 +81,7 @@ struct WNet {
     int32_t small_cells, prune, outer, fuse, chain, sweep, sweep_min, sweep_canon, tile_h, sweep_iters;
     int64_t big_iters, tile_bytes;
     double log2_small, log2_big, minfill_above, chain_weight, big_cells;
+    int32_t big_log2, pad_;  // big_cells = 2^big_log2 (-1: not a power of two)
     uint32_t pool_off[kWVars];
     int32_t scope_stride[kWCsr];
     uint16_t card[kWVars], scope_off[kWVars + 1];
@@ -78,16 +97,8 @@ struct WEnt {  // a created factor: dense, C-order over vars (strides kept: CHAI
     uint8_t vars[kWAxes];
     int32_t strides[kWAxes];
 };
-struct WView {  // an input of the step being emitted
-    int32_t n, cells, alloc, h;
-    uint64_t off;
-    B2S scope;
-    uint8_t vars[kWAxes];
-    int32_t strides[kWAxes];
-};
-struct WSim {  // one candidate order's byte-model state (a lane each)
+struct WSim {  // one candidate order's byte-model state (a lane each): the created factors alive
     B2S scope[kWSimEnt];
-    uint32_t mem[kWVars];  // per variable: the live created factors that contain it
     uint8_t cnt[kWSimEnt];
 };
 struct WGreedy {
@@ -101,7 +112,8 @@ struct WState {
     // the request
     uint8_t order[kWVars];   // the elimination order the search chose
     uint16_t ecode[kWVars];
-    uint8_t key[kWVars];
+    uint8_t key[kWVars];     // position of a variable in the layout order: elimination position, query variables behind (255: none)
+    uint8_t pvar[kWVars];    // ... and back
     int8_t pos[kWVars];
     uint32_t cpt_cells[kWVars], cpt_off[kWVars];
     union {
@@ -116,9 +128,8 @@ struct WState {
         } o;
         struct {  // emission
             WEnt ent[kWEnt];
-            uint8_t live[kWEnt];           // alive created factors in creation order
-            int64_t foff[Arena::kMaxBlocks], fsz[Arena::kMaxBlocks];
-            WView in[kMaxIn];
+            uint8_t live[kWEnt], live_tmp[kWEnt];  // alive created factors in creation order
+            int64_t foff[kWBlocks], fsz[kWBlocks];
             uint8_t hl[kWIns], hs[kSweepMaxSmall + 4];  // handles: factors of the product in flight / of a SWEEP candidate
             int32_t s[kMaxIn][kWAxes], xs[kMaxIn][3];
             int32_t t[20][kWAxes];         // the step forms' axis tables
@@ -142,12 +153,11 @@ struct WResult {
 WV_HD B2 b2_and(const B2 &x, const B2 &y) { B2 r; r.a = x.a & y.a; r.b = x.b & y.b; return r; }
 WV_HD B2 b2_or(const B2 &x, const B2 &y) { B2 r; r.a = x.a | y.a; r.b = x.b | y.b; return r; }
 WV_HD B2 b2_andn(const B2 &x, const B2 &y) { B2 r; r.a = x.a & ~y.a; r.b = x.b & ~y.b; return r; }
-WV_HD B2 b2_above(int y) {  // the bits > y
+WV_HD B2 b2_above(int y) {  // the bits > y, 0 <= y < 128
     B2 r;
-    if (y < 63) { r.a = ~0ull << (y + 1); r.b = ~0ull; }
-    else if (y == 63) { r.a = 0; r.b = ~0ull; }
-    else if (y < 127) { r.a = 0; r.b = ~0ull << (y - 63); }
-    else { r.a = 0; r.b = 0; }
+    const uint64_t lo = (~1ull) << (y & 63);  // bits > (y mod 64) of a word
+    r.a = y < 64 ? lo : 0ull;
+    r.b = y < 64 ? ~0ull : lo;
     return r;
 }
 WV_HD int b2_first(const B2 &s) { return s.a ? __builtin_ctzll(s.a) : 64 + __builtin_ctzll(s.b); }
@@ -166,71 +176,74 @@ struct WOrderCtx {
     WV_HD double cells_of(const B2 &u) const { return order_pow2(l * b2_count(u)); }
 
     // SURVEY section 8(d) byte model of one candidate (order_simulate), run by ONE lane: the created factors live in a table of
-    // kWSimEnt entries that are recycled as they are consumed, every variable keeps the set of live entries that contain it.
-    // (Sums of cell counts are sums of integers < 2^53: the order of the terms does not matter, the total is the host's.)
-    WV_HD double simulate(WSim &S, const uint8_t *order, int n_order, double abort_above, bool &over) const {
+    // kWSimEnt entries that are recycled as they are consumed; the entries that contain x are found by testing the live ones (a handful).
+    // Integer arithmetic: every cell count is a power of two, the weights 8 and 8 x chain_weight are 8 / w8 (wave_view admits the
+    // chain weights 1, 1/2, 1/4, 1/8 only), so the cost in bytes is an integer below 2^63 - the number the host computes in doubles
+    // (sums of integers < 2^53: exact, the order of the terms does not matter).
+    WV_HD double simulate(WSim &S, const uint8_t *order, int n_order, bool &over) const {
         B2 alive0 = rel;
         uint32_t calive = 0;
-        double bytes = 0;
+        uint64_t bytes = 0;
+        const uint64_t w8 = (uint64_t)(8.0 * N.chain_weight);
+        const int big_log2 = N.big_log2;  // a table is big iff its cells > big_cells: l x count > big_log2 (big_cells = 2^big_log2) or compared as doubles below
         for (int o = 0; o < n_order; ++o) {
             const int x = order[o];
             const B2 m0 = b2_and(N.fam[x], alive0);
             alive0 = b2_andn(alive0, m0);
-            const uint32_t mc = S.mem[x] & calive;
-            calive &= ~mc;
             B2 u;
-            double in = 0;
+            uint64_t in = 0;
             int nbig = 0;
             b2_each(m0, [&](int i) {
                 const B2 sc = b2_and(N.scope[i], keep);
                 u = b2_or(u, sc);
-                const double c = cells_of(sc);
-                in += c;
-                nbig += c > N.big_cells;
+                const int e2 = l * b2_count(sc);
+                in += 1ull << e2;
+                nbig += big_log2 >= 0 ? e2 > big_log2 : order_pow2(e2) > N.big_cells;
             });
-            for (uint32_t m = mc; m; m &= m - 1) {
+            uint32_t mc = 0;
+            for (uint32_t m = calive; m; m &= m - 1) {
                 const int e = __builtin_ctz(m);
-                u = b2_or(u, S.scope[e]);
-                const double c = order_pow2(l * S.cnt[e]);
-                in += c;
-                nbig += c > N.big_cells;
+                const B2 sc = S.scope[e];
+                if (!sc.test(x)) continue;
+                mc |= 1u << e;
+                u = b2_or(u, sc);
+                const int e2 = l * S.cnt[e];
+                in += 1ull << e2;
+                nbig += big_log2 >= 0 ? e2 > big_log2 : order_pow2(e2) > N.big_cells;
             }
+            calive &= ~mc;
             u.clr(x);
             const int ucnt = b2_count(u);
-            const double uc = order_pow2(l * ucnt);
-            bytes += (nbig == 1 ? 8.0 * N.chain_weight : 8.0) * (in + uc);
-            if (bytes > abort_above) return bytes;
+            bytes += (nbig == 1 ? w8 : 8ull) * (in + (1ull << (l * ucnt)));
             const uint32_t free_ = ~calive & ((1u << kWSimEnt) - 1);
-            if (!free_) { over = true; return __builtin_inf(); }
+            if (!free_ || l * ucnt >= 58) { over = true; return __builtin_inf(); }
             const int e = __builtin_ctz(free_);
             S.scope[e] = u;
             S.cnt[e] = (uint8_t)ucnt;
             calive |= 1u << e;
-            b2_each(u, [&](int v) { S.mem[v] = (S.mem[v] & ~mc) | (1u << e); });
         }
         B2 u;
-        double in = 0;
+        uint64_t in = 0;
         b2_each(alive0, [&](int i) {
             const B2 sc = b2_and(N.scope[i], keep);
             u = b2_or(u, sc);
-            in += cells_of(sc);
+            in += 1ull << (l * b2_count(sc));
         });
         for (uint32_t m = calive; m; m &= m - 1) {
             const int e = __builtin_ctz(m);
             u = b2_or(u, S.scope[e]);
-            in += order_pow2(l * S.cnt[e]);
+            in += 1ull << (l * S.cnt[e]);
         }
-        return bytes + 8.0 * (in + cells_of(u));
+        if (l * b2_count(u) >= 58) { over = true; return __builtin_inf(); }
+        return (double)(bytes + 8ull * (in + (1ull << (l * b2_count(u)))));
     }
 
     // candidates [c0, c1) side by side, one per lane -> W.o.cost
     WV_HD void simulate_batch(int c0, int c1) {
-        wv::for_n(kWSims * kWVars, [&](int i) { W.o.sim[i / kWVars].mem[i % kWVars] = 0; });
-        wv::sync();
         bool over = false;
         wv::for_n(c1 - c0, [&](int k) {
             bool ov = false;
-            const double c = simulate(W.o.sim[k], W.o.cand[c0 + k], W.o.n_cand[c0 + k], __builtin_inf(), ov);
+            const double c = simulate(W.o.sim[k], W.o.cand[c0 + k], W.o.n_cand[c0 + k], ov);
             W.o.cost[c0 + k] = ov ? -1.0 : c;
         });
         wv::sync();
@@ -328,7 +341,7 @@ struct WOrderCtx {
     }
 
     // order_search: the whole search of one request -> W.order, returns the number of hidden variables in it
-    WV_HD int search(int nq, const int32_t *qvars, int ne, const int32_t *evars, const B2 *anc, bool no_prune) {
+    WV_HD int search(int nq, const int32_t *qvars, int ne, const int32_t *evars, const B2 *anc, bool no_prune WV_PROF_ARG) {
         B2 qb, eb;
         rel = B2{};
         for (int i = 0; i < nq; ++i) { const int v = qvars[i]; qb.set(v); rel.set(v); rel = b2_or(rel, anc[v]); }
@@ -358,17 +371,24 @@ struct WOrderCtx {
             }
         }
         wv::sync();
+        WV_TICK(0)  // relevant set, candidate sweeps
         for (int c0 = 0; c0 < nc; c0 += kWSims) simulate_batch(c0, c0 + kWSims < nc ? c0 + kWSims : nc);
+        WV_TICK(1)  // byte model of the sweeps
         if (overflow) return -1;
         double best_cost = __builtin_inf();
         int best = -1;
         for (int c = 0; c < nc; ++c)
             if (W.o.cost[c] < best_cost) { best_cost = W.o.cost[c]; best = c; }
         // greedy min-fill where the sweeps cost more than minfill_above
-        if (best_cost > N.minfill_above * N.chain_weight && greedy(nc, best_cost)) {
-            simulate_batch(nc, nc + 1);
-            if (overflow) return -1;
-            if (W.o.cost[nc] < best_cost) best = nc;
+        if (best_cost > N.minfill_above * N.chain_weight) {
+            const bool can_win = greedy(nc, best_cost);
+            WV_TICK(2)  // min-fill
+            if (can_win) {
+                simulate_batch(nc, nc + 1);
+                WV_TICK(3)  // its byte model
+                if (overflow) return -1;
+                if (W.o.cost[nc] < best_cost) best = nc;
+            }
         }
         const int nb = W.o.n_cand[best];
         wv::for_n(nb, [&](int i) { W.order[i] = W.o.cand[best][i]; });
@@ -378,6 +398,12 @@ struct WOrderCtx {
 };
 
 
+#if defined(MIBN_WAVE_COUNT) && !defined(__HIP_DEVICE_COMPILE__)  // (tools/wave_check.cpp: how often each step form is tried / emitted)
+static long g_wave_count[32];
+#define WV_COUNT(k) (++g_wave_count[k])
+#else
+#define WV_COUNT(k)
+#endif
 // ===========================================================================================================================
 // Emission (emit_core.h: Arena, Emitter, emit_begin, emit_run, tag_program).  Factor handles: h < 128 = the evidence-sliced CPT
 // of variable h (a view of the network tables: nothing is stored but its cells and its offset), 128 + e = created factor e.
@@ -403,6 +429,8 @@ struct WEmit {
     int n_live = 0;          // created factors alive (W.e.live: creation order)
     uint32_t ent_busy = 0;   // entries in use: alive, or an input / the output of the step in flight
     uint32_t consumed_ents = 0;  // entries consumed by the step in flight (their data stays until the step is complete)
+    const uint8_t *cur_hl = nullptr;  // the inputs of the step being emitted (handles)
+    int npos = 0;            // layout positions in use (W.pvar)
     int n_pool = 0, pool_cap = 0;  // the host's pool accounting (its limits are part of the program's definition)
     int nf = 0;              // arena: free blocks (W.e.foff / fsz), top
     int64_t top = 0;
@@ -435,21 +463,6 @@ struct WEmit {
                 if (E.vars[a] == v) st = E.strides[a];
         }
         return st;
-    }
-    WV_HD bool load_view(int h, WView &V) {
-        if (h >= kWVars) {
-            const WEnt &E = W.e.ent[h - kWVars];
-            wv::for_n(E.n, [&](int a) { V.vars[a] = E.vars[a]; V.strides[a] = E.strides[a]; });
-            WV_LANE0 { V.n = E.n; V.cells = E.cells; V.alloc = E.cells; V.h = h; V.off = (uint64_t)E.off; V.scope = E.scope; }
-        } else {
-            const int k0 = N.scope_off[h], k1 = N.scope_off[h + 1];
-            const int n = wv::compact_n(k1 - k0, 0, [&](int i) { return keep.test(N.scope_var[k0 + i]); },
-                                        [&](int i, int k) { if (k < kWAxes) { V.vars[k] = N.scope_var[k0 + i]; V.strides[k] = N.scope_stride[k0 + i]; } });
-            if (n > kWAxes) { err = kEmitErrDevice; return false; }
-            WV_LANE0 { V.n = n; V.cells = (int32_t)W.cpt_cells[h]; V.alloc = 0; V.h = h; V.off = (uint64_t)W.cpt_off[h] | kConstFlag; V.scope = b2_and(N.scope[h], keep); }
-        }
-        wv::sync();
-        return true;
     }
     WV_HD int ent_alloc() {  // a free entry for the factor a step creates (-1: none - the request goes to the host)
         const uint32_t free_ = ~ent_busy & ((1u << kWEnt) - 1);
@@ -502,14 +515,16 @@ struct WEmit {
             WV_LANE0 fsz[i - 1] += n;
         } else if (right) {
             WV_LANE0 { foff[i] = o; fsz[i] += n; }
-        } else if (nf < Arena::kMaxBlocks) {
+        } else if (nf < kWBlocks) {
             WV_LANE0 {
                 for (int k = nf; k > i; --k) { foff[k] = foff[k - 1]; fsz[k] = fsz[k - 1]; }
                 foff[i] = o;
                 fsz[i] = n;
             }
             ++nf;
-        }  // else: leak the block (only costs scratch space)
+        } else {
+            err = kEmitErrDevice;  // (the host's list is twice as long and leaks beyond that: not reproduced here)
+        }
         wv::sync();
     }
 
@@ -552,50 +567,72 @@ struct WEmit {
 
     // ---- GENERIC encoding (emit_generic): iteration space = output cells -----------------------------------------------------
     WV_HD void emit_generic(int n_in, WEnt &out, int64_t cells, int cx, bool final_, uint32_t *&wout) {
-        const int na = out.n;
+        const int na = out.n, l = N.uniform_log2;
+        const int64_t K = int64_t(1) << l;  // (every axis is a multi-state variable: 2^l states)
         int nlo = 0;
         int64_t lo = 1;
         const int64_t lomax = n_in <= 3 ? kLoMax : kLoTarget;
-        while (nlo < na && lo < kLoTarget && lo * card(out.vars[nlo]) <= lomax) lo *= card(out.vars[nlo++]);
+        while (nlo < na && lo < kLoTarget && lo * K <= lomax) { lo *= K; ++nlo; }
         // merge adjacent axes that are contiguous in every input: axis a continues the block of a - 1 iff every input's stride
         // along a is its stride along a - 1 times that axis' cardinality (the block's start stride times its cells so far)
         int32_t (*s)[kWAxes] = W.e.s;
         const uint64_t cont = wv::mask64(na, [&](int a) {
             if (a == 0 || a == nlo) return false;
             bool m = true;
-            const int64_t c = card(out.vars[a - 1]);
-            for (int j = 0; j < n_in; ++j) m = m && (int64_t)s[j][a] == (int64_t)s[j][a - 1] * c;
+            for (int j = 0; j < n_in; ++j) m = m && (int64_t)s[j][a] == (int64_t)s[j][a - 1] * K;
             return m;
         });
         int32_t *mcard = W.e.t[T_MC], *start = W.e.t[T_MAP];
         int ma = 0, mlo = 0;
-        uint64_t blk = 0;
-        for (int a = 0; a < na; ++a) {
-            const uint32_t c = (uint32_t)card(out.vars[a]);
-            if (((cont >> a) & 1) && ma > 0 && blk * c < (1u << 30)) {
-                blk *= c;
-                WV_LANE0 mcard[ma - 1] = (int32_t)blk;
-            } else {
-                WV_LANE0 { mcard[ma] = (int32_t)c; start[ma] = a; }
-                blk = c;
-                ++ma;
-                if (a < nlo) ++mlo;
+        if (l * na < 30) {
+            // (no block can reach 2^30 cells: the blocks are the runs between the axes that do not continue their predecessor)
+            const uint32_t bnd = ~(uint32_t)cont & (na < 32 ? (1u << na) - 1 : ~0u);
+            ma = __builtin_popcount(bnd);
+            mlo = __builtin_popcount(bnd & ((1u << nlo) - 1));
+            wv::for_n(ma, [&](int m) {
+                uint32_t b = bnd;
+                for (int q = 0; q < m; ++q) b &= b - 1;
+                const int a0 = __builtin_ctz(b);
+                b &= b - 1;
+                const int a1 = b ? __builtin_ctz(b) : na;
+                start[m] = a0;
+                mcard[m] = (int32_t)(1u << (l * (a1 - a0)));
+            });
+        } else {
+            uint64_t blk = 0;
+            for (int a = 0; a < na; ++a) {
+                if (((cont >> a) & 1) && ma > 0 && blk * (uint64_t)K < (1u << 30)) {
+                    blk *= (uint64_t)K;
+                    WV_LANE0 mcard[ma - 1] = (int32_t)blk;
+                } else {
+                    WV_LANE0 { mcard[ma] = (int32_t)K; start[ma] = a; }
+                    blk = (uint64_t)K;
+                    ++ma;
+                    if (a < nlo) ++mlo;
+                }
             }
         }
         wv::sync();
         if (ma > kMaxAxes) { err = kEmitErrStepAxes; return; }
-        const int words = kHdrWords + 3 * n_in + ma + n_in * ma;
+        const int nbw = 3 * n_in, body = nbw + ma + n_in * ma;
+        const int words = kHdrWords + body;
         uint32_t *w = extend(words);
         wout = w;
         header(kKindGeneric, n_in, ma, mlo, cx, final_, lo, cells / lo, (uint64_t)out.off, words);
         uint32_t *p = w + kHdrWords;
-        for (int j = 0; j < n_in; ++j) {
-            put_off(p, W.e.in[j].off);
-            put(p, (uint32_t)W.e.xs[j][0]);
-        }
-        wv::for_n(ma, [&](int a) { p[a] = (uint32_t)mcard[a]; });
-        p += ma;
-        wv::for_n(n_in * ma, [&](int i) { p[i] = (uint32_t)s[i / ma][start[i % ma]]; });
+        const uint8_t *hl = cur_hl;
+        wv::for_n(n_in * 32, [&](int i) {  // lane (j, a): the three words of input j (a < 3), the merged cardinalities (j = 0), its merged strides
+            const int j = i >> 5, a = i & 31;
+            if (a < 3) {
+                const uint64_t off = foffset(hl[j]);
+                p[3 * j + a] = a == 0 ? (uint32_t)(off & 0xffffffffu) : (a == 1 ? (uint32_t)(off >> 32) : (uint32_t)W.e.xs[j][0]);
+            }
+            if (a < ma) {
+                if (j == 0) p[nbw + a] = (uint32_t)mcard[a];
+                p[nbw + ma + j * ma + a] = (uint32_t)s[j][start[a]];
+            }
+        });
+        (void)body;
     }
 
     WV_HD static int nth_bit(uint32_t m, int k) {
@@ -676,7 +713,7 @@ struct WEmit {
         const int na = out.n;
         uint32_t bigm = 0;
         for (int j = 0; j < n_in; ++j)
-            if (W.e.in[j].cells > N.small_cells) bigm |= 1u << j;
+            if (fcells(cur_hl[j]) > N.small_cells) bigm |= 1u << j;
         const int nb = __builtin_popcount(bigm), ns = n_in - nb;
         const uint32_t smallm = ~bigm & ((1u << n_in) - 1);
         if (nb < 1 || nb > 2 || ns > kMaxSmall || cx > kMaxCx) return false;
@@ -761,13 +798,13 @@ struct WEmit {
         uint32_t *p = w + kHdrWords;
         for (int b = 0; b < nb; ++b) {
             const int j = b ? big1 : big0;
-            put_off(p, W.e.in[j].off);
+            put_off(p, foffset(cur_hl[j]));
             put(p, (uint32_t)W.e.xs[j][0]);
             put(p, (uint32_t)W.e.xs[j][1]);
         }
         for (uint32_t m = smallm; m; m &= m - 1) {
             const int j = __builtin_ctz(m);
-            put_off(p, W.e.in[j].off);
+            put_off(p, foffset(cur_hl[j]));
             put(p, (uint32_t)W.e.xs[j][0]);
             put(p, (uint32_t)W.e.xs[j][1]);
             wv::for_n(nT, [&](int i) { p[i] = (uint32_t)s[j][i < nN ? t[T_NAX][i] : t[T_CTRL][i - nN]]; });
@@ -847,7 +884,7 @@ struct WEmit {
         int32_t (*s)[kWAxes] = W.e.s;
         uint32_t bigm = 0;
         for (int j = 0; j < n_in; ++j)
-            if (W.e.in[j].cells > N.small_cells) bigm |= 1u << j;
+            if (fcells(cur_hl[j]) > N.small_cells) bigm |= 1u << j;
         const int nbig = __builtin_popcount(bigm), ns = n_in - nbig;
         if (nbig != 2 || ns > kMaxSmall) return false;
         const uint32_t smallm = ~bigm & ((1u << n_in) - 1);
@@ -892,13 +929,13 @@ struct WEmit {
         uint32_t *p = w + kHdrWords;
         for (int q = 0; q < 2; ++q) {
             const int j = q ? B : A;
-            put_off(p, W.e.in[j].off);
+            put_off(p, foffset(cur_hl[j]));
             put(p, (uint32_t)W.e.xs[j][0]);
             put(p, (uint32_t)W.e.xs[j][1]);
         }
         for (uint32_t m = smallm; m; m &= m - 1) {
             const int j = __builtin_ctz(m);
-            put_off(p, W.e.in[j].off);
+            put_off(p, foffset(cur_hl[j]));
             put(p, (uint32_t)W.e.xs[j][0]);
             put(p, (uint32_t)W.e.xs[j][1]);
             put(p, (uint32_t)s[j][r.nax0]);
@@ -935,7 +972,7 @@ struct WEmit {
         uint32_t g12m = 0, g3m = 0;
         bool x3dep = false;
         for (int j = 0; j < n_in; ++j) {
-            if (W.e.in[j].cells > N.small_cells) {
+            if (fcells(cur_hl[j]) > N.small_cells) {
                 if (big >= 0) return false;
                 big = j;
             } else if (xs(j, 2) != 0 && xs(j, 0) == 0 && xs(j, 1) == 0) {
@@ -1055,7 +1092,7 @@ struct WEmit {
         hdr_set(7, 2u | ((uint32_t)n12 << 4) | (2u << 8) | ((uint32_t)(nT - 2) << 12) | (16u << 16));
         hdr_set(8, (uint32_t)T12 | (4u << 16));
         uint32_t *p = w + kHdrWords;
-        put_off(p, W.e.in[big].off);
+        put_off(p, foffset(cur_hl[big]));
         put(p, (uint32_t)xs(big, 0));
         put(p, (uint32_t)xs(big, 1));
         put(p, (uint32_t)T12);
@@ -1064,7 +1101,7 @@ struct WEmit {
         put(p, (uint32_t)t12x3);
         for (uint32_t m = g12m; m; m &= m - 1) {
             const int j = __builtin_ctz(m);
-            put_off(p, W.e.in[j].off);
+            put_off(p, foffset(cur_hl[j]));
             put(p, (uint32_t)xs(j, 0));
             put(p, (uint32_t)xs(j, 1));
             put(p, (uint32_t)sc(j, 0));
@@ -1089,7 +1126,7 @@ struct WEmit {
         p += nc3;
         for (uint32_t m = g3m; m; m &= m - 1) {
             const int j = __builtin_ctz(m);
-            put_off(p, W.e.in[j].off);
+            put_off(p, foffset(cur_hl[j]));
             put(p, (uint32_t)xs(j, 2));
             put(p, (uint32_t)sc(j, 2));
             if (n12dep) { put(p, (uint32_t)sc(j, 0)); put(p, (uint32_t)sc(j, 1)); }
@@ -1106,6 +1143,7 @@ struct WEmit {
     // ---- SWEEP form (emit_sweep): k = 2..5 four-state variables X[0..k) of the one big input, the tile resident in LDS ---------
     // hs[0..n_in) = the candidate's factors; X = W.order + i.  Does its own bookkeeping; false: nothing emitted, nothing allocated.
     WV_HD bool emit_sweep(const uint8_t *hs, int n_in, const uint8_t *X, int k, int eo) {
+        WV_COUNT(14 + k);
         if (k < 2 || k > 5 || n_in - 1 > kSweepMaxSmall) return false;
         int Fh = -1;
         for (int j = 0; j < n_in; ++j)
@@ -1276,6 +1314,7 @@ struct WEmit {
         max_step_cells = emit_max(max_step_cells, (double)F.cells);
         n_steps += 1;
         tag_step((uint32_t)(w - data));
+        WV_COUNT(20 + k);
         for (int j = 0; j < n_in; ++j)
             if (falloc(hs[j])) arena_release((int64_t)foffset(hs[j]), falloc(hs[j]));
         return true;
@@ -1283,47 +1322,64 @@ struct WEmit {
 
     // ---- one step (Emitter::emit): multiply hl[0..n_in), sum out X[0..nx); the new factor is entry eo --------------------------
     WV_HD bool emit(const uint8_t *hl, int n_in, const int *X, int nx, bool final_, int64_t final_off, int eo, bool fiber_only) {
+        WV_COUNT(nx * 2 + (fiber_only ? 1 : 0));
         WEnt &out = W.e.ent[eo];
-        for (int j = 0; j < n_in; ++j)
-            if (!load_view(hl[j], W.e.in[j])) return false;
+        cur_hl = hl;
+        const int l = N.uniform_log2;
         B2 scope;
-        for (int j = 0; j < n_in; ++j) scope = b2_or(scope, W.e.in[j].scope);
+        double in_cells = 0;
+        int maxn = 1;
+        for (int j = 0; j < n_in; ++j) {
+            const int h = hl[j];
+            scope = b2_or(scope, fscope(h));
+            in_cells += (double)fcells(h);
+            const int rn = h < kWVars ? (int)N.scope_off[h + 1] - (int)N.scope_off[h] : W.e.ent[h - kWVars].n;
+            maxn = rn > maxn ? rn : maxn;
+        }
         for (int k = 0; k < nx; ++k) scope.clr(X[k]);
         const int na = b2_count(scope);
         if (na > kWAxes) { err = kEmitErrDevice; return false; }
-        // layout: longest-living variable fastest - the rank of a variable = the variables of the scope with a larger key (ties: smaller id)
-        wv::for_n(N.n_vars, [&](int v) {
-            if (!scope.test(v)) return;
-            const int kv = W.key[v];
-            int r = 0;
-            b2_each(scope, [&](int u) { const int ku = W.key[u]; r += ku > kv || (ku == kv && u < v); });
+        // every axis is a multi-state variable of 2^l states: the dense strides are powers of two
+        if (l * na >= 31) { if (!fiber_only) err = kEmitErrCells; return false; }
+        const int64_t cells = int64_t(1) << (l * na);
+        // layout: longest-living variable fastest.  In layout-position space (W.key / W.pvar: elimination position, the query variables
+        // behind) the scope is a bit set, the rank of a variable the number of scope bits above its own
+        const B2 ps = wv::mask128(npos, [&](int p) { return scope.test(W.pvar[p]); });
+        wv::for_n(npos, [&](int p) {
+            if (!ps.test(p)) return;
+            const int r = b2_count(b2_and(ps, b2_above(p)));
+            const int v = W.pvar[p];
             out.vars[r] = (uint8_t)v;
+            out.strides[r] = (int32_t)(1u << (l * r));
             W.pos[v] = (int8_t)r;
         });
-        wv::sync();
-        int64_t cells = 1;
-        for (int a = 0; a < na; ++a) {
-            WV_LANE0 out.strides[a] = (int32_t)cells;
-            cells *= card(out.vars[a]);
-            if (cells >= (1ll << 31)) { if (!fiber_only) err = kEmitErrCells; return false; }
-        }
         WV_LANE0 { out.n = na; out.cells = (int32_t)cells; out.scope = scope; }
         // per-input strides along the output axes, and along the eliminated variables
         int32_t (*s)[kWAxes] = W.e.s;
-        wv::for_n(n_in * kWAxes, [&](int i) { s[i / kWAxes][i % kWAxes] = 0; });
-        wv::for_n(n_in * 3, [&](int i) { W.e.xs[i / 3][i % 3] = 0; });
+        wv::for_n(n_in * 32, [&](int i) { const int j = i >> 5, a = i & 31; if (a < na) s[j][a] = 0; else if (a < na + 3) W.e.xs[j][a - na] = 0; });
         wv::sync();
-        double in_cells = 0;
-        for (int j = 0; j < n_in; ++j) in_cells += (double)W.e.in[j].cells;
-        wv::for_n(n_in * kWAxes, [&](int i) {
-            const int j = i / kWAxes, k = i % kWAxes;
-            const WView &V = W.e.in[j];
-            if (k >= V.n) return;
-            const int v = V.vars[k];
-            if (nx > 0 && v == X[0]) W.e.xs[j][0] = V.strides[k];
-            else if (nx > 1 && v == X[1]) W.e.xs[j][1] = V.strides[k];
-            else if (nx > 2 && v == X[2]) W.e.xs[j][2] = V.strides[k];
-            else s[j][W.pos[v]] = V.strides[k];
+        int sh = 0;
+        while ((1 << sh) < maxn) ++sh;
+        wv::for_n(n_in << sh, [&](int i) {
+            const int j = i >> sh, k = i & ((1 << sh) - 1);
+            const int h = hl[j];
+            int v, st;
+            if (h < kWVars) {
+                const int q = (int)N.scope_off[h] + k;
+                if (q >= (int)N.scope_off[h + 1]) return;
+                v = N.scope_var[q];
+                if (!keep.test(v)) return;
+                st = N.scope_stride[q];
+            } else {
+                const WEnt &E = W.e.ent[h - kWVars];
+                if (k >= E.n) return;
+                v = E.vars[k];
+                st = E.strides[k];
+            }
+            if (nx > 0 && v == X[0]) W.e.xs[j][0] = st;
+            else if (nx > 1 && v == X[1]) W.e.xs[j][1] = st;
+            else if (nx > 2 && v == X[2]) W.e.xs[j][2] = st;
+            else s[j][W.pos[v]] = st;
         });
         wv::sync();
         const int c1 = nx > 0 ? card(X[0]) : 1;
@@ -1342,8 +1398,10 @@ struct WEmit {
         if (!fiber) {
             if (fiber_only) {
                 if (oalloc) arena_release(ooff, oalloc);
+                WV_COUNT(8 + nx);
                 return false;
             }
+            WV_COUNT(streaming ? 12 : 13);
             emit_generic(n_in, out, cells, cx, final_, w);
         }
         if (err) return false;
@@ -1357,7 +1415,7 @@ struct WEmit {
         n_steps += 1;
         tag_step((uint32_t)(w - data));
         for (int j = 0; j < n_in; ++j)
-            if (W.e.in[j].alloc) arena_release((int64_t)W.e.in[j].off, W.e.in[j].alloc);
+            if (falloc(hl[j])) arena_release((int64_t)foffset(hl[j]), falloc(hl[j]));
         return true;
     }
 
@@ -1436,15 +1494,28 @@ struct WEmit {
         for (uint64_t m = m0.b; m && go; m &= m - 1) go = f(64 + __builtin_ctzll(m));
         for (uint64_t m = mc; m && go; m &= m - 1) go = f(kWVars + (int)W.e.live[__builtin_ctzll(m)]);
     }
-    WV_HD void consume(int h) {
-        if (h < kWVars) { alive0.clr(h); return; }
-        const int e = h - kWVars;
-        const uint64_t at = wv::mask64(n_live, [&](int p) { return W.e.live[p] == e; });
-        if (!at) return;
-        const int p0 = __builtin_ctzll(at);
-        WV_LANE0 for (int p = p0; p + 1 < n_live; ++p) W.e.live[p] = W.e.live[p + 1];
-        --n_live;
-        consumed_ents |= 1u << e;
+    // the factors list[a..b) leave the alive sets: CPT slices by bit, created ones by ONE order-preserving compaction of the live list
+    // (their entries stay busy - consumed_ents - until the step in flight is complete)
+    WV_HD void consume_range(const uint8_t *list, int a, int b) {
+        uint32_t cons = 0;
+        for (int j = a; j < b; ++j) {
+            const int h = list[j];
+            if (h < kWVars) alive0.clr(h);
+            else cons |= 1u << (h - kWVars);
+        }
+        if (cons) remove_live(wv::mask64(n_live, [&](int p) { return ((cons >> W.e.live[p]) & 1) != 0; }));
+    }
+    WV_HD void remove_live(uint64_t rm) {  // rm: positions of the live list
+        if (!rm) return;
+        uint32_t cons = 0;
+        for (uint64_t m = rm; m; m &= m - 1) cons |= 1u << W.e.live[__builtin_ctzll(m)];
+        consumed_ents |= cons;
+        const int n = n_live;
+        uint8_t *live = W.e.live, *tmp = W.e.live_tmp;
+        wv::for_n(n, [&](int p) { tmp[p] = live[p]; });
+        wv::sync();
+        wv::for_n(n, [&](int p) { if (!((rm >> p) & 1)) live[p - __builtin_popcountll(rm & ((1ull << p) - 1))] = tmp[p]; });
+        n_live = n - __builtin_popcountll(rm);
         wv::sync();
     }
     WV_HD void add_factor(int e) {
@@ -1495,13 +1566,14 @@ struct WEmit {
     }
 
     // ---- the elimination loop and the final product (emit_run); the order is W.order[0..n_best) ---------------------------------
-    WV_HD int run(int nq, const int32_t *qvars, int64_t out_off, int n_best) {
+    WV_HD int run(int nq, const int32_t *qvars, int64_t out_off, int n_best WV_PROF_ARG) {
         if (nq > 127) return kEmitErrDevice;
-        wv::for_n(N.n_vars, [&](int v) { W.key[v] = 0; W.pos[v] = -1; });
+        wv::for_n(N.n_vars, [&](int v) { W.key[v] = 255; W.pos[v] = -1; });
         wv::sync();
-        wv::for_n(n_best, [&](int i) { W.key[W.order[i]] = (uint8_t)i; });
-        wv::sync();
-        wv::for_n(nq, [&](int i) { W.key[qvars[i]] = (uint8_t)(128 + i); });
+        wv::for_n(n_best, [&](int i) { W.key[W.order[i]] = (uint8_t)i; W.pvar[i] = W.order[i]; });
+        wv::for_n(nq, [&](int i) { W.key[qvars[i]] = (uint8_t)(n_best + i); W.pvar[n_best + i] = (uint8_t)qvars[i]; });
+        npos = n_best + nq;
+        if (npos > kWVars) return kEmitErrDevice;
         wv::sync();
         uint32_t *count_word = extend(1);
         WV_LANE0 count_word[0] = 0;
@@ -1516,12 +1588,21 @@ struct WEmit {
             ent_busy &= ~consumed_ents;  // the previous step's inputs are gone
             consumed_ents = 0;
             const int x = best[i];
-            // pop every factor mentioning x (bayes_net.py:780-784)
+            // pop every factor mentioning x (bayes_net.py:780-784): the CPT slices by variable, then the created ones in creation order
             int n_in = 0;
-            each_with(x, -1, [&](int h) { if (n_in < kWIns) { WV_LANE0 hl[n_in] = (uint8_t)h; } ++n_in; return true; });
-            if (n_in > kWIns) return kEmitErrDevice;
-            wv::sync();
-            for (int j = 0; j < n_in; ++j) consume(hl[j]);
+            {
+                const B2 m0 = b2_and(N.fam[x], alive0);
+                alive0 = b2_andn(alive0, m0);
+                const uint64_t mc = wv::mask64(n_live, [&](int p) { return ((B2)W.e.ent[W.e.live[p]].scope).test(x); });
+                const int n0 = b2_count(m0);
+                n_in = n0 + __builtin_popcountll(mc);
+                if (n_in > kWIns) return kEmitErrDevice;
+                WV_LANE0 { int k = 0; b2_each(m0, [&](int v) { hl[k++] = (uint8_t)v; }); }
+                wv::for_n(n_live, [&](int p) { if ((mc >> p) & 1) hl[n0 + __builtin_popcountll(mc & ((1ull << p) - 1))] = (uint8_t)(kWVars + W.e.live[p]); });
+                wv::sync();
+                remove_live(mc);
+            }
+            WV_TICK(5)  // factors of x
             // the one big input of the step, if there is exactly one
             int nbig = 0, bigh = -1;
             for (int j = 0; j < n_in; ++j)
@@ -1565,7 +1646,7 @@ struct WEmit {
                     if (eo < 0) return false;
                     ++n_pool;
                     if (emit_sweep(hs, sweep_n[k - 1], best + i, k, eo)) {
-                        for (int j = n_in; j < sweep_n[k - 1]; ++j) consume(hs[j]);
+                        consume_range(hs, n_in, sweep_n[k - 1]);
                         add_factor(eo);
                         i += k - 1;
                         return true;
@@ -1576,7 +1657,9 @@ struct WEmit {
                 }
                 return false;
             };
-            if (sweep_max >= 4 && try_sweep(5, 4)) continue;
+            WV_TICK(6)  // sweep candidates
+            if (sweep_max >= 4 && try_sweep(5, 4)) { WV_TICK(7) continue; }
+            WV_TICK(7)  // SWEEP 5 / 4
             if (err) return err;
             // CHAIN: three consecutive 4-state variables of one big table in a single pass
             if (N.fuse && N.chain && i + 2 < n_best && n_in < kMaxIn && n_pool + 1 <= pool_cap && card(x) == 4 && card(best[i + 1]) == 4 &&
@@ -1605,9 +1688,10 @@ struct WEmit {
                             if (eo < 0) return err;
                             ++n_pool;
                             if (emit(hl, n3, X, 3, false, 0, eo, true)) {
-                                for (int j = n_in; j < n3; ++j) consume(hl[j]);
+                                consume_range(hl, n_in, n3);
                                 add_factor(eo);
                                 i += 2;
+                                WV_TICK(8)
                                 continue;
                             }
                             --n_pool;
@@ -1617,9 +1701,11 @@ struct WEmit {
                     }
                 }
             }
-            if (sweep_max >= 3 && try_sweep(3, 3)) continue;
+            WV_TICK(8)  // CHAIN
+            if (sweep_max >= 3 && try_sweep(3, 3)) { WV_TICK(9) continue; }
             if (err) return err;
-            if (N.sweep_min <= 2 && sweep_max >= 2 && try_sweep(2, 2)) continue;  // (a pair of one big table: before the FIBER pair form)
+            if (N.sweep_min <= 2 && sweep_max >= 2 && try_sweep(2, 2)) { WV_TICK(9) continue; }  // (a pair of one big table: before the FIBER pair form)
+            WV_TICK(9)  // SWEEP 3 / 2
             if (err) return err;
             // joint elimination of two variables in one FIBER pass
             if (N.fuse && i + 1 < n_best && n_in < kMaxIn && n_pool + 1 <= pool_cap) {
@@ -1650,9 +1736,10 @@ struct WEmit {
                         if (eo < 0) return err;
                         ++n_pool;
                         if (emit(hl, n2, X, 2, false, 0, eo, true)) {
-                            for (int j = n_in; j < n2; ++j) consume(hl[j]);
+                            consume_range(hl, n_in, n2);
                             add_factor(eo);
                             ++i;
+                            WV_TICK(10)
                             continue;
                         }
                         --n_pool;
@@ -1661,9 +1748,11 @@ struct WEmit {
                     }
                 }
             }
+            WV_TICK(10)  // pair
             const int out = emit_limited(n_in, x, false, 0);  // pointwise_mul + sum_out (785)
             if (err) return err;
             add_factor(out);
+            WV_TICK(11)  // single elimination
         }
         if (err) return err;
         ent_busy &= ~consumed_ents;
@@ -1682,6 +1771,7 @@ struct WEmit {
         WV_LANE0 count_word[0] = (uint32_t)(n_steps - steps0);
         arena_cells = emit_max(arena_cells, top);
         flush_segment();
+        WV_TICK(12)  // final product
         if (err) return err;
         return 0;
     }
@@ -1690,9 +1780,9 @@ struct WEmit {
 // One request, start to finish: order search, then emission into `slot` (cap words).  `anc` = the network's ancestor sets (global
 // memory: read once per query / evidence variable).  Fills R; the work items are in W.e.tags[0..R.n_tags).
 WV_HD void wave_plan_request(const WNet &N, WState &W, const B2 *anc, int nq, const int32_t *qvars, int ne, const int32_t *evars,
-                             const int32_t *ecodes, bool no_prune, int64_t out_off, uint32_t *slot, uint32_t cap, WResult &R) {
+                             const int32_t *ecodes, bool no_prune, int64_t out_off, uint32_t *slot, uint32_t cap, WResult &R WV_PROF_ARG) {
     WOrderCtx oc(N, W);
-    const int n_best = oc.search(nq, qvars, ne, evars, anc, no_prune);
+    const int n_best = oc.search(nq, qvars, ne, evars, anc, no_prune WV_PROF_PASS);
     R.words = 1; R.n_tags = 0; R.err = 0;
     R.alg_bytes = R.alg_flops = R.n_steps = R.max_step_cells = 0;
     R.arena_cells = 0;
@@ -1702,7 +1792,8 @@ WV_HD void wave_plan_request(const WNet &N, WState &W, const B2 *anc, int nq, co
     // (hidden as emit_begin has it: the multi-state variables only - single-state ones are never axes, never eliminated)
     WEmit em(N, W, slot, cap);
     int err = em.begin(ne, evars, ecodes, oc.rel, oc.hidden, oc.keep, eb);
-    if (!err) err = em.run(nq, qvars, out_off, n_best);
+    WV_TICK(4)  // CPT slices
+    if (!err) err = em.run(nq, qvars, out_off, n_best WV_PROF_PASS);
     R.err = err;
     R.words = em.size;
     R.n_tags = (uint32_t)em.n_tags;

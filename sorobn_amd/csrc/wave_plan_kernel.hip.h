@@ -37,12 +37,19 @@ struct WavePlanArgs {
     uint32_t tag_cap;
 };
 constexpr int kWaveWG = 4;  // waves (requests) per workgroup
-constexpr int kWaveMaxQ = 16, kWaveMaxE = 64;  // query / evidence variables of a request (more: the host plans the chunk)
+constexpr int kWaveMaxQ = 8, kWaveMaxE = 32;  // query / evidence variables of a request (more: the host plans the chunk)
 struct WaveReq { int32_t q[kWaveMaxQ], e[kWaveMaxE], c[kWaveMaxE]; };
+
+#if defined(MIBN_WAVE_PROF)
+__device__ unsigned long long g_wave_prof[24];  // ticks per phase, summed over the waves (WV_TICK in wave_plan.h)
+#endif
 
 __global__ void reset_cursor_kernel(uint32_t *cursor) { *cursor = 0; }
 
-__global__ __launch_bounds__(64 * kWaveWG) void wave_plan_kernel(const WavePlanArgs A) {
+#ifndef MIBN_WAVE_MIN_WGS
+#define MIBN_WAVE_MIN_WGS 3  // workgroups per CU the register budget allows (3: 168 VGPRs; LDS: 51 KB per workgroup)
+#endif
+__global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_kernel(const WavePlanArgs A) {
     __shared__ WNet N;
     __shared__ WState W[kWaveWG];
     __shared__ WaveReq RQ[kWaveWG];
@@ -79,7 +86,15 @@ __global__ __launch_bounds__(64 * kWaveWG) void wave_plan_kernel(const WavePlanA
     wv::sync();
     WState &S = W[wave];
     WResult R;
+#if defined(MIBN_WAVE_PROF)
+    WProf prof_;
+    for (int k = 0; k < 24; ++k) prof_.a[k] = 0;
+    prof_.t = __builtin_amdgcn_s_memtime();
+    wave_plan_request(N, S, A.anc, nq, rq.q, ne, rq.e, rq.c, (A.flags & MIBN_Q_NOPRUNE) != 0, A.out_off[b], slot, A.prog_stride, R, prof_);
+    if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_wave_prof[k], prof_.a[k]);
+#else
     wave_plan_request(N, S, A.anc, nq, rq.q, ne, rq.e, rq.c, (A.flags & MIBN_Q_NOPRUNE) != 0, A.out_off[b], slot, A.prog_stride, R);
+#endif
     int err = R.err;
     if (!err) {
         uint32_t first = 0;

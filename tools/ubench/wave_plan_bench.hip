@@ -95,6 +95,18 @@ int main(int argc, char **argv) {
         fflush(stdout);
         best_ms = std::min(best_ms, ms);
     }
+#if defined(MIBN_WAVE_PROF)
+    {
+        unsigned long long hp[24];
+        CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_wave_prof), sizeof(hp)));
+        static const char *names[13] = {"relevant set, candidate sweeps", "byte model of the sweeps", "min-fill search", "byte model of the min-fill order", "CPT slices",
+                                        "factors of x", "sweep candidates", "SWEEP 5 / 4", "CHAIN", "SWEEP 3 / 2", "pair", "single elimination", "final product"};
+        double tot = 0;
+        for (int k = 0; k < 13; ++k) tot += (double)hp[k];
+        for (int k = 0; k < 13; ++k) printf("  phase %-34s %8.0f clocks per request  %5.1f %%\n", names[k], (double)hp[k] / (4.0 * B), 100.0 * (double)hp[k] / tot);
+        printf("  all phases: %.0f clocks per request (s_memtime, four launches)\n", tot / (4.0 * B));
+    }
+#endif
     // against the host planner, word for word
     std::vector<EmitMeta> meta(B);
     CHECK(hipMemcpy(meta.data(), d_meta, B * sizeof(EmitMeta), hipMemcpyDeviceToHost));

@@ -99,6 +99,15 @@ int main(int argc, char **argv) {
         }
     }
     std::printf("most work items of a request %zu\n", max_tags);
+#if defined(MIBN_WAVE_COUNT)
+    {
+        const long *c = g_wave_count;
+        const double n = (double)B;
+        std::printf("per request: emit() calls nx=0 %.2f  nx=1 %.2f  nx=2 (pair attempts) %.2f  nx=3 (CHAIN attempts) %.2f; failed pair %.2f failed CHAIN %.2f; GENERIC of a streaming-size step %.2f, of a small step %.2f\n",
+                    c[0] / n, c[2] / n, c[5] / n, c[7] / n, c[10] / n, c[11] / n, c[12] / n, c[13] / n);
+        std::printf("             SWEEP attempts k=2..5: %.2f %.2f %.2f %.2f   emitted: %.2f %.2f %.2f %.2f\n", c[16] / n, c[17] / n, c[18] / n, c[19] / n, c[22] / n, c[23] / n, c[24] / n, c[25] / n);
+    }
+#endif
     std::printf("%lld requests, %d evidence nodes: %lld requests differ (order / program / statistics / work items; mean %.1f hidden variables)\n", (long long)B, NE, (long long)bad, (double)n_hidden / B);
     return bad != 0;
 }
