@@ -295,6 +295,7 @@ struct mibn_ctx {
     uint32_t emit_words = 6144;      // words of a request's program slot (doubles after a chunk that did not fit)
     // wave-cooperative device planner (wave_plan_kernel)
     int wave_plan = 1;               // option: 1 = chunks the device plans go through wave_plan_kernel where the network is covered (wave_plan.h)
+    int wave_wgs = 0;                // option: workgroups of a wave_plan_kernel launch (0: one per four requests - the whole chip at once)
     WNet *wnet_host = nullptr;       // the packed network + options as uploaded last
     WNet *d_wnet = nullptr;
     bool wnet_ok = false;
@@ -573,6 +574,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "tiny_zero_copy") h->tiny_zero_copy = value != 0;
     else if (n == "mfma_kernel") h->mfma_kernel = value != 0;
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
+    else if (n == "wave_wgs") h->wave_wgs = std::max(0, (int)value);
     else if (n == "wave_plan") h->wave_plan = value != 0;  // 0: the device plans with order_kernel + emit_kernel (one request per lane)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
     else if (n == "plan_sort") h->plan_sort = (int)value;
@@ -878,6 +880,10 @@ int pinned(mibn_ctx *h, mibn_ctx::Staging &sg, size_t bytes) {
 // (258 / 254 k at 24 / 32 lanes and four threads, 263 / 269 k at six; profiles/r05_f_planlanes.log, r05_g_planlanes.log).
 // (Calls of 32 768 requests - such a rank's shard of a 2^18-request step on eight GPUs - are bound by the kernels again, whatever the lanes:
 //  250.3 / 251.5 k at 24 / 32 lanes and two threads, 240 / 250 k at one: 32 there.  profiles/r05_k_calls32k.log)
+// chunks the device plans go through wave_plan_kernel (its time grows with the requests it is given - order_kernel / emit_kernel are
+// latency-bound: theirs hardly does): the host's share of a chunk may shrink to a hundredth
+static bool wave_mode(const mibn_ctx *h) { return h->wave_plan && h->wnet_ok; }
+
 static int plan_lanes_now(const mibn_ctx *h) {
     if (h->plan_lanes > 0) return h->plan_lanes;
     return h->pool && h->pool->size() <= 2 && h->chunk > 32768 ? 24 : 32;
@@ -1084,7 +1090,11 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         A.tag_cursor = h->d_emit_cursor;
         A.tag_cap = (uint32_t)tag_cap;
         hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, P, h->d_emit_cursor);
-        hipLaunchKernelGGL(wave_plan_kernel, dim3((unsigned)((n + kWaveWG - 1) / kWaveWG)), dim3(64 * kWaveWG), 0, P, A);
+        {
+            int64_t grid = (n + kWaveWG - 1) / kWaveWG;
+            if (h->wave_wgs > 0) grid = std::min<int64_t>(grid, h->wave_wgs);
+            hipLaunchKernelGGL(wave_plan_kernel, dim3((unsigned)grid), dim3(64 * kWaveWG), 0, P, A);
+        }
         HIP_TRY(h, hipGetLastError());
     }
     for (int64_t s0 = 0; !wave && s0 < n; s0 += kPlanSlice) {
@@ -1532,7 +1542,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
         int64_t nd = 0;          // requests [b0, b0 + nd) planned by the device, the rest by the host's workers meanwhile
         size_t prog_base = 0;    // words of st.d_prog the device has written (the host's programs follow)
         if (emit_on) {
-            nd = h->gpu_emit == 2 ? n : std::min<int64_t>(n, std::max<int64_t>(64, (int64_t)((double)n * std::min(h->emit_share, h->emit_share_opt > 0 ? 1.0 : 0.95) + 0.5)));
+            nd = h->gpu_emit == 2 ? n : std::min<int64_t>(n, std::max<int64_t>(64, (int64_t)((double)n * std::min(h->emit_share, h->emit_share_opt > 0 ? 1.0 : (wave_mode(h) ? 0.99 : 0.95)) + 0.5)));
             if (n - nd < 256) nd = n;  // (without a pinned share the host keeps at least a twentieth: its rate stays measured)
             const size_t stride = h->emit_words;
             if ((rc = plan_on_device_launch(h, flags, b0, b0 + nd, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), st, (size_t)n * stride))) return bail(rc);

@@ -61,62 +61,63 @@ __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_ker
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
-    const int64_t b = (int64_t)blockIdx.x * kWaveWG + wave;
-    if (b >= A.B) return;
-    EmitMeta m;
-    m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
-    m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
-    m.arena_cells = 0;
-    uint32_t *slot = A.prog + (size_t)b * A.prog_stride;
-    if (A.skip[b]) {
-        if (lane == 0) { slot[0] = 0; A.meta[b] = m; }
-        return;
-    }
-    const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
-    const int nq = (int)(A.q_off[b + 1] - q0), ne = (int)(A.e_off[b + 1] - e0);
-    if (nq > kWaveMaxQ || ne > kWaveMaxE) {
-        m.err = kEmitErrDevice;
-        if (lane == 0) A.meta[b] = m;
-        return;
-    }
-    // the request's variables: read once (the arrays are in pinned host memory), kept in LDS
-    WaveReq &rq = RQ[wave];
-    if (lane < nq) rq.q[lane] = A.q_vars[q0 + lane];
-    if (lane < ne) { rq.e[lane] = A.e_vars[e0 + lane]; rq.c[lane] = A.e_codes[e0 + lane]; }
-    wv::sync();
-    WState &S = W[wave];
-    WResult R;
-#if defined(MIBN_WAVE_PROF)
-    WProf prof_;
-    for (int k = 0; k < 24; ++k) prof_.a[k] = 0;
-    prof_.t = __builtin_amdgcn_s_memtime();
-    wave_plan_request(N, S, A.anc, nq, rq.q, ne, rq.e, rq.c, (A.flags & MIBN_Q_NOPRUNE) != 0, A.out_off[b], slot, A.prog_stride, R, prof_);
-    if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_wave_prof[k], prof_.a[k]);
-#else
-    wave_plan_request(N, S, A.anc, nq, rq.q, ne, rq.e, rq.c, (A.flags & MIBN_Q_NOPRUNE) != 0, A.out_off[b], slot, A.prog_stride, R);
-#endif
-    int err = R.err;
-    if (!err) {
-        uint32_t first = 0;
-        if (lane == 0) first = atomicAdd(A.tag_cursor, R.n_tags);
-        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-        if (first + R.n_tags <= A.tag_cap) {
-            // (the lanes copy the items a dword each)
-            static_assert(sizeof(Tag) % 4 == 0, "work items are copied dword by dword");
-            constexpr uint32_t kTagWords = sizeof(Tag) / 4;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(S.e.tags);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(A.tags + first);
-            for (uint32_t i = (uint32_t)lane; i < R.n_tags * kTagWords; i += 64) dst[i] = src[i];
-            m.n_tags = R.n_tags;
-            m.tag_first = first;
-        } else {
-            err = kEmitErrWords;
+    // (a grid smaller than the chunk - option wave_wgs - walks it: the workgroup keeps its copy of the network, the launch its footprint)
+    for (int64_t b = (int64_t)blockIdx.x * kWaveWG + wave; b < A.B; b += (int64_t)gridDim.x * kWaveWG) {
+        EmitMeta m;
+        m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
+        m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
+        m.arena_cells = 0;
+        uint32_t *slot = A.prog + (size_t)b * A.prog_stride;
+        if (A.skip[b]) {
+            if (lane == 0) { slot[0] = 0; A.meta[b] = m; }
+            continue;
         }
+        const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
+        const int nq = (int)(A.q_off[b + 1] - q0), ne = (int)(A.e_off[b + 1] - e0);
+        if (nq > kWaveMaxQ || ne > kWaveMaxE) {
+            m.err = kEmitErrDevice;
+            if (lane == 0) A.meta[b] = m;
+            continue;
+        }
+        // the request's variables: read once (the arrays are in pinned host memory), kept in LDS
+        WaveReq &rq = RQ[wave];
+        if (lane < nq) rq.q[lane] = A.q_vars[q0 + lane];
+        if (lane < ne) { rq.e[lane] = A.e_vars[e0 + lane]; rq.c[lane] = A.e_codes[e0 + lane]; }
+        wv::sync();
+        WState &S = W[wave];
+        WResult R;
+    #if defined(MIBN_WAVE_PROF)
+        WProf prof_;
+        for (int k = 0; k < 24; ++k) prof_.a[k] = 0;
+        prof_.t = __builtin_amdgcn_s_memtime();
+        wave_plan_request(N, S, A.anc, nq, rq.q, ne, rq.e, rq.c, (A.flags & MIBN_Q_NOPRUNE) != 0, A.out_off[b], slot, A.prog_stride, R, prof_);
+        if (lane == 0) for (int k = 0; k < 24; ++k) atomicAdd(&g_wave_prof[k], prof_.a[k]);
+    #else
+        wave_plan_request(N, S, A.anc, nq, rq.q, ne, rq.e, rq.c, (A.flags & MIBN_Q_NOPRUNE) != 0, A.out_off[b], slot, A.prog_stride, R);
+    #endif
+        int err = R.err;
+        if (!err) {
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(A.tag_cursor, R.n_tags);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            if (first + R.n_tags <= A.tag_cap) {
+                // (the lanes copy the items a dword each)
+                static_assert(sizeof(Tag) % 4 == 0, "work items are copied dword by dword");
+                constexpr uint32_t kTagWords = sizeof(Tag) / 4;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(S.e.tags);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(A.tags + first);
+                for (uint32_t i = (uint32_t)lane; i < R.n_tags * kTagWords; i += 64) dst[i] = src[i];
+                m.n_tags = R.n_tags;
+                m.tag_first = first;
+            } else {
+                err = kEmitErrWords;
+            }
+        }
+        m.err = err;
+        m.words = R.words;
+        m.alg_bytes = R.alg_bytes; m.alg_flops = R.alg_flops; m.n_steps = R.n_steps; m.max_step_cells = R.max_step_cells;
+        m.arena_cells = R.arena_cells;
+        if (lane == 0) A.meta[b] = m;
     }
-    m.err = err;
-    m.words = R.words;
-    m.alg_bytes = R.alg_bytes; m.alg_flops = R.alg_flops; m.n_steps = R.n_steps; m.max_step_cells = R.max_step_cells;
-    m.arena_cells = R.arena_cells;
-    if (lane == 0) A.meta[b] = m;
 }
 
