@@ -447,10 +447,13 @@ struct WEmit {
     WV_HD int card(int v) const { return (int)N.card[v]; }
 
     // ---- factors ------------------------------------------------------------------------------------------------------------
+    // (measured and not kept, profiles/r06_l_uni.log: wv::uni on the handles and on what the accessors return - scalar registers, scalar
+    //  branches - costs more in spilled scalar registers than it saves in vector instructions: 14.5 against 13.6 ms per chunk)
     WV_HD int64_t fcells(int h) const { return h < kWVars ? (int64_t)W.cpt_cells[h] : (int64_t)W.e.ent[h - kWVars].cells; }
     WV_HD B2 fscope(int h) const { return h < kWVars ? b2_and(N.scope[h], keep) : (B2)W.e.ent[h - kWVars].scope; }
     WV_HD int64_t falloc(int h) const { return h < kWVars ? 0 : (int64_t)W.e.ent[h - kWVars].cells; }
     WV_HD uint64_t foffset(int h) const { return h < kWVars ? ((uint64_t)W.cpt_off[h] | kConstFlag) : (uint64_t)W.e.ent[h - kWVars].off; }
+    WV_HD uint64_t foffset_v(int h) const { return foffset(h); }
     // stride of variable v in factor h (0: not an axis)
     WV_HD int64_t fstride_of(int h, int v) const {
         int64_t st = 0;
@@ -624,7 +627,7 @@ struct WEmit {
         wv::for_n(n_in * 32, [&](int i) {  // lane (j, a): the three words of input j (a < 3), the merged cardinalities (j = 0), its merged strides
             const int j = i >> 5, a = i & 31;
             if (a < 3) {
-                const uint64_t off = foffset(hl[j]);
+                const uint64_t off = foffset_v(hl[j]);
                 p[3 * j + a] = a == 0 ? (uint32_t)(off & 0xffffffffu) : (a == 1 ? (uint32_t)(off >> 32) : (uint32_t)W.e.xs[j][0]);
             }
             if (a < ma) {
@@ -1329,13 +1332,15 @@ struct WEmit {
         B2 scope;
         double in_cells = 0;
         int maxn = 1;
+        int64_t in_sum = 0;  // (cell counts: integers - summed exactly, converted once)
         for (int j = 0; j < n_in; ++j) {
             const int h = hl[j];
             scope = b2_or(scope, fscope(h));
-            in_cells += (double)fcells(h);
-            const int rn = h < kWVars ? (int)N.scope_off[h + 1] - (int)N.scope_off[h] : W.e.ent[h - kWVars].n;
+            in_sum += fcells(h);
+            const int rn = h < kWVars ? (int)N.scope_off[h + 1] - (int)N.scope_off[h] : (int)W.e.ent[h - kWVars].n;
             maxn = rn > maxn ? rn : maxn;
         }
+        in_cells = (double)in_sum;
         for (int k = 0; k < nx; ++k) scope.clr(X[k]);
         const int na = b2_count(scope);
         if (na > kWAxes) { err = kEmitErrDevice; return false; }

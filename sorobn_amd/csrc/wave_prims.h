@@ -36,6 +36,8 @@ __device__ inline uint64_t uni(uint64_t v) {
            ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
 }
 __device__ inline bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ inline int64_t uni(int64_t v) { return (int64_t)uni((uint64_t)v); }
+__device__ inline B2 uni(const B2 &s) { B2 r; r.a = uni(s.a); r.b = uni(s.b); return r; }
 
 template <class F> __device__ inline void for_n(int n, F f) {
     for (int i = lane(); i < n; i += kWidth) f(i);
