@@ -904,7 +904,7 @@ def main():
                     for kv in a.opt:
                         k, v = kv.split("=")
                         eng2.set_option(k, float(v))
-                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=24, warmup_calls=16, batch=32768)  # (a fresh engine: its buffers, the share controller)
+                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=32, warmup_calls=40, batch=32768)  # (forty warm-up calls: the share controller and the pinned buffers of a fresh engine settle over the first twenty - r06_o / r06_q)  # (a fresh engine: its buffers, the share controller)
                     eng2.close()
                 except Exception as e:  # noqa: BLE001
                     out["configs"][name] = {"error": repr(e)}

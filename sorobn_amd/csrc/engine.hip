@@ -254,6 +254,8 @@ struct mibn_ctx {
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
     double retired_requests = 0, seen_requests = 0;  // requests whose kernel time has been booked (the unit of kernel_ms in the policy's windows)
     double host_rate = 0;                            // requests per ms the host's workers planned beside the device planner (smoothed; 0: not measured)
+    double kernel_ms_per_req = 0;                    // retired kernel time per request over the policy's last windows (smoothed; 0: not measured)
+    double fixed_ms_per_req = 0;                     // the host's side of a call besides planning - validation, schedule - per request (smoothed)
     // device order search (order_kernel)
     int plan_lanes = 0;              // requests per wave of order_kernel / emit_kernel (1..64); 0 = by the rank's planning threads: plan_lanes_now()
     int plan_waves = 16;             // waves per workgroup of the two (1..16): see order_kernel
@@ -1395,6 +1397,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
     }
     ensure_pool(h);
     if (h->trace) std::fprintf(stderr, "[mibn plan] validation of %lld requests %.2f ms\n", (long long)B, now_ms() - t_start);
+    double call_fixed_ms = now_ms() - t_start;  // the host's side of this call besides planning (the share rule of wave_plan_kernel)
     if (h->adaptive && !h->adaptive_seeded) {
         // A rank with a handful of planning threads (8 ranks on a 16-CPU quota: 2-4 each) cannot plan a stream like C3 at the rate
         // its GPU executes it (67 / 133 k queries/s at 2 / 4 threads against 280 k): it starts with the device planner instead of
@@ -1415,6 +1418,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
             //  call saw "100 ms of planning, 136 ms of kernels" as often as "100 against 68" on a steadily host-bound stream - n_evidence
             //  = 16 in round 5's session D: the two host-bound windows in a row the switch asks for came once in twelve calls)
             const double dreq = h->retired_requests - h->seen_requests;
+            if (dreq > 0) h->kernel_ms_per_req = h->kernel_ms_per_req > 0 ? 0.5 * h->kernel_ms_per_req + 0.5 * dk / dreq : dk / dreq;
             // The device planner goes again where the host ALONE would keep up: the requests its workers plan per ms (measured
             // beside the device planner) x the kernel time per request must cover a request with a margin - the margin also
             // absorbs that the kernels of device-planned chunks run ~ 17 % longer than they would without the planner's kernels.
@@ -1618,8 +1622,25 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 //  fired and the device planner stayed on at three quarters of every chunk: 430 instead of 550 k queries/s, session N)
                 if (host_ms > 0.02) h->host_rate = h->host_rate > 0 ? 0.5 * h->host_rate + 0.5 * (double)(n - nd) / host_ms : (double)(n - nd) / host_ms;
                 if (h->emit_share_opt <= 0 && host_ms > 0.02 && dev_ms > 1.0 && 4 * n >= 3 * h->chunk) {
-                    const double host_n = (double)(n - nd) / host_ms * dev_ms;
-                    h->emit_share = std::max(0.25, std::min(1.0, 0.5 * h->emit_share + 0.5 * (1.0 - host_n / (double)n)));
+                    if (wave_mode(h) && h->kernel_ms_per_req > 0) {
+                        // wave_plan_kernel's time grows with the requests it is given, and it is GPU time taken from the VE kernels: the
+                        // device gets what the host cannot plan while the GPU works through the chunk -
+                        //   fixed + (n - nd) ih  <=  0.85 (kv n + kp nd)     ih: ms per request of the host's workers, kv: kernel ms per
+                        // request (retired launches, the adaptive policy's windows), kp: planner ms per request (just measured, beside
+                        // the kernels), fixed: the host's side of a call besides planning (validation, the schedule).  (The planning
+                        // rates alone left a two-thread rank host-bound - 223 against 262 k queries/s; a feedback rule on the policy's
+                        // planner-wall / kernel-time ratio counted the waits for the device as host time and ended at a share of 0.99:
+                        // profiles/r06_r_ab.log, r06_s_ab.log)
+                        const double ih = host_ms / (double)(n - nd), kv = h->kernel_ms_per_req, kp = dev_ms / (double)nd;
+                        const double fixed = h->fixed_ms_per_req * (double)n;
+                        const double target = std::max(0.03, std::min(0.99, ((double)n * ih + fixed - 0.85 * kv * (double)n) / ((ih + 0.85 * kp) * (double)n)));
+                        h->emit_share = 0.5 * h->emit_share + 0.5 * target;
+                        if (h->trace) std::fprintf(stderr, "[mibn share] host %.4f ms/request (%lld in %.1f ms), kernels %.5f ms/request, planner %.5f ms/request, fixed %.1f ms -> target %.3f, share %.3f\n",
+                                                   ih, (long long)(n - nd), host_ms, kv, kp, fixed, target, h->emit_share);
+                    } else {
+                        const double host_n = (double)(n - nd) / host_ms * dev_ms;
+                        h->emit_share = std::max(0.25, std::min(1.0, 0.5 * h->emit_share + 0.5 * (1.0 - host_n / (double)n)));
+                    }
                 }
             }
         }
@@ -1689,6 +1710,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
             Schedule &sc = st.sched;
             build_schedule(h->net, ck, st.bufs, r0, r1, sc);
             h->stats.plan_ms += now_ms() - t0;
+            call_fixed_ms += now_ms() - t0;
             if (h->trace) std::fprintf(stderr, "[mibn plan] build_schedule %.2f ms (%zu items, %zu workgroups, %zu launches)\n", now_ms() - t0, sc.items.size(), sc.wg_item.size(), sc.launches.size());
             const size_t need_bytes = (size_t)std::max<int64_t>(16, sc.arena_cells) * sizeof(double);
             if (need_bytes > h->arena_bytes[lane]) {
@@ -1840,6 +1862,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
         HIP_TRY(h, hipEventRecord(h->lane_ev, h->stream2));
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->lane_ev, 0));
     }
+    if (B > 0) h->fixed_ms_per_req = h->fixed_ms_per_req > 0 ? 0.5 * h->fixed_ms_per_req + 0.5 * call_fixed_ms / (double)B : call_fixed_ms / (double)B;
     if (h->trace) std::fprintf(stderr, "[mibn plan] call of %lld requests: %.2f ms to the last launch (plan %.2f, h2d %.2f)\n", (long long)B, now_ms() - t_start, h->stats.plan_ms, h->stats.h2d_ms);
     if (ticket) {
         mibn_ctx::Pending &pd = h->pend[slot];

@@ -55,12 +55,12 @@ struct WProf { unsigned long long t, a[24]; };
 constexpr int kEmitErrDevice = 7;  // the request exceeds a device limit below: the host plans the chunk (like kEmitErrWords)
 constexpr int kWVars = 128;
 constexpr int kWHints = 4;
-constexpr int kWCsr = 512;     // scope entries of all CPTs together
+constexpr int kWCsr = 384;     // scope entries of all CPTs together
 constexpr int kWAxes = 24;     // axes of a factor / of a step before merging
 constexpr int kWEnt = 20;      // created factors alive at once (+ the inputs of the step in flight)
 constexpr int kWSims = 4;      // candidate orders simulated side by side
 constexpr int kWSimEnt = 24;   // factors alive at once in a simulation
-constexpr int kWTags = 64;     // work items of a request
+constexpr int kWTags = 56;     // work items of a request
 constexpr int kWBlocks = 32;   // free blocks of the arena (the host's list holds Arena::kMaxBlocks = 64: a request that would need more goes to the host)
 constexpr int kWIns = 160;     // factor handles of one product
 
@@ -90,12 +90,12 @@ struct WNet {
 };
 
 // ---- per-wave state -------------------------------------------------------------------------------------------------------
-struct WEnt {  // a created factor: dense, C-order over vars (strides kept: CHAIN / SWEEP choose their own axis order)
+struct WEnt {  // a created factor: dense, C-order over vars - every axis has 2^l states, axis a the stride 2^(l a) (dstride): whatever
+               // order a step form gives its output (emit: layout keys, CHAIN: its own, SWEEP: surviving digits first), it is dense in it
     int32_t cells, n;
     int64_t off;
     B2S scope;
     uint8_t vars[kWAxes];
-    int32_t strides[kWAxes];
 };
 struct WSim {  // one candidate order's byte-model state (a lane each): the created factors alive
     B2S scope[kWSimEnt];
@@ -112,8 +112,7 @@ struct WState {
     // the request
     uint8_t order[kWVars];   // the elimination order the search chose
     uint16_t ecode[kWVars];
-    uint8_t key[kWVars];     // position of a variable in the layout order: elimination position, query variables behind (255: none)
-    uint8_t pvar[kWVars];    // ... and back
+    uint8_t pvar[kWVars];    // layout position -> variable: the elimination order, the query variables behind it
     int8_t pos[kWVars];
     uint32_t cpt_cells[kWVars], cpt_off[kWVars];
     union {
@@ -132,7 +131,7 @@ struct WState {
             int64_t foff[kWBlocks], fsz[kWBlocks];
             uint8_t hl[kWIns], hs[kSweepMaxSmall + 4];  // handles: factors of the product in flight / of a SWEEP candidate
             int32_t s[kMaxIn][kWAxes], xs[kMaxIn][3];
-            int32_t t[20][kWAxes];         // the step forms' axis tables
+            int32_t t[18][kWAxes];         // the step forms' axis tables
             uint32_t nout[16], nB[16];
             WStage stg[5];                 // SWEEP: the stages of the candidate pass
             uint32_t hdr[kHdrWords];       // the header of the step in flight (flushed to the program when the step is complete)
@@ -409,7 +408,7 @@ static long g_wave_count[32];
 // of variable h (a view of the network tables: nothing is stored but its cells and its offset), 128 + e = created factor e.
 // ===========================================================================================================================
 // rows of WState::e.t
-enum { T_RCARD, T_ROST, T_RTST, T_RB0, T_RB1, T_MC, T_MO, T_MT, T_MB0, T_MB1, T_NAX, T_RAX, T_CTRL, T_MAP, T_A, T_B, T_C, T_D, T_E, T_F };
+enum { T_RCARD, T_ROST, T_RTST, T_RB0, T_RB1, T_MC, T_MO, T_MT, T_MB0, T_MB1, T_NAX, T_RAX, T_CTRL, T_MAP, T_A, T_B, T_C, T_F };
 
 struct WEmit {
     const WNet &N;
@@ -445,6 +444,7 @@ struct WEmit {
     }
 
     WV_HD int card(int v) const { return (int)N.card[v]; }
+    WV_HD int32_t dstride(int a) const { return (int32_t)(1u << (N.uniform_log2 * a)); }  // stride of axis a of a created factor
 
     // ---- factors ------------------------------------------------------------------------------------------------------------
     // (measured and not kept, profiles/r06_l_uni.log: wv::uni on the handles and on what the accessors return - scalar registers, scalar
@@ -463,7 +463,7 @@ struct WEmit {
         } else {
             const WEnt &E = W.e.ent[h - kWVars];
             for (int a = 0; a < E.n; ++a)
-                if (E.vars[a] == v) st = E.strides[a];
+                if (E.vars[a] == v) st = dstride(a);
         }
         return st;
     }
@@ -735,7 +735,7 @@ struct WEmit {
         wv::for_n(nr, [&](int i) {
             const int a = t[T_RAX][i];
             t[T_RCARD][i] = card(out.vars[a]);
-            t[T_ROST][i] = out.strides[a];
+            t[T_ROST][i] = dstride(a);
             t[T_RB0][i] = s[big0][a];
             t[T_RB1][i] = nb > 1 ? s[big1][a] : 0;
             t[T_RTST][i] = 0;
@@ -780,7 +780,7 @@ struct WEmit {
             int64_t r = n, off = 0;
             for (int i = 0; i < nN; ++i) {
                 const int a = t[T_NAX][i], c = card(out.vars[a]);
-                off += (r % c) * out.strides[a];
+                off += (r % c) * dstride(a);
                 r /= c;
             }
             W.e.nout[n] = (uint32_t)off;
@@ -836,7 +836,7 @@ struct WEmit {
         if (__builtin_popcountll(fm) < 2) return r;
         r.nax0 = __builtin_ctzll(fm);
         r.nax1 = __builtin_ctzll(fm & (fm - 1));
-        r.key = (int64_t)out.strides[r.nax0] + out.strides[r.nax1];
+        r.key = (int64_t)dstride(r.nax0) + dstride(r.nax1);
         if (r.key >= best_key) return r;
         // R axes: everything but the two N axes; ctrl axes = R axes a small input depends on
         const int nr = na - 2;
@@ -844,7 +844,7 @@ struct WEmit {
             const int ax = i + (i >= r.nax0) + (i + (i >= r.nax0) >= r.nax1);
             t[T_RAX][i] = ax;
             t[T_RCARD][i] = card(out.vars[ax]);
-            t[T_ROST][i] = out.strides[ax];
+            t[T_ROST][i] = dstride(ax);
             t[T_RB0][i] = s[a_][ax];
             t[T_RB1][i] = s[b][ax];
             t[T_RTST][i] = 0;
@@ -907,7 +907,7 @@ struct WEmit {
         const int nr = r.nr, nlo = r.nlo, nctrl = r.nctrl;
         if (r.rcells * 16 < N.big_iters) return false;
         wv::for_n(16, [&](int n) {
-            W.e.nout[n] = (uint32_t)((n & 3) * out.strides[r.nax0] + (n >> 2) * out.strides[r.nax1]);
+            W.e.nout[n] = (uint32_t)((n & 3) * dstride(r.nax0) + (n >> 2) * dstride(r.nax1));
             W.e.nB[n] = (uint32_t)((n & 3) * s[B][r.nax0] + (n >> 2) * s[B][r.nax1]);
         });
         wv::sync();
@@ -1086,7 +1086,7 @@ struct WEmit {
         const int words = kHdrWords + 8 + n12 * (4 + nT) + nT + 16 + 2 + nd3 + n3s * (2 + nd3) + 3 * ma + 2 * ma;
         if (words > kMaxStepWords) return false;
         // commit the axis order of the output
-        wv::for_n(na, [&](int a) { out.vars[a] = (uint8_t)vars2[a]; out.strides[a] = ostr[a]; });
+        wv::for_n(na, [&](int a) { out.vars[a] = (uint8_t)vars2[a]; });  // (ostr[a] = 2^(l a): dense in the new order too)
         wv::sync();
         uint32_t *w = extend(words);
         wout = w;
@@ -1175,7 +1175,7 @@ struct WEmit {
             for (int a = 0; a < F.n; ++a)
                 if (F.vars[a] == xj) {
                     for (int q = 0; q < k; ++q)
-                        if ((int64_t)F.strides[a] == Rcells << (2 * q)) d = q;
+                        if ((int64_t)dstride(a) == Rcells << (2 * q)) d = q;
                 }
             if (d < 0 || var_on(d) >= 0) return false;
             digs |= (uint32_t)d << (4 * j);
@@ -1223,8 +1223,8 @@ struct WEmit {
                 if (src < 0) {
                     // an R axis of F: four states, power-of-two stride
                     for (int a = 0; a < F.n; ++a)
-                        if (F.vars[a] == v && (int64_t)F.strides[a] < Rcells) {
-                            const int64_t st_ = F.strides[a];
+                        if (F.vars[a] == v && (int64_t)dstride(a) < Rcells) {
+                            const int64_t st_ = dstride(a);
                             if (card(v) == 4 && (st_ & (st_ - 1)) == 0) src = 8 + __builtin_ctzll((unsigned long long)st_);
                         }
                 }
@@ -1261,19 +1261,20 @@ struct WEmit {
             if (var_on(d) >= 0) { survs |= (uint32_t)d << (4 * kout); ++kout; }
         const int64_t out_cells = Rcells << (2 * kout);
         if (out_cells >= (1ll << 31)) return false;
-        const int nR = wv::sum_n(F.n, [&](int a) { return (int64_t)F.strides[a] < Rcells ? 1 : 0; });
+        const int nR = wv::sum_n(F.n, [&](int a) { return (int64_t)dstride(a) < Rcells ? 1 : 0; });
         if (kout + nR > kWAxes) { err = kEmitErrDevice; return false; }
         WEnt &out = W.e.ent[eo];
         B2 oscope;
         for (int q = 0; q < kout; ++q) {
             const int v = var_on((int)((survs >> (4 * q)) & 0xf));
-            WV_LANE0 { out.vars[q] = (uint8_t)v; out.strides[q] = 1 << (2 * q); }
+            WV_LANE0 out.vars[q] = (uint8_t)v;  // (stride 4^q = dstride(q): SWEEP variables have four states, l = 2)
             oscope.set(v);
         }
-        wv::compact_n(F.n, kout, [&](int a) { return (int64_t)F.strides[a] < Rcells; },
-                      [&](int a, int pos) { out.vars[pos] = F.vars[a]; out.strides[pos] = (int32_t)((int64_t)F.strides[a] << (2 * kout)); });
+        // (F's R axes are its first ones - the eliminated variables are its slowest - so R axis a lands on position kout + a: its stride
+        //  F's 2^(l a) times 4^kout = dstride(kout + a))
+        wv::compact_n(F.n, kout, [&](int a) { return (int64_t)dstride(a) < Rcells; }, [&](int a, int pos) { out.vars[pos] = F.vars[a]; });
         for (int a = 0; a < F.n; ++a)
-            if ((int64_t)F.strides[a] < Rcells) oscope.set(F.vars[a]);
+            if ((int64_t)dstride(a) < Rcells) oscope.set(F.vars[a]);
         const int na = kout + nR;
         const int words = kHdrWords + 2 + k * kSweepStageWords + ns_total * kSweepSmallWords;
         if (words > kMaxStepWords) return false;
@@ -1355,7 +1356,6 @@ struct WEmit {
             const int r = b2_count(b2_and(ps, b2_above(p)));
             const int v = W.pvar[p];
             out.vars[r] = (uint8_t)v;
-            out.strides[r] = (int32_t)(1u << (l * r));
             W.pos[v] = (int8_t)r;
         });
         WV_LANE0 { out.n = na; out.cells = (int32_t)cells; out.scope = scope; }
@@ -1379,7 +1379,7 @@ struct WEmit {
                 const WEnt &E = W.e.ent[h - kWVars];
                 if (k >= E.n) return;
                 v = E.vars[k];
-                st = E.strides[k];
+                st = dstride(k);
             }
             if (nx > 0 && v == X[0]) W.e.xs[j][0] = st;
             else if (nx > 1 && v == X[1]) W.e.xs[j][1] = st;
@@ -1573,10 +1573,8 @@ struct WEmit {
     // ---- the elimination loop and the final product (emit_run); the order is W.order[0..n_best) ---------------------------------
     WV_HD int run(int nq, const int32_t *qvars, int64_t out_off, int n_best WV_PROF_ARG) {
         if (nq > 127) return kEmitErrDevice;
-        wv::for_n(N.n_vars, [&](int v) { W.key[v] = 255; W.pos[v] = -1; });
-        wv::sync();
-        wv::for_n(n_best, [&](int i) { W.key[W.order[i]] = (uint8_t)i; W.pvar[i] = W.order[i]; });
-        wv::for_n(nq, [&](int i) { W.key[qvars[i]] = (uint8_t)(n_best + i); W.pvar[n_best + i] = (uint8_t)qvars[i]; });
+        wv::for_n(n_best, [&](int i) { W.pvar[i] = W.order[i]; });
+        wv::for_n(nq, [&](int i) { W.pvar[n_best + i] = (uint8_t)qvars[i]; });
         npos = n_best + nq;
         if (npos > kWVars) return kEmitErrDevice;
         wv::sync();

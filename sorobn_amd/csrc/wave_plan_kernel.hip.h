@@ -47,7 +47,7 @@ __device__ unsigned long long g_wave_prof[24];  // ticks per phase, summed over 
 __global__ void reset_cursor_kernel(uint32_t *cursor) { *cursor = 0; }
 
 #ifndef MIBN_WAVE_MIN_WGS
-#define MIBN_WAVE_MIN_WGS 3  // workgroups per CU the register budget allows (3: 168 VGPRs; LDS: 51 KB per workgroup)
+#define MIBN_WAVE_MIN_WGS 4  // workgroups per CU the register budget allows (4: 128 VGPRs - 270 spilled, still the fastest: 11.0 ms per chunk against 13.8 at 3, profiles/r06_v_occupancy.log; LDS: 39.6 KB per workgroup)
 #endif
 __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_kernel(const WavePlanArgs A) {
     __shared__ WNet N;
