@@ -574,7 +574,8 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "gibbs_lds") h->gibbs_lds = std::max(0, std::min(2, (int)value));
     else if (n == "tiny") h->tiny = value != 0;
     else if (n == "tiny_zero_copy") h->tiny_zero_copy = value != 0;
-    else if (n == "mfma_kernel") h->mfma_kernel = value != 0;
+    else if (n == "mfma_kernel") h->mfma_kernel = value != 0;  // (round 6 measured CHAIN and OUTER in ve_mfma_kernel too: at its 128 registers they spill 74 and the
+                                                                //  whole kernel pays - 291 against 298 k queries/s in three interleaved repetitions, profiles/r06_y_ab.log)
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "wave_wgs") h->wave_wgs = std::max(0, (int)value);
     else if (n == "wave_plan") h->wave_plan = value != 0;  // 0: the device plans with order_kernel + emit_kernel (one request per lane)

@@ -29,6 +29,8 @@ namespace mibn {
 
 // (hipcc parses a kernel's body in its host pass too: there the functions below are __host__ __device__ over the host primitives)
 #define WV_HD MIBN_HD inline
+// (the big step forms out of line - __attribute__((noinline)) on emit_sweep / emit_outer / emit_chain_as - were measured worse: the
+//  emitter's state then lives in private memory, 1 008 bytes of scratch per lane against 560)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WV_LANE0 if (wv::lane() == 0)
 #else
