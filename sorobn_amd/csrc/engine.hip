@@ -1621,7 +1621,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 // (host_ms > 0.02, not > 1: a stream answered from plan templates - n_evidence = 1 once its 9 900 shapes are stored - plans
                 //  its 13 000 requests in 0.7 ms; with the old bar its rate was never measured, "the host alone would keep up" never
                 //  fired and the device planner stayed on at three quarters of every chunk: 430 instead of 550 k queries/s, session N)
-                if (host_ms > 0.02) h->host_rate = h->host_rate > 0 ? 0.5 * h->host_rate + 0.5 * (double)(n - nd) / host_ms : (double)(n - nd) / host_ms;
+                if (host_ms > 0.02) h->host_rate = h->host_rate > 0 ? (wave_mode(h) ? 0.75 : 0.5) * h->host_rate + (wave_mode(h) ? 0.25 : 0.5) * (double)(n - nd) / host_ms : (double)(n - nd) / host_ms;
                 if (h->emit_share_opt <= 0 && host_ms > 0.02 && dev_ms > 1.0 && 4 * n >= 3 * h->chunk) {
                     if (wave_mode(h) && h->kernel_ms_per_req > 0) {
                         // wave_plan_kernel's time grows with the requests it is given, and it is GPU time taken from the VE kernels: the
@@ -1632,7 +1632,9 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                         // rates alone left a two-thread rank host-bound - 223 against 262 k queries/s; a feedback rule on the policy's
                         // planner-wall / kernel-time ratio counted the waits for the device as host time and ended at a share of 0.99:
                         // profiles/r06_r_ab.log, r06_s_ab.log)
-                        const double ih = host_ms / (double)(n - nd), kv = h->kernel_ms_per_req, kp = dev_ms / (double)nd;
+                        // (ih: the smoothed rate and the slower of it and this chunk's - the workers of a rank with the whole CPU quota plan in
+                        //  bursts, 35 000 n_evidence = 16 requests in 38 ms one call and 74 ms the next: profiles/r06_x_share16.log)
+                        const double ih = std::max(host_ms / (double)(n - nd), h->host_rate > 0 ? 1.0 / h->host_rate : 0.0), kv = h->kernel_ms_per_req, kp = dev_ms / (double)nd;
                         const double fixed = h->fixed_ms_per_req * (double)n;
                         const double target = std::max(0.03, std::min(0.99, ((double)n * ih + fixed - 0.85 * kv * (double)n) / ((ih + 0.85 * kp) * (double)n)));
                         h->emit_share = 0.5 * h->emit_share + 0.5 * target;
