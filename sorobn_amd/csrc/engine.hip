@@ -1221,6 +1221,12 @@ int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, do
     }
     ck.total_words = (size_t)n * stride;
     if (refused) {
+        if (h->trace || h->emit_fallbacks < 4) {  // (a rare event worth a line: the first few are always reported)
+            int64_t nw = 0, nb = 0, first = -1;
+            for (int64_t i = 0; i < n; ++i) { nw += meta[i].err == kEmitErrWords; nb += meta[i].err == kEmitErrDevice; if (meta[i].err && first < 0) first = i; }
+            std::fprintf(stderr, "[mibn plan] device planner: %lld requests beyond a device limit, %lld did not fit their slot / the item buffer (first: request %lld, %u words, %u items; %zu items of %zu in the buffer): the host plans the chunk\n",
+                         (long long)nb, (long long)nw, (long long)(b0 + first), first >= 0 ? meta[first].words : 0u, first >= 0 ? meta[first].n_tags : 0u, n_tags, tag_cap);
+        }
         if (!beyond) h->emit_words = std::min<uint32_t>(h->emit_words * 2, 1u << 20);
         ++h->emit_fallbacks;
         return 1;
@@ -1564,6 +1570,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
             const double tw = now_ms();
             rc = plan_on_device_collect(h, b0, nd, nd < n ? dp : ck, &dev_ms);
             h->emit_ms += now_ms() - tw;
+            if (h->trace >= 2) std::fprintf(stderr, "[mibn plan] collect returned %d at %.2f ms of the block\n", rc, now_ms() - t0);
             for (mibn_kernel_stat *ks : {&h->kstats[kNumKernels + 3], &h->ktotal[kNumKernels + 3]}) {  // (beside the chunk in flight: their time is not GPU busy time of its own)
                 if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", stat_name(kNumKernels + 3));
                 ks->launches += 2;
@@ -1681,6 +1688,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
         for (auto &b : st.bufs)
             if (b.cap && !b.data) { h->err = "pinned host allocation failed"; return MIBN_E_HIP; }
         h->stats.plan_ms += now_ms() - t0;
+        if (h->trace >= 2) std::fprintf(stderr, "[mibn plan] chunk planning block %.2f ms (on the device: %d)\n", now_ms() - t0, (int)on_device);
         if (!on_device && (rc = ensure(h, st.d_prog, st.prog_cap, ck.total_words + kMaxStepWords))) return rc;  // (slack: segment_wave prefetches whole descriptor slots)
         if ((rc = ensure(h, st.d_prog_off, st.prog_off_cap, (size_t)n))) return rc;
         if ((rc = ensure(h, st.d_arena_off, st.arena_off_cap, (size_t)n))) return rc;

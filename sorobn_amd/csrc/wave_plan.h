@@ -59,7 +59,7 @@ constexpr int kWVars = 128;
 constexpr int kWHints = 4;
 constexpr int kWCsr = 384;     // scope entries of all CPTs together
 constexpr int kWAxes = 24;     // axes of a factor / of a step before merging
-constexpr int kWEnt = 20;      // created factors alive at once (+ the inputs of the step in flight)
+constexpr int kWEnt = 24;      // created factors alive at once (+ the inputs of the step in flight)
 constexpr int kWSims = 4;      // candidate orders simulated side by side
 constexpr int kWSimEnt = 24;   // factors alive at once in a simulation
 constexpr int kWTags = 56;     // work items of a request
