@@ -623,6 +623,38 @@ def test_device_planner_writes_the_host_programs(amd):
         assert "order_kernel+emit_kernel" not in [k["name"] for k in b.backend.engine.kernel_stats()]
 
 
+def test_wave_planner_hands_what_it_does_not_cover_to_the_host(amd):
+    """wave_plan_kernel covers requests of at most 32 evidence variables and a few other bounded shapes (csrc/wave_plan.h, wave_plan_kernel.hip.h):
+    a request beyond one reports kEmitErrDevice, the engine plans that chunk on the host - never a different program.  Forty evidence nodes in
+    every eighth request of a device-planned batch: the answers are the host-planned ones bit for bit, and the planner's kernel did run."""
+    spec = netspec.grid_spec(10, 10, 4, seed=0)
+    bn = netspec.build(spec, amd.BayesNet)
+    be = bn.backend
+    to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
+    q, ev, ec = netspec.c3_requests(100, 4, 1024, 40, seed=11)
+    q4, ev4, ec4 = netspec.c3_requests(100, 4, 1024, 4, seed=12)
+    q_off = np.arange(1025, dtype=np.int64)
+    ne = np.where(np.arange(1024) % 8 == 0, 40, 4)
+    e_off = np.concatenate([[0], np.cumsum(ne)]).astype(np.int64)
+    qq = np.where(np.arange(1024) % 8 == 0, q, q4)
+    evs = np.concatenate([ev[i] if i % 8 == 0 else ev4[i] for i in range(1024)])
+    ecs = np.concatenate([ec[i] if i % 8 == 0 else ec4[i] for i in range(1024)])
+    want, off = be.engine.query_batch(q_off, to_var[qq], e_off, to_var[evs], ecs)
+    be.engine.set_option("gpu_emit", 1)
+    be.engine.set_option("emit_share", 1.0)
+    be.engine.set_option("chunk", 256)
+    got, off2 = be.engine.query_batch(q_off, to_var[qq], e_off, to_var[evs], ecs)
+    assert np.array_equal(off, off2) and np.array_equal(got, want)
+    # the requests it covers, alone: planned by the kernel (mode 2: word for word the host's programs)
+    be.engine.set_option("gpu_emit", 2)
+    sel = np.arange(1024) % 8 != 0
+    a = be.engine.query_fixed(to_var[q4[sel]][:, None], to_var[ev4[sel]], ec4[sel])
+    planned = [k for k in be.engine.kernel_stats() if k["name"] == "order_kernel+emit_kernel"]
+    assert planned and planned[0]["items"] == int(sel.sum())
+    be.engine.set_option("gpu_emit", 0)
+    assert np.array_equal(a, be.engine.query_fixed(to_var[q4[sel]][:, None], to_var[ev4[sel]], ec4[sel]))
+
+
 def test_adaptive_policy_starts_a_starved_rank_on_the_device_planner(amd):
     """Option adaptive (bench.py switches it on): an engine with at most four planning threads - a rank of an 8-GPU node with a
     16-CPU quota - plans on the device from its first call (engine.hip, run_batch); the answers are the host-planned ones bit for
