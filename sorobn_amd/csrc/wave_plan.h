@@ -137,6 +137,10 @@ struct WState {
             uint32_t nout[16], nB[16];
             WStage stg[5];                 // SWEEP: the stages of the candidate pass
             uint32_t hdr[kHdrWords];       // the header of the step in flight (flushed to the program when the step is complete)
+            struct {                       // the emitter's cold state (in LDS: as registers every lane would hold it alike - and spill it)
+                double alg_bytes, alg_flops, n_steps, max_step_cells, seg_bytes;
+                uint32_t seg_first, seg_steps;
+            } c;
             Tag tags[kWTags];
         } e;
     };
@@ -415,17 +419,14 @@ enum { T_RCARD, T_ROST, T_RTST, T_RB0, T_RB1, T_MC, T_MO, T_MT, T_MB0, T_MB1, T_
 struct WEmit {
     const WNet &N;
     WState &W;
-    EmitNet en;              // the options tag_program's helpers read (no pointers)
     // where the words go: the request's slot of the chunk's program buffer (EmitBuf, device branch)
     uint32_t *data;
     uint32_t size = 0, cap;
     bool overflow = false;
-    // statistics (EmitStats)
-    double alg_bytes = 0, alg_flops = 0, n_steps = 0, max_step_cells = 0;
-    int64_t arena_cells = 0, out_cells = 0;
+    // (the statistics - EmitStats - and the open segment of the work items live in W.e.c)
     int err = 0;
     // the request
-    B2 rel, hidden, keep, eb;
+    B2 keep;                 // the variables that can be axes (multi-state, not evidence)
     B2 alive0;               // CPT slices not yet consumed
     int n_live = 0;          // created factors alive (W.e.live: creation order)
     uint32_t ent_busy = 0;   // entries in use: alive, or an input / the output of the step in flight
@@ -437,12 +438,19 @@ struct WEmit {
     int64_t top = 0;
     // work items (tag_program, step by step)
     int n_tags = 0, level = 0;
-    uint32_t seg_first = 0, seg_steps = 0;
-    double seg_bytes = 0;
 
     WV_HD WEmit(const WNet &n, WState &w, uint32_t *slot, uint32_t cap_) : N(n), W(w), data(slot), cap(cap_) {
-        en.n_vars = n.n_vars; en.small_cells = n.small_cells; en.big_iters = n.big_iters; en.tile_h = n.tile_h; en.sweep_iters = n.sweep_iters;
-        en.tile_bytes = n.tile_bytes;
+        WV_LANE0 { W.e.c.alg_bytes = W.e.c.alg_flops = W.e.c.n_steps = W.e.c.max_step_cells = W.e.c.seg_bytes = 0; W.e.c.seg_first = W.e.c.seg_steps = 0; }
+        wv::sync();
+    }
+    // the step's share of the statistics (EmitStats)
+    WV_HD void book(double bytes, double flops, double step_cells) {
+        WV_LANE0 {
+            W.e.c.alg_bytes += bytes;
+            W.e.c.alg_flops += flops;
+            W.e.c.max_step_cells = emit_max(W.e.c.max_step_cells, step_cells);
+            W.e.c.n_steps += 1;
+        }
     }
 
     WV_HD int card(int v) const { return (int)N.card[v]; }
@@ -1315,10 +1323,7 @@ struct WEmit {
         }
         hdr_set(9, (uint32_t)(((int64_t)in_cells + out_cells + 2) >> 2));
         flush_header(w);
-        alg_bytes += 8.0 * (in_cells + (double)out_cells);
-        alg_flops += (double)k * 4.0 * (double)F.cells;
-        max_step_cells = emit_max(max_step_cells, (double)F.cells);
-        n_steps += 1;
+        book(8.0 * (in_cells + (double)out_cells), (double)k * 4.0 * (double)F.cells, (double)F.cells);
         tag_step((uint32_t)(w - data));
         WV_COUNT(20 + k);
         for (int j = 0; j < n_in; ++j)
@@ -1414,12 +1419,9 @@ struct WEmit {
         if (err) return false;
         hdr_set(9, (uint32_t)(((int64_t)in_cells + cells + 2) >> 2));
         flush_header(w);
-        alg_bytes += 8.0 * (in_cells + (double)cells);
-        double pc = (double)cells;
+        double pc = (double)cells;  // cells of the product scope = the output's cells x the eliminated cardinalities
         for (int k = 0; k < nx; ++k) pc *= card(X[k]);
-        alg_flops += n_in * pc;
-        max_step_cells = emit_max(max_step_cells, pc);
-        n_steps += 1;
+        book(8.0 * (in_cells + (double)cells), n_in * pc, pc);
         tag_step((uint32_t)(w - data));
         for (int j = 0; j < n_in; ++j)
             if (falloc(hl[j])) arena_release((int64_t)foffset(hl[j]), falloc(hl[j]));
@@ -1433,34 +1435,49 @@ struct WEmit {
         ++n_tags;
     }
     WV_HD void flush_segment() {
+        const uint32_t seg_steps = W.e.c.seg_steps;
         if (seg_steps) {
-            put_tag(Tag{seg_first, seg_steps | kItemSegment, 1u, (uint16_t)level, (uint16_t)kKidSeg, (float)seg_bytes});
+            put_tag(Tag{W.e.c.seg_first, seg_steps | kItemSegment, 1u, (uint16_t)level, (uint16_t)kKidSeg, (float)W.e.c.seg_bytes});
             ++level;
-            seg_steps = 0;
-            seg_bytes = 0;
+            wv::sync();
+            WV_LANE0 { W.e.c.seg_steps = 0; W.e.c.seg_bytes = 0; }
+            wv::sync();
         }
+    }
+    // (step_is_tiled / step_tile_h of emit_core.h on the options in WNet)
+    WV_HD bool hdr_is_tiled(const uint32_t *w) const {
+        if ((w[0] & 0xff) == kKindFiber || (w[0] & 0xff) == kKindSweep) return true;
+        const bool fin = (w[1] >> 16) & kFlagFinal;
+        return !fin && (int64_t)w[2] * (int64_t)w[3] >= N.big_iters;
+    }
+    WV_HD int hdr_tile_h(const uint32_t *w) const {
+        if ((w[0] & 0xff) == kKindSweep) return emit_max(1, emit_min((int)N.sweep_iters, kTileMax));
+        if (N.tile_h > 0) return emit_min((int)N.tile_h, kTileMax);
+        const int64_t per_iter = emit_max<int64_t>(1, step_cost_bytes(w) / emit_max<int64_t>(1, (int64_t)w[3]));
+        return (int)emit_max<int64_t>(1, emit_min<int64_t>(kTileMax, N.tile_bytes / per_iter));
     }
     WV_HD void tag_step(uint32_t off) {
         if (overflow) return;
         wv::sync();
         const uint32_t *w = W.e.hdr;
         const double bytes = (double)step_cost_bytes(w);
-        if (step_is_tiled(en, w)) {
+        if (hdr_is_tiled(w)) {
             flush_segment();
-            const uint32_t th = (uint32_t)step_tile_h(en, w);
+            const uint32_t th = (uint32_t)hdr_tile_h(w);
             put_tag(Tag{off, (w[0] & 0xff) == kKindSweep ? w[3] : th, (w[3] + th - 1) / th, (uint16_t)level, (uint16_t)kernel_id_of_step(w), (float)bytes});
             ++level;
         } else {
-            if (!seg_steps) seg_first = off;
-            ++seg_steps;
-            seg_bytes += bytes;
+            WV_LANE0 {
+                if (!W.e.c.seg_steps) W.e.c.seg_first = off;
+                ++W.e.c.seg_steps;
+                W.e.c.seg_bytes += bytes;
+            }
         }
     }
 
-
     // ---- the request (emit_begin) ---------------------------------------------------------------------------------------------
-    WV_HD int begin(int ne, const int32_t *evars, const int32_t *ecodes, const B2 &rel_, const B2 &hidden_, const B2 &keep_, const B2 &eb_) {
-        rel = rel_; hidden = hidden_; keep = keep_; eb = eb_;
+    WV_HD int begin(int ne, const int32_t *evars, const int32_t *ecodes, const B2 &rel, const B2 &keep_, const B2 &eb) {
+        keep = keep_;
         wv::for_n(ne, [&](int i) { W.ecode[evars[i]] = (uint16_t)(ecodes ? ecodes[i] : 0); });
         wv::sync();
         const bool bad = wv::any_n(N.n_vars, [&](int v) {
@@ -1582,7 +1599,6 @@ struct WEmit {
         wv::sync();
         uint32_t *count_word = extend(1);
         WV_LANE0 count_word[0] = 0;
-        const double steps0 = n_steps;
         uint8_t *hl = W.e.hl, *hs = W.e.hs;
         const uint8_t *best = W.order;
         int32_t *sweep_n = W.e.t[T_F];
@@ -1763,8 +1779,6 @@ struct WEmit {
         ent_busy &= ~consumed_ents;
         consumed_ents = 0;
         // posterior = pointwise_mul(factors) / sum (bayes_net.py:789-790), written in the caller's query order
-        out_cells = 1;
-        for (int i = 0; i < nq; ++i) out_cells *= card(qvars[i]);
         int n_in = 0;
         b2_each(alive0, [&](int v) { if (n_in < kWIns) { WV_LANE0 hl[n_in] = (uint8_t)v; } ++n_in; });
         for (int p = 0; p < n_live; ++p) { if (n_in < kWIns) { WV_LANE0 hl[n_in] = (uint8_t)(kWVars + W.e.live[p]); } ++n_in; }
@@ -1773,8 +1787,8 @@ struct WEmit {
         emit_limited(n_in, -1, true, out_off);
         if (err) return err;
         if (overflow) return kEmitErrWords;
-        WV_LANE0 count_word[0] = (uint32_t)(n_steps - steps0);
-        arena_cells = emit_max(arena_cells, top);
+        wv::sync();
+        WV_LANE0 count_word[0] = (uint32_t)W.e.c.n_steps;
         flush_segment();
         WV_TICK(12)  // final product
         if (err) return err;
@@ -1796,14 +1810,15 @@ WV_HD void wave_plan_request(const WNet &N, WState &W, const B2 *anc, int nq, co
     for (int i = 0; i < ne; ++i) eb.set(evars[i]);
     // (hidden as emit_begin has it: the multi-state variables only - single-state ones are never axes, never eliminated)
     WEmit em(N, W, slot, cap);
-    int err = em.begin(ne, evars, ecodes, oc.rel, oc.hidden, oc.keep, eb);
+    int err = em.begin(ne, evars, ecodes, oc.rel, oc.keep, eb);
     WV_TICK(4)  // CPT slices
     if (!err) err = em.run(nq, qvars, out_off, n_best WV_PROF_PASS);
     R.err = err;
     R.words = em.size;
     R.n_tags = (uint32_t)em.n_tags;
-    R.alg_bytes = em.alg_bytes; R.alg_flops = em.alg_flops; R.n_steps = em.n_steps; R.max_step_cells = em.max_step_cells;
-    R.arena_cells = em.arena_cells;
+    wv::sync();
+    R.alg_bytes = W.e.c.alg_bytes; R.alg_flops = W.e.c.alg_flops; R.n_steps = W.e.c.n_steps; R.max_step_cells = W.e.c.max_step_cells;
+    R.arena_cells = em.top;
 }
 
 }  // namespace mibn
