@@ -15,6 +15,7 @@
 #   parity        the GPU parity suite under non-default engine options: PARITY_OPTS="mfma_kernel=1" [PARITY_K="<pytest -k expr>"]
 #   planner       tools/bench_planner.py (host planning rate, one thread)
 #   smoke         __graft_entry__.smoke()
+#   plantrace     rocprofv3 kernel trace of a two-planning-threads rank (the device planner beside the VE kernels): calls / total / average per kernel
 #   planlanes     the device planner alone (--sync, whole chunks on the device) at PLAN_LANES="1 4 16 32 64" requests per wave: kernel ms per chunk
 #   plansq        SQ counters of the device planner's kernels (one pass, --sync, whole chunks on the device; PLAN_OPTS="--opt wave_plan=1")
 TAG=${1:?tag}; shift
@@ -106,6 +107,22 @@ for n, d in by.items():
     wc = d.get("SQ_WAVE_CYCLES", (0, 1))[1] or 1
     print("%-24s launches %5d  " % (n[:24], d.get("SQ_WAVE_CYCLES", (0, 0))[0]) + "  ".join("%s %.3f" % (c.replace("SQ_", ""), v / wc) for c, (k, v) in sorted(d.items()) if c != "SQ_WAVE_CYCLES") + "  (fractions of SQ_WAVE_CYCLES)  wave cycles %.3g" % wc)
 PY
+  find $OUT -name "*.db" -delete ;;
+plantrace)
+  ( cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_plantrace -o t -- python $ROOT/bench.py --steps 3 --warmup 3 --no-cpu --no-configs --threads 2 > $OUT/${TAG}_plantrace.log 2>&1 )
+  python3 - "$(find $OUT/${TAG}_plantrace -name '*.db' | head -1)" <<'PY' | tee $OUT/${TAG}_plantrace_summary.txt
+import sqlite3, sys
+cur = sqlite3.connect(sys.argv[1]).cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+kd = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch"))
+ks = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
+rows = cur.execute(f"select s.kernel_name, count(*), sum(d.end - d.start) / 1e6, avg(d.end - d.start) / 1e6, max(d.end - d.start) / 1e6 from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+print("bench.py --threads 2 (device planner on): kernel-trace, durations in ms")
+for n, c, t, a, m in rows[:12]:
+    print("%-60s calls %6d  total %10.2f  avg %8.3f  max %8.3f  %5.1f %%" % (n[:60], c, t, a, m, 100 * t / tot))
+PY
+  grep -h '"metric"' $OUT/${TAG}_plantrace.log | head -1 | cut -c1-400 >> $OUT/${TAG}_plantrace_summary.txt
   find $OUT -name "*.db" -delete ;;
 smoke)
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/${TAG}_smoke.log ;;
