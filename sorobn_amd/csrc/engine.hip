@@ -207,6 +207,8 @@ struct mibn_ctx {
     struct Set {
         Staging stage[4];           // prog_off, arena_off, items, wg_item
         std::vector<ProgBuf> bufs;  // pinned host program buffers, one per worker
+        std::vector<ProgBuf> xbufs; // ... and the ones the host re-plans single requests of a device-planned chunk into (beyond a device limit)
+        BatchPlan xplan;
         uint32_t *d_prog = nullptr;
         size_t prog_cap = 0;
         uint64_t *d_prog_off = nullptr;
@@ -295,6 +297,7 @@ struct mibn_ctx {
     double emit_share_opt = -1;
     BatchPlan emit_dev, emit_host;   // the two parts of a chunk before they are joined
     uint32_t emit_words = 6144;      // words of a request's program slot (doubles after a chunk that did not fit)
+    int64_t emit_single = 0;         // requests of device-planned chunks the host planned because they exceeded a device limit
     // wave-cooperative device planner (wave_plan_kernel)
     int wave_plan = 1;               // option: 1 = chunks the device plans go through wave_plan_kernel where the network is covered (wave_plan.h)
     int wave_wgs = 0;                // option: workgroups of a wave_plan_kernel launch (0: one per four requests - the whole chip at once)
@@ -532,6 +535,8 @@ void mibn_destroy(mibn_t *h) {
         for (auto &st : h->set) {
             for (auto &b : st.bufs)
                 if (b.data) (void)hipHostFree(b.data);
+            for (auto &b : st.xbufs)
+                if (b.data) (void)hipHostFree(b.data);
             (void)hipFree(st.d_prog);
             (void)hipFree(st.d_prog_off);
             (void)hipFree(st.d_arena_off);
@@ -767,8 +772,11 @@ void ensure_pool(mibn_ctx *h) {
     h->pool = new ThreadPool(h->threads > 0 ? h->threads : default_threads());
     for (auto &st : h->set) {
         st.bufs.resize(h->pool->size());
-        if (!h->planner_only)
+        st.xbufs.resize(h->pool->size());
+        if (!h->planner_only) {
             for (auto &b : st.bufs) b.grow = pinned_grow;
+            for (auto &b : st.xbufs) b.grow = pinned_grow;
+        }
     }
 }
 
@@ -1171,7 +1179,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
 #ifndef MIBN_HOST_BOUND_RATIO
 #define MIBN_HOST_BOUND_RATIO 1.15  // adaptive policy: planner wall time over GPU kernel time above which a stream of calls counts as host-bound
 #endif
-int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, double *dev_ms) {
+int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, double *dev_ms, std::vector<int64_t> *beyond_list) {
     hipStream_t P = h->search_stream;
     const size_t stride = h->emit_words;
     const size_t tag_cap = (size_t)n * 64;
@@ -1205,7 +1213,10 @@ int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, do
     for (int64_t i = 0; i < n; ++i) {
         const EmitMeta &m = meta[i];
         if (m.err == kEmitErrWords) { refused = true; continue; }
-        if (m.err == kEmitErrDevice) { refused = true; beyond = true; continue; }  // (beyond what wave_plan_kernel covers: the host plans the chunk)
+        if (m.err == kEmitErrDevice) {  // beyond what wave_plan_kernel covers: the host plans this request (the chunk, if they are many)
+            if (beyond_list && beyond_list->size() < 256) { beyond_list->push_back(i); continue; }
+            refused = true; beyond = true; continue;
+        }
         if (m.err) { h->err = "request " + std::to_string(b0 + i) + ": " + emit_error_message(m.err); return MIBN_E_LIMIT; }
         ck.prog_off[i] = (uint64_t)i * stride;
         ck.local_off[i] = ck.prog_off[i];
@@ -1550,6 +1561,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
             return code;
         };
         bool on_device = false;
+        std::vector<int64_t> beyond;  // requests of the device's part that exceed a device limit (kEmitErrDevice): the host plans them
         int64_t nd = 0;          // requests [b0, b0 + nd) planned by the device, the rest by the host's workers meanwhile
         size_t prog_base = 0;    // words of st.d_prog the device has written (the host's programs follow)
         if (emit_on) {
@@ -1568,7 +1580,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 if (!hp.err.empty()) { h->err = hp.err; return bail(MIBN_E_LIMIT); }
             }
             const double tw = now_ms();
-            rc = plan_on_device_collect(h, b0, nd, nd < n ? dp : ck, &dev_ms);
+            rc = plan_on_device_collect(h, b0, nd, nd < n ? dp : ck, &dev_ms, &beyond);
             h->emit_ms += now_ms() - tw;
             if (h->trace >= 2) std::fprintf(stderr, "[mibn plan] collect returned %d at %.2f ms of the block\n", rc, now_ms() - t0);
             for (mibn_kernel_stat *ks : {&h->kstats[kNumKernels + 3], &h->ktotal[kNumKernels + 3]}) {  // (beside the chunk in flight: their time is not GPU busy time of its own)
@@ -1654,6 +1666,46 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 }
             }
         }
+        if (on_device && !beyond.empty()) {
+            // The requests of the device's part that exceed one of wave_plan_kernel's limits: the host plans THEM (round 6: a refused
+            // request used to send its whole chunk to the host - n_evidence = 16 met a limit five times in 200 000 requests and lost a
+            // third of its rate) - one plan_batch over the device's range with everything else masked out; a program goes into its
+            // request's own slot of the device program buffer, its work items and statistics take the place the kernel left empty.
+            std::vector<char> mask(skip.begin(), skip.end());
+            for (int64_t i = 0; i < nd; ++i) mask[(size_t)(b0 + i)] = 1;
+            for (int64_t i : beyond) mask[(size_t)(b0 + i)] = skip[(size_t)(b0 + i)];
+            BatchPlan &xp = st.xplan;
+            plan_batch(h->net, *h->pool, st.xbufs, b0, b0 + nd, q_off, q_vars, e_off, e_vars, e_codes, out_off, mask.data(), xp,
+                       (flags & MIBN_Q_NOPRUNE) != 0, nullptr, nullptr, b0);
+            if (!xp.err.empty()) { h->err = xp.err; return bail(MIBN_E_LIMIT); }
+            const size_t stride = h->emit_words;
+            const size_t X = ck.tags.size();
+            ck.tags.resize(X + xp.tags.size());
+            for (size_t t = 0; t < xp.tags.size(); ++t) ck.tags[X + t] = xp.tags[t];
+            bool fits = true;
+            for (int64_t i : beyond) {
+                const uint32_t *w = st.xbufs[(size_t)xp.thread_of[(size_t)i]].data + xp.local_off[(size_t)i];
+                size_t words = 1;
+                for (uint32_t k = 0; k < w[0]; ++k) words += w[words + 6];
+                if (words + kMaxStepWords > stride) { fits = false; break; }
+                HIP_TRY(h, hipMemcpyAsync(st.d_prog + (size_t)i * stride, w, words * 4, hipMemcpyHostToDevice, h->copy_stream));
+                ck.prog_off[(size_t)i] = (uint64_t)i * stride;
+                ck.local_off[(size_t)i] = ck.prog_off[(size_t)i];
+                ck.thread_of[(size_t)i] = (int32_t)(X + (size_t)xp.thread_of[(size_t)i]);
+                ck.tag_first[(size_t)i] = xp.tag_first[(size_t)i];
+                ck.tag_count[(size_t)i] = xp.tag_count[(size_t)i];
+                ck.cost[(size_t)i] = xp.cost[(size_t)i];
+                ck.arena_need[(size_t)i] = xp.arena_need[(size_t)i];
+            }
+            ck.st.alg_bytes += xp.st.alg_bytes; ck.st.alg_flops += xp.st.alg_flops; ck.st.n_steps += xp.st.n_steps;
+            ck.st.max_step_cells = std::max(ck.st.max_step_cells, xp.st.max_step_cells);
+            ck.arena_cells = std::max(ck.arena_cells, xp.arena_cells);
+            if (h->trace || h->emit_single < 4)
+                std::fprintf(stderr, "[mibn plan] device planner: %zu of %lld requests beyond a device limit (first: request %lld): planned on the host\n", beyond.size(), (long long)nd,
+                             (long long)(b0 + beyond[0]));
+            h->emit_single += (int64_t)beyond.size();
+            if (!fits) on_device = false;  // (a program longer than its slot: the host plans the chunk after all)
+        }
         if (!on_device)
             plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ck,
                        (flags & MIBN_Q_NOPRUNE) != 0, orders, order_len);
@@ -1661,6 +1713,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
             // test mode: the host plans the chunk too - programs, work items and statistics must agree exactly
             const size_t stride = h->emit_words;
             std::vector<uint32_t> dev((size_t)n * stride);
+            HIP_TRY(h, hipStreamSynchronize(h->copy_stream));  // (the programs of requests beyond a device limit, planned on the host above)
             HIP_TRY(h, hipMemcpy(dev.data(), st.d_prog, dev.size() * 4, hipMemcpyDeviceToHost));
             BatchPlan ref;
             plan_batch(h->net, *h->pool, st.bufs, b0, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), ref,
@@ -1676,7 +1729,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                                  std::to_string(hw[k]) + " device " + std::to_string(dw[k]);
                         return bail(MIBN_E_STATE);
                     }
-                const Tag *ht = ref.tags[ref.thread_of[i]].data() + ref.tag_first[i], *dt = ck.tags[0].data() + ck.tag_first[i];
+                const Tag *ht = ref.tags[ref.thread_of[i]].data() + ref.tag_first[i], *dt = ck.tags[(size_t)ck.thread_of[i]].data() + ck.tag_first[i];
                 bool same = ref.tag_count[i] == ck.tag_count[i] && ref.arena_need[i] == ck.arena_need[i] && ref.cost[i] == ck.cost[i];
                 for (uint32_t k = 0; same && k < ref.tag_count[i]; ++k)
                     same = ht[k].rel_off == dt[k].rel_off && ht[k].a == dt[k].a && ht[k].wgs == dt[k].wgs && ht[k].level == dt[k].level &&

@@ -625,8 +625,9 @@ def test_device_planner_writes_the_host_programs(amd):
 
 def test_wave_planner_hands_what_it_does_not_cover_to_the_host(amd):
     """wave_plan_kernel covers requests of at most 32 evidence variables and a few other bounded shapes (csrc/wave_plan.h, wave_plan_kernel.hip.h):
-    a request beyond one reports kEmitErrDevice, the engine plans that chunk on the host - never a different program.  Forty evidence nodes in
-    every eighth request of a device-planned batch: the answers are the host-planned ones bit for bit, and the planner's kernel did run."""
+    a request beyond one reports kEmitErrDevice and the host plans THAT REQUEST into its slot of the device-planned chunk (more than 256 of them in
+    a chunk: the whole chunk) - never a different program.  Forty evidence nodes in every eighth request of a device-planned batch: the answers
+    are the host-planned ones bit for bit, the chunks stay with the planner's kernel."""
     spec = netspec.grid_spec(10, 10, 4, seed=0)
     bn = netspec.build(spec, amd.BayesNet)
     be = bn.backend
@@ -645,6 +646,12 @@ def test_wave_planner_hands_what_it_does_not_cover_to_the_host(amd):
     be.engine.set_option("chunk", 256)
     got, off2 = be.engine.query_batch(q_off, to_var[qq], e_off, to_var[evs], ecs)
     assert np.array_equal(off, off2) and np.array_equal(got, want)
+    # ... request by request: the chunks stay device-planned, the host plans the 128 requests beyond the limit into their slots
+    planned = [k for k in be.engine.kernel_stats() if k["name"] == "order_kernel+emit_kernel"]
+    assert planned and planned[0]["items"] == 1024, planned
+    be.engine.set_option("gpu_emit", 2)  # (mode 2: every program, work item and statistic of the mixed chunks against the host planner)
+    got2, _ = be.engine.query_batch(q_off, to_var[qq], e_off, to_var[evs], ecs)
+    assert np.array_equal(got2, want)
     # the requests it covers, alone: planned by the kernel (mode 2: word for word the host's programs)
     be.engine.set_option("gpu_emit", 2)
     sel = np.arange(1024) % 8 != 0
