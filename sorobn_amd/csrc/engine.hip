@@ -300,6 +300,7 @@ struct mibn_ctx {
     int64_t emit_single = 0;         // requests of device-planned chunks the host planned because they exceeded a device limit
     // wave-cooperative device planner (wave_plan_kernel)
     int wave_plan = 1;               // option: 1 = chunks the device plans go through wave_plan_kernel where the network is covered (wave_plan.h)
+    int plan_priority = 2;           // option: the device planner's stream priority (2 highest - the default since round 4 -, 1 normal, 0 lowest); before the first device-planned chunk
     int wave_wgs = 0;                // option: workgroups of a wave_plan_kernel launch (0: one per four requests - the whole chip at once)
     WNet *wnet_host = nullptr;       // the packed network + options as uploaded last
     WNet *d_wnet = nullptr;
@@ -583,6 +584,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
                                                                 //  whole kernel pays - 291 against 298 k queries/s in three interleaved repetitions, profiles/r06_y_ab.log)
     else if (n == "gpu_emit") h->gpu_emit = std::max(0, std::min(2, (int)value));  // whole chunks planned on the device (order search + program emission)
     else if (n == "wave_wgs") h->wave_wgs = std::max(0, (int)value);
+    else if (n == "plan_priority") h->plan_priority = std::max(0, std::min(2, (int)value));
     else if (n == "wave_plan") h->wave_plan = value != 0;  // 0: the device plans with order_kernel + emit_kernel (one request per lane)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
     else if (n == "plan_sort") h->plan_sort = (int)value;
@@ -913,7 +915,7 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
     if (!h->search_stream) {
         int lo = 0, hi = 0;
         HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(h, hipStreamCreateWithPriority(&h->search_stream, hipStreamNonBlocking, hi));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->search_stream, hipStreamNonBlocking, h->plan_priority >= 2 ? hi : (h->plan_priority == 1 ? (lo + hi) / 2 : lo)));
     }
     const size_t nq = (size_t)(q_off[b1] - q_off[b0]), ne = (size_t)(e_off[b1] - e_off[b0]);
     const size_t off_bytes = (size_t)(n + 1) * 8;
@@ -981,7 +983,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
     if (!h->search_stream) {
         int lo = 0, hi = 0;
         HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(h, hipStreamCreateWithPriority(&h->search_stream, hipStreamNonBlocking, hi));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->search_stream, hipStreamNonBlocking, h->plan_priority >= 2 ? hi : (h->plan_priority == 1 ? (lo + hi) / 2 : lo)));
     }
     hipStream_t P = h->search_stream;
     const size_t nq = (size_t)(q_off[b1] - q_off[b0]), ne = (size_t)(e_off[b1] - e_off[b0]);

@@ -416,28 +416,50 @@ static long g_wave_count[32];
 // rows of WState::e.t
 enum { T_RCARD, T_ROST, T_RTST, T_RB0, T_RB1, T_MC, T_MO, T_MT, T_MB0, T_MB1, T_NAX, T_RAX, T_CTRL, T_MAP, T_A, T_B, T_C, T_F };
 
+// A value every lane of the wave holds alike and that lives across whole steps (the emitter's counters and masks): every update
+// goes through wv::uni, so the compiler keeps it in a SCALAR register - scalar registers spill into the lanes of a vector register,
+// vector registers into scratch memory, and at 128 vector registers the planner spills (profiles/NOTES_r06.md, session AP).
+// The host build: a plain T.
+#if defined(MIBN_WAVE_NO_UNI)
+template <class T> using WUni = T;
+#else
+template <class T> struct WUni {
+    T v;
+    WV_HD WUni() : v() {}
+    WV_HD WUni(T x) : v(wv::uni(x)) {}
+    WV_HD operator T() const { return v; }
+    WV_HD WUni &operator=(T x) { v = wv::uni(x); return *this; }
+    WV_HD WUni &operator+=(T x) { v = wv::uni((T)(v + x)); return *this; }
+    WV_HD WUni &operator-=(T x) { v = wv::uni((T)(v - x)); return *this; }
+    WV_HD WUni &operator|=(T x) { v = wv::uni((T)(v | x)); return *this; }
+    WV_HD WUni &operator&=(T x) { v = wv::uni((T)(v & x)); return *this; }
+    WV_HD WUni &operator++() { v = wv::uni((T)(v + 1)); return *this; }
+    WV_HD WUni &operator--() { v = wv::uni((T)(v - 1)); return *this; }
+};
+#endif
+
 struct WEmit {
     const WNet &N;
     WState &W;
     // where the words go: the request's slot of the chunk's program buffer (EmitBuf, device branch)
     uint32_t *data;
-    uint32_t size = 0, cap;
-    bool overflow = false;
+    WUni<uint32_t> size = 0u, cap;
+    WUni<bool> overflow = false;
     // (the statistics - EmitStats - and the open segment of the work items live in W.e.c)
-    int err = 0;
+    WUni<int> err = 0;
     // the request
     B2 keep;                 // the variables that can be axes (multi-state, not evidence)
     B2 alive0;               // CPT slices not yet consumed
-    int n_live = 0;          // created factors alive (W.e.live: creation order)
-    uint32_t ent_busy = 0;   // entries in use: alive, or an input / the output of the step in flight
-    uint32_t consumed_ents = 0;  // entries consumed by the step in flight (their data stays until the step is complete)
+    WUni<int> n_live = 0;          // created factors alive (W.e.live: creation order)
+    WUni<uint32_t> ent_busy = 0u;  // entries in use: alive, or an input / the output of the step in flight
+    WUni<uint32_t> consumed_ents = 0u;  // entries consumed by the step in flight (their data stays until the step is complete)
     const uint8_t *cur_hl = nullptr;  // the inputs of the step being emitted (handles)
-    int npos = 0;            // layout positions in use (W.pvar)
-    int n_pool = 0, pool_cap = 0;  // the host's pool accounting (its limits are part of the program's definition)
-    int nf = 0;              // arena: free blocks (W.e.foff / fsz), top
-    int64_t top = 0;
+    WUni<int> npos = 0;            // layout positions in use (W.pvar)
+    WUni<int> n_pool = 0, pool_cap = 0;  // the host's pool accounting (its limits are part of the program's definition)
+    WUni<int> nf = 0;              // arena: free blocks (W.e.foff / fsz), top
+    WUni<int64_t> top = (int64_t)0;
     // work items (tag_program, step by step)
-    int n_tags = 0, level = 0;
+    WUni<int> n_tags = 0, level = 0;
 
     WV_HD WEmit(const WNet &n, WState &w, uint32_t *slot, uint32_t cap_) : N(n), W(w), data(slot), cap(cap_) {
         WV_LANE0 { W.e.c.alg_bytes = W.e.c.alg_flops = W.e.c.n_steps = W.e.c.max_step_cells = W.e.c.seg_bytes = 0; W.e.c.seg_first = W.e.c.seg_steps = 0; }
@@ -1477,7 +1499,7 @@ struct WEmit {
 
     // ---- the request (emit_begin) ---------------------------------------------------------------------------------------------
     WV_HD int begin(int ne, const int32_t *evars, const int32_t *ecodes, const B2 &rel, const B2 &keep_, const B2 &eb) {
-        keep = keep_;
+        keep = wv::uni(keep_);
         wv::for_n(ne, [&](int i) { W.ecode[evars[i]] = (uint16_t)(ecodes ? ecodes[i] : 0); });
         wv::sync();
         const bool bad = wv::any_n(N.n_vars, [&](int v) {
@@ -1496,7 +1518,7 @@ struct WEmit {
         });
         wv::sync();
         if (bad) return kEmitErrDevice;
-        alive0 = rel;
+        alive0 = wv::uni(rel);
         n_pool = b2_count(rel);
         pool_cap = emit_pool_cap(N.n_vars);
         return 0;
@@ -1524,7 +1546,7 @@ struct WEmit {
         uint32_t cons = 0;
         for (int j = a; j < b; ++j) {
             const int h = list[j];
-            if (h < kWVars) alive0.clr(h);
+            if (h < kWVars) { B2 a = alive0; a.clr(h); alive0 = wv::uni(a); }
             else cons |= 1u << (h - kWVars);
         }
         if (cons) remove_live(wv::mask64(n_live, [&](int p) { return ((cons >> W.e.live[p]) & 1) != 0; }));
@@ -1613,7 +1635,7 @@ struct WEmit {
             int n_in = 0;
             {
                 const B2 m0 = b2_and(N.fam[x], alive0);
-                alive0 = b2_andn(alive0, m0);
+                alive0 = wv::uni(b2_andn(alive0, m0));
                 const uint64_t mc = wv::mask64(n_live, [&](int p) { return ((B2)W.e.ent[W.e.live[p]].scope).test(x); });
                 const int n0 = b2_count(m0);
                 n_in = n0 + __builtin_popcountll(mc);
