@@ -909,7 +909,7 @@ def main():
                     for kv in a.opt:
                         k, v = kv.split("=")
                         eng2.set_option(k, float(v))
-                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=32, warmup_calls=40, batch=32768)  # (forty warm-up calls: the share controller and the pinned buffers of a fresh engine settle over the first twenty - r06_o / r06_q)  # (a fresh engine: its buffers, the share controller)
+                    out["configs"][name] = c3_variant(eng2, to_var, a.n_evidence, calls=64, warmup_calls=40, batch=32768)  # (forty warm-up calls: the share controller and the pinned buffers of a fresh engine settle over the first twenty - r06_o / r06_q; sixty-four timed calls: the timed region starts with an idle GPU and the first call's planning is not hidden - a sixty-fourth of the region, the standalone runs' share)  # (a fresh engine: its buffers, the share controller)
                     eng2.close()
                 except Exception as e:  # noqa: BLE001
                     out["configs"][name] = {"error": repr(e)}
