@@ -43,6 +43,9 @@ struct WProf { unsigned long long t, a[24]; };
 #define WV_PROF_ARG , WProf &prof_
 #define WV_PROF_PASS , prof_
 #define WV_TICK(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_.a[k] += t_ - prof_.t; prof_.t = t_; }
+#if MIBN_WAVE_PROF >= 2  // the parts of emit() as phases 13.. of their own (taken out of the phase that called it)
+#define WV_ETICK(k) { if (pp_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pp_->a[k] += t_ - pp_->t; pp_->t = t_; } }
+#endif
 #elif defined(MIBN_WAVE_PROF)
 struct WProf { unsigned long long t, a[24]; };
 #define WV_PROF_ARG , WProf &prof_
@@ -52,6 +55,9 @@ struct WProf { unsigned long long t, a[24]; };
 #define WV_PROF_ARG
 #define WV_PROF_PASS
 #define WV_TICK(k)
+#endif
+#if !defined(WV_ETICK)
+#define WV_ETICK(k)
 #endif
 
 constexpr int kEmitErrDevice = 7;  // the request exceeds a device limit below: the host plans the chunk (like kEmitErrWords)
@@ -460,6 +466,9 @@ struct WEmit {
     WUni<int64_t> top = (int64_t)0;
     // work items (tag_program, step by step)
     WUni<int> n_tags = 0, level = 0;
+#if defined(MIBN_WAVE_PROF)
+    WProf *pp_ = nullptr;
+#endif
 
     WV_HD WEmit(const WNet &n, WState &w, uint32_t *slot, uint32_t cap_) : N(n), W(w), data(slot), cap(cap_) {
         WV_LANE0 { W.e.c.alg_bytes = W.e.c.alg_flops = W.e.c.n_steps = W.e.c.max_step_cells = W.e.c.seg_bytes = 0; W.e.c.seg_first = W.e.c.seg_steps = 0; }
@@ -1356,6 +1365,7 @@ struct WEmit {
     // ---- one step (Emitter::emit): multiply hl[0..n_in), sum out X[0..nx); the new factor is entry eo --------------------------
     WV_HD bool emit(const uint8_t *hl, int n_in, const int *X, int nx, bool final_, int64_t final_off, int eo, bool fiber_only) {
         WV_COUNT(nx * 2 + (fiber_only ? 1 : 0));
+        WV_ETICK(13)  // (the caller's part up to here)
         WEnt &out = W.e.ent[eo];
         cur_hl = hl;
         const int l = N.uniform_log2;
@@ -1377,6 +1387,7 @@ struct WEmit {
         // every axis is a multi-state variable of 2^l states: the dense strides are powers of two
         if (l * na >= 31) { if (!fiber_only) err = kEmitErrCells; return false; }
         const int64_t cells = int64_t(1) << (l * na);
+        WV_ETICK(14)  // scope
         // layout: longest-living variable fastest.  In layout-position space (W.key / W.pvar: elimination position, the query variables
         // behind) the scope is a bit set, the rank of a variable the number of scope bits above its own
         const B2 ps = wv::mask128(npos, [&](int p) { return scope.test(W.pvar[p]); });
@@ -1388,6 +1399,7 @@ struct WEmit {
             W.pos[v] = (int8_t)r;
         });
         WV_LANE0 { out.n = na; out.cells = (int32_t)cells; out.scope = scope; }
+        WV_ETICK(15)  // layout
         // per-input strides along the output axes, and along the eliminated variables
         int32_t (*s)[kWAxes] = W.e.s;
         wv::for_n(n_in * 32, [&](int i) { const int j = i >> 5, a = i & 31; if (a < na) s[j][a] = 0; else if (a < na + 3) W.e.xs[j][a - na] = 0; });
@@ -1416,6 +1428,7 @@ struct WEmit {
             else s[j][W.pos[v]] = st;
         });
         wv::sync();
+        WV_ETICK(16)  // strides
         const int c1 = nx > 0 ? card(X[0]) : 1;
         const int cx = nx > 1 ? c1 * card(X[1]) : c1;
         int64_t ooff, oalloc;
@@ -1423,12 +1436,14 @@ struct WEmit {
         else { ooff = arena_alloc(cells); oalloc = cells; }
         WV_LANE0 out.off = ooff;
         wv::sync();
+        WV_ETICK(17)  // arena_alloc
         uint32_t *w = nullptr;
         const bool streaming = !final_ && cells >= N.big_iters;
         const bool fiber = !streaming ? false
                            : nx == 3  ? emit_chain(n_in, out, w)
                                       : ((N.outer && nx > 0 && emit_outer(n_in, out, cx, c1, w)) || emit_fiber(n_in, out, cx, c1, w));
         if (err) return false;
+        WV_ETICK(18)  // streaming forms
         if (!fiber) {
             if (fiber_only) {
                 if (oalloc) arena_release(ooff, oalloc);
@@ -1439,14 +1454,18 @@ struct WEmit {
             emit_generic(n_in, out, cells, cx, final_, w);
         }
         if (err) return false;
+        WV_ETICK(19)  // GENERIC
         hdr_set(9, (uint32_t)(((int64_t)in_cells + cells + 2) >> 2));
         flush_header(w);
         double pc = (double)cells;  // cells of the product scope = the output's cells x the eliminated cardinalities
         for (int k = 0; k < nx; ++k) pc *= card(X[k]);
         book(8.0 * (in_cells + (double)cells), n_in * pc, pc);
+        WV_ETICK(20)  // header, statistics
         tag_step((uint32_t)(w - data));
+        WV_ETICK(21)  // work item
         for (int j = 0; j < n_in; ++j)
             if (falloc(hl[j])) arena_release((int64_t)foffset(hl[j]), falloc(hl[j]));
+        WV_ETICK(22)  // arena_release
         return true;
     }
 
@@ -1613,6 +1632,9 @@ struct WEmit {
 
     // ---- the elimination loop and the final product (emit_run); the order is W.order[0..n_best) ---------------------------------
     WV_HD int run(int nq, const int32_t *qvars, int64_t out_off, int n_best WV_PROF_ARG) {
+#if defined(MIBN_WAVE_PROF)
+        pp_ = &prof_;
+#endif
         if (nq > 127) return kEmitErrDevice;
         wv::for_n(n_best, [&](int i) { W.pvar[i] = W.order[i]; });
         wv::for_n(nq, [&](int i) { W.pvar[n_best + i] = (uint8_t)qvars[i]; });

@@ -99,11 +99,14 @@ int main(int argc, char **argv) {
     {
         unsigned long long hp[24];
         CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_wave_prof), sizeof(hp)));
-        static const char *names[13] = {"relevant set, candidate sweeps", "byte model of the sweeps", "min-fill search", "byte model of the min-fill order", "CPT slices",
-                                        "factors of x", "sweep candidates", "SWEEP 5 / 4", "CHAIN", "SWEEP 3 / 2", "pair", "single elimination", "final product"};
+        static const char *names[24] = {"relevant set, candidate sweeps", "byte model of the sweeps", "min-fill search", "byte model of the min-fill order", "CPT slices",
+                                        "factors of x", "sweep candidates", "SWEEP 5 / 4", "CHAIN", "SWEEP 3 / 2", "pair", "single elimination", "final product",
+                                        "emit(): (the caller up to the call)", "emit(): scope", "emit(): layout ranks", "emit(): strides", "emit(): arena_alloc", "emit(): FIBER / OUTER / CHAIN forms",
+                                        "emit(): GENERIC form", "emit(): header, statistics", "emit(): work item", "emit(): arena_release", ""};
+        const int np = MIBN_WAVE_PROF >= 2 ? 23 : 13;
         double tot = 0;
-        for (int k = 0; k < 13; ++k) tot += (double)hp[k];
-        for (int k = 0; k < 13; ++k) printf("  phase %-34s %8.0f clocks per request  %5.1f %%\n", names[k], (double)hp[k] / (4.0 * B), 100.0 * (double)hp[k] / tot);
+        for (int k = 0; k < np; ++k) tot += (double)hp[k];
+        for (int k = 0; k < np; ++k) printf("  phase %-34s %8.0f clocks per request  %5.1f %%\n", names[k], (double)hp[k] / (4.0 * B), 100.0 * (double)hp[k] / tot);
         printf("  all phases: %.0f clocks per request (s_memtime, four launches)\n", tot / (4.0 * B));
     }
 #endif
