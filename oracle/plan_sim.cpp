@@ -24,6 +24,8 @@
 using namespace mibn;
 
 static std::string g_err;
+static int g_order_effort = 0;
+static double g_second_above = 1e7;
 static int g_small_cells = 1024, g_big_iters = 4096, g_tile_h = 0, g_fuse = 1, g_prune = 1, g_chain = 1, g_sweep = 5, g_sweep_min = 2;
 extern "C" void plan_sim_set_small_cells(int v) { g_small_cells = v; }
 extern "C" void plan_sim_set_tiling(int big_iters, int tile_h) { g_big_iters = big_iters; g_tile_h = tile_h; }
@@ -32,6 +34,7 @@ extern "C" void plan_sim_set_chain(int chain) { g_chain = chain; }
 extern "C" void plan_sim_set_sweep(int sweep) { g_sweep = sweep; }
 extern "C" void plan_sim_set_sweep_min(int k) { g_sweep_min = k; }
 extern "C" void plan_sim_set_prune(int prune) { g_prune = prune; }
+extern "C" void plan_sim_set_order_effort(int effort, double second_above) { g_order_effort = effort; g_second_above = second_above; }
 
 extern "C" const char *plan_sim_error() { return g_err.c_str(); }
 
@@ -446,6 +449,7 @@ extern "C" int plan_sim_query_batch(int32_t n_vars, const int32_t *card, const i
     net.chain = g_chain;
     net.sweep = g_sweep;
     net.sweep_min = g_sweep_min;
+    net.order_effort = g_order_effort; net.second_above = g_second_above;
     net.prune = g_prune;
     net.stagger = stagger;
     net.set_hints(n_hints, hints);
@@ -584,6 +588,7 @@ extern "C" int64_t plan_sim_cache_check(int32_t n_vars, const int32_t *card, con
     net.chain = g_chain;
     net.sweep = g_sweep;
     net.sweep_min = g_sweep_min;
+    net.order_effort = g_order_effort; net.second_above = g_second_above;
     net.prune = g_prune;
     std::vector<int64_t> out_off(B + 1, 0);
     for (int64_t b = 0; b < B; ++b) {
@@ -635,6 +640,7 @@ extern "C" int64_t plan_sim_program(int32_t n_vars, const int32_t *card, const i
     net.chain = g_chain;
     net.sweep = g_sweep;
     net.sweep_min = g_sweep_min;
+    net.order_effort = g_order_effort; net.second_above = g_second_above;
     net.prune = g_prune;
     net.set_hints(n_hints, hints);
     Request rq;
@@ -666,12 +672,13 @@ extern "C" int64_t wave_plan_program(int32_t n_vars, const int32_t *card, const 
     net.chain = g_chain;
     net.sweep = g_sweep;
     net.sweep_min = g_sweep_min;
+    net.order_effort = g_order_effort; net.second_above = g_second_above;
     net.prune = g_prune;
     net.set_hints(n_hints, hints);
     std::unique_ptr<WNet> wn(new WNet);
     if (!net.wave_view(*wn)) return -3;
     std::unique_ptr<WState> ws(new WState);
-    std::vector<uint32_t> slot((size_t)cap + kMaxStepWords);
+    std::vector<uint32_t> slot(((size_t)cap + kMaxStepWords) * (g_order_effort ? 2 : 1) + (g_order_effort ? kWStashWords + 4 * kMaxStepWords : 0));  // (effort 1: two programs and the stash share the slot)
     WResult R;
     wave_plan_request(*wn, *ws, net.anc2.data(), nq, qvars, ne, evars, ecodes, no_prune != 0, 0, slot.data(), (uint32_t)slot.size(), R);
     if (R.err == kEmitErrDevice) return -4;
@@ -698,6 +705,7 @@ extern "C" int64_t plan_sim_program_tags(int32_t n_vars, const int32_t *card, co
     net.chain = g_chain;
     net.sweep = g_sweep;
     net.sweep_min = g_sweep_min;
+    net.order_effort = g_order_effort; net.second_above = g_second_above;
     net.prune = g_prune;
     net.set_hints(n_hints, hints);
     Request rq;
@@ -726,6 +734,7 @@ extern "C" double plan_sim_bench(int32_t n_vars, const int32_t *card, const int6
     net.chain = g_chain;
     net.sweep = g_sweep;
     net.sweep_min = g_sweep_min;
+    net.order_effort = g_order_effort; net.second_above = g_second_above;
     net.set_hints(n_hints, hints);
     net.plan_cache = 0;  // PLANNING is what is timed: the second pass over the same requests must not be answered from templates of the first
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
@@ -763,6 +772,7 @@ extern "C" int64_t plan_sim_device_style(int32_t n_vars, const int32_t *card, co
     if (n_vars > 128) { g_err = "the device planner covers networks of up to 128 variables"; return -1; }
     net.small_cells = g_small_cells; net.big_iters = g_big_iters; net.tile_h = g_tile_h; net.fuse = g_fuse; net.chain = g_chain;
     net.sweep = g_sweep; net.sweep_min = g_sweep_min; net.prune = g_prune;
+    net.order_effort = g_order_effort; net.second_above = g_second_above;
     net.set_hints(n_hints, hints);
     const EmitNet en = net.emit_view();
     const OrderNet on = net.order_view();

@@ -617,6 +617,8 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
             if (!h->planner_only) return upload_order_net(h);
         }
     }
+    else if (n == "order_effort") h->net.order_effort = std::max(0, std::min(1, (int)value));  // 1: more candidate orders, the byte model's best two both emitted where the best is expensive (order_search.h)
+    else if (n == "second_above") h->net.second_above = value;  // modelled bytes above which the runner-up order is emitted too
     else if (n == "order_weights") h->net.order_weights = std::max(0, std::min(64, (int)value));  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
     else if (n == "sweep_adapt") h->net.sweep_adapt = std::max(0, (int)value);  // fewer tiles per workgroup in sweep launches below this many workgroups
@@ -1104,7 +1106,8 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         A.tag_cap = (uint32_t)tag_cap;
         hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, P, h->d_emit_cursor);
         {
-            int64_t grid = (n + kWaveWG - 1) / kWaveWG;
+            // (the waves draw requests from a counter: the grid is what the chip holds at once - MIBN_WAVE_MIN_WGS workgroups per CU)
+            int64_t grid = std::min<int64_t>((n + kWaveWG - 1) / kWaveWG, (int64_t)h->n_cu * MIBN_WAVE_MIN_WGS);
             if (h->wave_wgs > 0) grid = std::min<int64_t>(grid, h->wave_wgs);
             hipLaunchKernelGGL(wave_plan_kernel, dim3((unsigned)grid), dim3(64 * kWaveWG), 0, P, A);
         }
@@ -1500,8 +1503,15 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
         (int64_t)(std::min(h->arena_gb * 1e9, 0.8 * (double)(free_b + h->arena_bytes[0] + h->arena_bytes[1])) / 8.0) / n_lanes;
     bool lane1_used = false;
     int64_t n_chunks = 0;
-    const bool emit_on = h->gpu_emit && h->order_net_ok && h->emit_net_ok;  // whole chunks planned on the device
-    const bool search_on = !emit_on && h->gpu_search && h->order_net_ok;
+    // order_effort >= 1 (more candidate orders, the byte model's best two both emitted): the wave planner has it, order_kernel / emit_kernel do
+    // not - where the wave planner does not cover the network the host plans (never two kinds of plans in one stream)
+    bool effort_ok = true;
+    if (h->net.order_effort >= 1 && (h->gpu_emit || h->gpu_search)) {
+        std::unique_ptr<WNet> probe(new WNet);
+        effort_ok = h->wave_plan && h->net.wave_view(*probe);
+    }
+    const bool emit_on = h->gpu_emit && h->order_net_ok && h->emit_net_ok && effort_ok;  // whole chunks planned on the device
+    const bool search_on = !emit_on && h->gpu_search && h->order_net_ok && h->net.order_effort < 1;
     int64_t search_b0 = -1;
     bool search_done = false;
     // a short first chunk gets an idle GPU going while the host plans the first full-size one (first_chunk = 2: also when

@@ -59,11 +59,17 @@ struct OrderNet {
     // orders are compared with the single-table steps at a quarter of their section-8(d) bytes.  (Powers of two only: the
     // host and the device search must round alike.)
     double chain_weight = 1.0, big_cells = 1024.0;
+    // effort 1 (Network::order_effort): more candidate orders - the meet sweep around the query's depth, and the small eliminations min-fill
+    // starts with followed by the meet sweep of the rest - and the SECOND best order kept beside the best: where the best is expensive the
+    // planner emits both and keeps the program that moves fewer bytes (the byte model ranks candidates well - among its best two the
+    // emitter finds 8 % fewer bytes on the C3 stream than the model's first choice of round 5's four, tools/order_exp.cpp)
+    int32_t effort = 0;
 };
 
 // factor slots of the byte model: slot v < 128 = the evidence-sliced CPT of variable v, slot 128 + o = the factor the o-th
 // elimination creates
 constexpr int kOrderSlotWords = 4, kOrderSlots = 64 * kOrderSlotWords;
+constexpr int kOrderOpening = 3;  // effort 1: variables of the factors min-fill's opening may create
 
 struct OrderScratch {
     // the request: relevant variables, and per relevant variable v the scope of its CPT without the evidence axes (f[v]) and
@@ -79,6 +85,10 @@ struct OrderScratch {
     // candidates
     uint8_t cand[128], best[128];
     int32_t n_cand, n_best;
+    // effort 1: the runner-up, and min-fill's order with the degree of every vertex when it was eliminated
+    uint8_t second[128], greedy[128], gdeg[128];
+    int32_t n_second, n_greedy;
+    double best_cost, second_cost;
 };
 
 MIBN_HD inline double order_pow2(int e) {  // 2^e, e >= 0
@@ -245,6 +255,7 @@ MIBN_HD inline bool order_greedy_impl(const OrderNet &net, OrderScratch &S, cons
                 }
             });
         }
+        S.gdeg[S.n_cand] = (uint8_t)b2_count(adj[best]);
         S.cand[S.n_cand++] = (uint8_t)best;
         alive.clr(best);
         created += kUniform ? order_pow2((int)ws[best]) : order_exp2(ws[best]);  // cells of the factor this elimination creates (its scope = the neighbours)
@@ -336,10 +347,10 @@ MIBN_HD inline void order_prepare(const OrderNet &net, OrderScratch &S, int nq, 
     hidden.b &= net.multi.b;
 }
 
-// The two sweep candidates into S.cand: which = 0 "meet" (down from the roots to the query's depth, then up from the
-// leaves), 1 = reverse topological.
-MIBN_HD inline void order_sweep(const OrderNet &net, OrderScratch &S, const B2 &hidden, int qdepth, int which) {
-    S.n_cand = 0;
+// The two sweep candidates into S.cand (behind its first n0 entries): which = 0 "meet" (down from the roots to depth `qdepth`, then up
+// from the leaves), 1 = reverse topological.
+MIBN_HD inline void order_sweep(const OrderNet &net, OrderScratch &S, const B2 &hidden, int qdepth, int which, int n0 = 0) {
+    S.n_cand = n0;
     auto filtered = [&](const int32_t *sorted_all, int lo_depth, int hi_depth) {
         for (int i = 0; i < net.n_vars; ++i) {
             const int v = sorted_all[i];
@@ -356,20 +367,40 @@ MIBN_HD inline void order_sweep(const OrderNet &net, OrderScratch &S, const B2 &
 }
 
 // The whole search for one request.  Fills S.best / S.n_best (hidden variables, first eliminated first) and returns the
-// modelled cost of that order (infinity when nothing is hidden).
+// modelled cost of that order (infinity when nothing is hidden).  net.effort >= 1: more candidates, and the runner-up in S.second /
+// S.n_second (0: none) with S.best_cost / S.second_cost.
 MIBN_HD inline double order_search(const OrderNet &net, OrderScratch &S, int nq, const int32_t *qvars, int ne, const int32_t *evars,
                                    bool no_prune) {
     B2 rel, hidden;
     order_prepare(net, S, nq, qvars, ne, evars, no_prune, rel, hidden);
     S.n_best = 0;
-    double best_cost = __builtin_inf();
+    S.n_second = 0;
+    S.n_greedy = 0;
+    double best_cost = __builtin_inf(), second_cost = __builtin_inf();
+    S.best_cost = S.second_cost = best_cost;
     if (!hidden.any()) return best_cost;
+    const bool two = net.effort >= 1;
+    auto same = [&](const uint8_t *a, int na, const uint8_t *b, int nb) {
+        if (na != nb) return false;
+        for (int i = 0; i < na; ++i)
+            if (a[i] != b[i]) return false;
+        return true;
+    };
     auto consider = [&]() {  // evaluates S.cand
-        const double c = order_simulate(net, S, S.cand, S.n_cand, best_cost);
+        const double c = order_simulate(net, S, S.cand, S.n_cand, two ? second_cost : best_cost);
         if (c < best_cost) {
+            if (two && S.n_best > 0) {
+                second_cost = best_cost;
+                S.n_second = S.n_best;
+                for (int i = 0; i < S.n_best; ++i) S.second[i] = S.best[i];
+            }
             best_cost = c;
             S.n_best = S.n_cand;
             for (int i = 0; i < S.n_cand; ++i) S.best[i] = S.cand[i];
+        } else if (two && c < second_cost && !same(S.cand, S.n_cand, S.best, S.n_best)) {
+            second_cost = c;
+            S.n_second = S.n_cand;
+            for (int i = 0; i < S.n_cand; ++i) S.second[i] = S.cand[i];
         }
     };
     int qdepth = 0x7fffffff;
@@ -386,9 +417,36 @@ MIBN_HD inline double order_search(const OrderNet &net, OrderScratch &S, int nq,
             if (hidden.test(sorted_all[i])) S.cand[S.n_cand++] = (uint8_t)sorted_all[i];
         consider();
     }
+    if (two && nq > 0)  // the two sweeps meet one level above and one below the query's
+        for (int d = -1; d <= 1; d += 2) {
+            if (qdepth + d < 0) continue;
+            order_sweep(net, S, hidden, qdepth + d, 0);
+            consider();
+        }
     // greedy min-fill: the best order on 60 % of the C3 requests (52.7 MB mean against 67.6 MB for the sweeps alone),
     // skipped where the sweeps already found a plan too cheap to be worth the time
-    if (best_cost > net.minfill_above * net.chain_weight && order_greedy(net, S, hidden, best_cost)) consider();
+    if (best_cost > net.minfill_above * net.chain_weight) {
+        const bool whole = order_greedy(net, S, hidden, two ? second_cost : best_cost);
+        if (two) {
+            S.n_greedy = S.n_cand;  // (aborted: what it had eliminated so far - the small eliminations come first)
+            for (int i = 0; i < S.n_cand; ++i) S.greedy[i] = S.cand[i];
+        }
+        if (whole) consider();
+        if (two) {
+            // min-fill's opening - its leading eliminations that create factors of at most kOrderOpening variables - then the meet sweep
+            // of the rest (wider openings add little: 2.0 / 1.7 / 1.6 / 1.3 % fewer bytes alone at 4 .. 7 against 5.4 % at 3)
+            int np = 0;
+            while (np < S.n_greedy && S.gdeg[np] <= kOrderOpening) ++np;
+            if (np > 0 && !(np == S.n_greedy && whole)) {
+                B2 rest = hidden;
+                for (int i = 0; i < np; ++i) { S.cand[i] = S.greedy[i]; rest.clr(S.greedy[i]); }
+                order_sweep(net, S, rest, qdepth, 0, np);
+                consider();
+            }
+        }
+    }
+    S.best_cost = best_cost;
+    S.second_cost = second_cost;
     return best_cost;
 }
 

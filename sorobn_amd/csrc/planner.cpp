@@ -210,6 +210,7 @@ OrderNet Network::order_view() const {
     o.minfill_above = minfill_above;
     o.chain_weight = (fuse && sweep >= 4 && order_weights) ? (order_weights == 1 ? 0.25 : 1.0 / (double)order_weights) : 1.0;  // (option value k > 1: weight 1 / k)
     o.big_cells = (double)small_cells;
+    o.effort = order_effort;
     return o;
 }
 
@@ -230,6 +231,7 @@ bool Network::wave_view(WNet &w) const {
     w.big_iters = ev.big_iters; w.tile_bytes = ev.tile_bytes;
     w.log2_small = ev.log2_small; w.log2_big = ev.log2_big;
     w.minfill_above = ov.minfill_above; w.chain_weight = ov.chain_weight; w.big_cells = ov.big_cells;
+    w.effort = ov.effort; w.second_above = second_above;
     // (the byte model runs on integers: 8 x the chain weight must be one, and the cost of an order stays below 2^53)
     if (!(ov.chain_weight == 1.0 || ov.chain_weight == 0.5 || ov.chain_weight == 0.25 || ov.chain_weight == 0.125)) return false;
     w.big_log2 = -1;
@@ -347,6 +349,8 @@ struct Scratch {
     std::vector<const PF *> ins;
     EmitScratch es;
     std::vector<int32_t> cand, best;   // candidate elimination orders (no per-request heap traffic)
+    std::vector<int32_t> second;       // the byte model's runner-up (order_effort >= 1)
+    std::vector<uint32_t> keep_words;  // the first order's program while the runner-up is emitted
 };
 Scratch &scratch() {
     static thread_local Scratch s;
@@ -554,6 +558,8 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     // candidate elimination orders, cheapest by the byte model wins
     std::vector<int32_t> &best = S.best, &cand = S.cand;
     best.clear();
+    std::vector<int32_t> &second = S.second;
+    second.clear();
     if (rq.n_order >= 0) {
         // the order was found by the device order search (same code, order_search.h)
         best.assign(rq.order, rq.order + rq.n_order);
@@ -562,6 +568,7 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
         OrderScratch &OS = order_scratch();
         order_search(net.order_view(), OS, rq.nq, rq.qvars, rq.ne, rq.evars, rq.no_prune);
         best.assign(OS.best, OS.best + OS.n_best);
+        if (net.order_effort >= 1 && OS.n_second > 0 && OS.best_cost >= net.second_above) second.assign(OS.second, OS.second + OS.n_second);
     } else if (hidden.any()) {
         std::vector<Bits> &scopes = S.scopes;
         std::vector<double> &scells = S.scope_cells;
@@ -622,7 +629,42 @@ static std::string plan_request_rec(const Network &net, const Request &rq, ProgB
     EmitProf &prof_ = g_host_emit_prof;
     prof_.t = __builtin_ia32_rdtsc();
 #endif
-    const int e = emit_run(en, ES, eb, es, rec, rq.nq, rq.qvars, rq.out_off, best.data(), (int)best.size() MIBN_PROF_PASS);
+    const size_t start_words = prog.size;
+    const EmitStats es0 = es;
+    const size_t rec_consts0 = rec ? rec->consts.size() : 0, rec_finals0 = rec ? rec->finals.size() : 0;
+    int e = emit_run(en, ES, eb, es, rec, rq.nq, rq.qvars, rq.out_off, best.data(), (int)best.size() MIBN_PROF_PASS);
+    if (!e && !second.empty()) {
+        // the runner-up of the byte model emitted too: the program that moves fewer bytes stays (the first on a tie, or if the
+        // second cannot be emitted)
+        std::vector<uint32_t> &keep = S.keep_words;
+        keep.assign(prog.data + start_words, prog.data + eb.size);
+        const EmitStats es_first = es;
+        PlanRecord rec_first;
+        if (rec) {
+            rec_first.consts.assign(rec->consts.begin() + rec_consts0, rec->consts.end());
+            rec_first.finals.assign(rec->finals.begin() + rec_finals0, rec->finals.end());
+            rec->consts.resize(rec_consts0);
+            rec->finals.resize(rec_finals0);
+        }
+        prog.size = start_words;
+        eb.data = prog.data; eb.size = prog.size; eb.cap = prog.cap;
+        es = es0;
+        int e2 = emit_begin(en, ES, rq.nq, rq.qvars, rq.ne, rq.evars, rq.ecodes, rq.no_prune);
+        if (!e2) e2 = emit_run(en, ES, eb, es, rec, rq.nq, rq.qvars, rq.out_off, second.data(), (int)second.size() MIBN_PROF_PASS);
+        if (e2 || !(es.alg_bytes - es0.alg_bytes < es_first.alg_bytes - es0.alg_bytes)) {
+            prog.size = start_words;
+            std::memcpy(prog.extend(keep.size()), keep.data(), keep.size() * sizeof(uint32_t));
+            es = es_first;
+            if (rec) {
+                rec->consts.resize(rec_consts0);
+                rec->finals.resize(rec_finals0);
+                rec->consts.insert(rec->consts.end(), rec_first.consts.begin(), rec_first.consts.end());
+                rec->finals.insert(rec->finals.end(), rec_first.finals.begin(), rec_first.finals.end());
+            }
+        } else if (st.order) {
+            *st.order = second;
+        }
+    }
     st.alg_bytes = es.alg_bytes; st.alg_flops = es.alg_flops; st.n_steps = es.n_steps; st.max_step_cells = es.max_step_cells;
     st.arena_cells = es.arena_cells; st.out_cells = es.out_cells;
     return emit_error_message(e);
@@ -862,7 +904,7 @@ uint64_t option_signature(const Network &net) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
     mix((uint64_t)net.small_cells); mix((uint64_t)net.big_iters); mix((uint64_t)net.tile_h); mix((uint64_t)net.fuse);
-    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_min); mix((uint64_t)net.sweep_adapt); mix((uint64_t)net.order_weights); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
+    mix((uint64_t)net.chain); mix((uint64_t)net.sweep); mix((uint64_t)net.sweep_iters); mix((uint64_t)net.sweep_min); mix((uint64_t)net.sweep_adapt); mix((uint64_t)net.order_weights); mix((uint64_t)net.order_effort); mix((uint64_t)net.second_above); mix((uint64_t)net.hint_sorted.size()); mix((uint64_t)net.sweep_canon); mix((uint64_t)net.outer); mix((uint64_t)net.prune); mix((uint64_t)net.minfill_above);
     mix((uint64_t)net.hints.size()); mix((uint64_t)net.tile_bytes);
     return h;
 }

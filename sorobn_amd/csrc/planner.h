@@ -70,6 +70,8 @@ struct Network {
     int builtin_sweeps = 1;  // two depth-first topological orders (grid: row- and column-major) as candidate orders next to the host's
                              // hints: -2 % bytes on C3.  Off in round 2 (no measurable time then); with round 3's kernels the bytes
                              // show: 269 -> 278 k queries/s, 4 ms more planning per 32 768 requests (profiles/r03_j_orders.log)
+    int order_effort = 0;    // 1: more candidate orders, and the two the byte model ranks first both emitted where the first costs more than second_above (order_search.h)
+    double second_above = 1e7;  // modelled bytes of the best order above which the runner-up is emitted too (order_effort >= 1)
     int order_weights = 1;   // compare candidate orders with single-table eliminations at a quarter of their bytes (order_search.h)
     int sweep_canon = 1;     // 0 (test hook): never flag a SWEEP step canonical - the kernel's general path runs everything
 

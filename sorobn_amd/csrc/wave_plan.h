@@ -67,6 +67,7 @@ constexpr int kWCsr = 384;     // scope entries of all CPTs together
 constexpr int kWAxes = 24;     // axes of a factor / of a step before merging
 constexpr int kWEnt = 24;      // created factors alive at once (+ the inputs of the step in flight)
 constexpr int kWSims = 4;      // candidate orders simulated side by side
+constexpr int kWCands = kWHints + 6;  // meet, reverse, the hints, (effort 1: the meet sweeps a level up and down,) min-fill, (its opening + meet)
 constexpr int kWSimEnt = 24;   // factors alive at once in a simulation
 constexpr int kWTags = 56;     // work items of a request
 constexpr int kWBlocks = 32;   // free blocks of the arena (the host's list holds Arena::kMaxBlocks = 64: a request that would need more goes to the host)
@@ -89,7 +90,8 @@ struct WNet {
     int32_t small_cells, prune, outer, fuse, chain, sweep, sweep_min, sweep_canon, tile_h, sweep_iters;
     int64_t big_iters, tile_bytes;
     double log2_small, log2_big, minfill_above, chain_weight, big_cells;
-    int32_t big_log2, pad_;  // big_cells = 2^big_log2 (-1: not a power of two)
+    double second_above;     // effort 1: modelled bytes of the best order above which the runner-up is emitted too
+    int32_t big_log2, effort;  // big_cells = 2^big_log2 (-1: not a power of two); OrderNet::effort
     uint32_t pool_off[kWVars];
     int32_t scope_stride[kWCsr];
     uint16_t card[kWVars], scope_off[kWVars + 1];
@@ -113,6 +115,7 @@ struct WGreedy {
     B2S adj[kWVars];
     uint64_t key[kWVars];
     int32_t miss[kWVars];
+    uint8_t gdeg[kWVars];  // effort 1: the degree of every vertex when it was eliminated (OrderScratch::gdeg)
 };
 struct WStage { int32_t cout, ns, nctrl, loop, f[3], t_off, t_cells, src[3], newv, cvar[3]; uint8_t in[kSweepMaxSmall]; };
 
@@ -125,9 +128,9 @@ struct WState {
     uint32_t cpt_cells[kWVars], cpt_off[kWVars];
     union {
         struct {  // order search
-            uint8_t cand[kWHints + 3][kWVars];  // meet, reverse, the hints, min-fill
-            int32_t n_cand[kWHints + 3];
-            double cost[kWHints + 3];
+            uint8_t cand[kWCands][kWVars];
+            int32_t n_cand[kWCands];
+            double cost[kWCands];
             union {
                 WSim sim[kWSims];
                 WGreedy g;
@@ -182,6 +185,8 @@ struct WOrderCtx {
     B2 rel, hidden, keep;  // keep = the variables that can be axes (multi-state, not evidence)
     bool overflow = false;
     int l;
+    double best_cost_ = 0;  // of the order in W.order
+    int second_ = -1;       // effort 1: the runner-up's slot in W.o.cand (-1: none) - valid until the emission takes the memory
     WV_HD WOrderCtx(const WNet &n, WState &w) : N(n), W(w), l(n.uniform_log2) {}
 
     WV_HD double cells_of(const B2 &u) const { return order_pow2(l * b2_count(u)); }
@@ -305,12 +310,12 @@ struct WOrderCtx {
         for (int it = 0; it < total; ++it) {
             const uint64_t kbest = wv::min_u64_n(nv, [&](int x) { return alive.test(x) ? G.key[x] : ~0ull; });
             const int best = (int)(kbest & 0xff);
-            WV_LANE0 cand[n] = (uint8_t)best;
+            const B2 nb = G.adj[best];
+            WV_LANE0 { cand[n] = (uint8_t)best; G.gdeg[n] = (uint8_t)b2_count(nb); }
             ++n;
             alive.clr(best);
-            const B2 nb = G.adj[best];
             created += order_pow2(l * b2_count(nb));  // (= ws[best]: l x degree, kept current for every live vertex)
-            if (16.0 * N.chain_weight * created > abort_above) { wv::sync(); return false; }
+            if (16.0 * N.chain_weight * created > abort_above) { WV_LANE0 W.o.n_cand[slot] = n; wv::sync(); return false; }
             // every common neighbour z of a pair (y, u) of nb that becomes adjacent loses that pair (two ordered pairs) from its count
             wv::for_n(nv, [&](int z) {
                 if (!rel.test(z) || nb.test(z) || z == best) return;
@@ -366,7 +371,8 @@ struct WOrderCtx {
         int qdepth = 0x7fffffff;
         for (int i = 0; i < nq; ++i) qdepth = (int)N.depth[qvars[i]] < qdepth ? (int)N.depth[qvars[i]] : qdepth;
         const int kNoDepth = 0x7fffffff;
-        // the sweeps: meet, reverse, the hints
+        // the sweeps: meet, reverse, the hints (effort 1: the meet sweep a level above and a level below the query's)
+        const bool two = N.effort >= 1;
         int nc = 0;
         {
             int n = filtered(W.o.cand[0], 0, N.topo_asc, 0, qdepth);
@@ -380,27 +386,77 @@ struct WOrderCtx {
                 WV_LANE0 W.o.n_cand[nc] = n;
                 ++nc;
             }
+            if (two && nq > 0)
+                for (int d = -1; d <= 1; d += 2) {
+                    if (qdepth + d < 0) continue;
+                    n = filtered(W.o.cand[nc], 0, N.topo_asc, 0, qdepth + d);
+                    n = filtered(W.o.cand[nc], n, N.topo_desc, qdepth + d, kNoDepth);
+                    WV_LANE0 W.o.n_cand[nc] = n;
+                    ++nc;
+                }
         }
         wv::sync();
         WV_TICK(0)  // relevant set, candidate sweeps
         for (int c0 = 0; c0 < nc; c0 += kWSims) simulate_batch(c0, c0 + kWSims < nc ? c0 + kWSims : nc);
         WV_TICK(1)  // byte model of the sweeps
         if (overflow) return -1;
-        double best_cost = __builtin_inf();
-        int best = -1;
-        for (int c = 0; c < nc; ++c)
-            if (W.o.cost[c] < best_cost) { best_cost = W.o.cost[c]; best = c; }
+        // the best and (effort 1) the runner-up - the cheapest candidate whose ORDER differs from the best's - in the host's
+        // sequence of candidates: the first of equals wins (order_search's consider())
+        auto same_order = [&](int a, int b) {
+            if (W.o.n_cand[a] != W.o.n_cand[b]) return false;
+            return !wv::any_n(W.o.n_cand[a], [&](int i) { return W.o.cand[a][i] != W.o.cand[b][i]; });
+        };
+        double best_cost = __builtin_inf(), second_cost = __builtin_inf();
+        int best = -1, second = -1;
+        auto rank = [&](int c0, int c1) {
+            for (int c = c0; c < c1; ++c) {
+                const double cost = W.o.cost[c];
+                if (cost < best_cost) {
+                    if (two && best >= 0) { second_cost = best_cost; second = best; }
+                    best_cost = cost;
+                    best = c;
+                } else if (two && cost < second_cost && !same_order(c, best)) {
+                    second_cost = cost;
+                    second = c;
+                }
+            }
+        };
+        rank(0, nc);
         // greedy min-fill where the sweeps cost more than minfill_above
         if (best_cost > N.minfill_above * N.chain_weight) {
-            const bool can_win = greedy(nc, best_cost);
+            const bool whole = greedy(nc, two ? second_cost : best_cost);
             WV_TICK(2)  // min-fill
-            if (can_win) {
-                simulate_batch(nc, nc + 1);
-                WV_TICK(3)  // its byte model
+            int n_new = whole ? 1 : 0;
+            if (two) {
+                // min-fill's opening (its leading eliminations that create factors of at most kOrderOpening variables), then the
+                // meet sweep of the rest - built before the simulations take the greedy state's memory
+                const int ng = W.o.n_cand[nc];
+                const uint64_t small = wv::mask64(ng < 64 ? ng : 64, [&](int i) { return W.o.g.gdeg[i] <= kOrderOpening; });
+                // (an opening is a handful of eliminations; 64 or more of them in a row: the request goes to the host)
+                if (small == ~0ull) return -1;
+                const int np = (int)__builtin_ctzll(~small);
+                if (np > 0 && !(np == ng && whole)) {
+                    const int slot = nc + n_new;  // (an aborted min-fill order is no candidate: the opening is built in place)
+                    const B2 all_hidden = hidden;
+                    if (slot != nc) wv::for_n(np, [&](int i) { W.o.cand[slot][i] = W.o.cand[nc][i]; });
+                    for (int i = 0; i < np; ++i) hidden.clr(W.o.cand[nc][i]);
+                    int n = filtered(W.o.cand[slot], np, N.topo_asc, 0, qdepth);
+                    n = filtered(W.o.cand[slot], n, N.topo_desc, qdepth, kNoDepth);
+                    WV_LANE0 W.o.n_cand[slot] = n;
+                    hidden = all_hidden;
+                    ++n_new;
+                    wv::sync();
+                }
+            }
+            if (n_new) {
+                simulate_batch(nc, nc + n_new);
+                WV_TICK(3)  // their byte model
                 if (overflow) return -1;
-                if (W.o.cost[nc] < best_cost) best = nc;
+                rank(nc, nc + n_new);
             }
         }
+        best_cost_ = best_cost;
+        second_ = second;
         const int nb = W.o.n_cand[best];
         wv::for_n(nb, [&](int i) { W.order[i] = W.o.cand[best][i]; });
         wv::sync();
@@ -1842,6 +1898,10 @@ struct WEmit {
 
 // One request, start to finish: order search, then emission into `slot` (cap words).  `anc` = the network's ancestor sets (global
 // memory: read once per query / evidence variable).  Fills R; the work items are in W.e.tags[0..R.n_tags).
+// effort 1: words parked behind the usable part of a request's slot while two orders are emitted - the runner-up's order (a byte per
+// variable) and the first program's work items
+constexpr uint32_t kWStashOrderWords = kWVars / 4, kWStashWords = kWStashOrderWords + kWTags * (uint32_t)(sizeof(Tag) / 4);
+
 WV_HD void wave_plan_request(const WNet &N, WState &W, const B2 *anc, int nq, const int32_t *qvars, int ne, const int32_t *evars,
                              const int32_t *ecodes, bool no_prune, int64_t out_off, uint32_t *slot, uint32_t cap, WResult &R WV_PROF_ARG) {
     WOrderCtx oc(N, W);
@@ -1852,17 +1912,70 @@ WV_HD void wave_plan_request(const WNet &N, WState &W, const B2 *anc, int nq, co
     if (n_best < 0) { R.err = kEmitErrDevice; return; }
     B2 eb;
     for (int i = 0; i < ne; ++i) eb.set(evars[i]);
+    // effort 1 (plan_request_rec): where the best order is expensive the runner-up is emitted too, behind the first program in the same slot,
+    // and the program that moves fewer bytes stays.  Its order waits behind the usable part of the slot (the search's memory is the emission's).
+    const bool try_second = N.effort >= 1 && oc.second_ >= 0 && oc.best_cost_ >= N.second_above;
+    int n_second = 0;
+    uint32_t *stash = nullptr;
+    if (try_second) {
+        if (cap < kWStashWords + 4 * (uint32_t)kMaxStepWords) { R.err = kEmitErrWords; return; }
+        cap -= kWStashWords;
+        stash = slot + cap;
+        n_second = W.o.n_cand[oc.second_];
+        uint8_t *so = reinterpret_cast<uint8_t *>(stash);
+        const uint8_t *src = W.o.cand[oc.second_];
+        wv::for_n(n_second, [&](int i) { so[i] = src[i]; });
+        wv::sync();
+    }
     // (hidden as emit_begin has it: the multi-state variables only - single-state ones are never axes, never eliminated)
-    WEmit em(N, W, slot, cap);
-    int err = em.begin(ne, evars, ecodes, oc.rel, oc.keep, eb);
-    WV_TICK(4)  // CPT slices
-    if (!err) err = em.run(nq, qvars, out_off, n_best WV_PROF_PASS);
-    R.err = err;
-    R.words = em.size;
-    R.n_tags = (uint32_t)em.n_tags;
-    wv::sync();
-    R.alg_bytes = W.e.c.alg_bytes; R.alg_flops = W.e.c.alg_flops; R.n_steps = W.e.c.n_steps; R.max_step_cells = W.e.c.max_step_cells;
-    R.arena_cells = em.top;
+    constexpr uint32_t kTagWords = sizeof(Tag) / 4;
+    uint32_t *tag_stash = stash ? stash + kWStashOrderWords : nullptr;
+    uint32_t base = 0;  // words of the first program (the second one is emitted behind it)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll  // (ONE copy of the emitter in the kernel)
+#endif
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            // the first program's work items leave the emission's memory, the runner-up's order comes back
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(W.e.tags);
+            wv::for_n((int)(R.n_tags * kTagWords), [&](int i) { tag_stash[i] = src[i]; });
+            wv::gsync();
+            const uint8_t *so = reinterpret_cast<const uint8_t *>(stash);
+            wv::for_n(n_second, [&](int i) { W.order[i] = so[i]; });
+            wv::sync();
+        }
+        WEmit em(N, W, slot + base, cap - base);
+        int err = em.begin(ne, evars, ecodes, oc.rel, oc.keep, eb);
+        WV_TICK(4)  // CPT slices
+        if (!err) err = em.run(nq, qvars, out_off, pass ? n_second : n_best WV_PROF_PASS);
+        wv::sync();
+        if (pass == 0) {
+            R.err = err;
+            R.words = em.size;
+            R.n_tags = (uint32_t)em.n_tags;
+            R.alg_bytes = W.e.c.alg_bytes; R.alg_flops = W.e.c.alg_flops; R.n_steps = W.e.c.n_steps; R.max_step_cells = W.e.c.max_step_cells;
+            R.arena_cells = em.top;
+            if (err || !try_second) return;
+            base = R.words;
+            continue;
+        }
+        // what only the device's limits refuse is not "the second order cannot be emitted": the request (its chunk, for the slot size) goes to the host
+        if (err == kEmitErrDevice || err == kEmitErrWords) { R.err = err; return; }
+        if (!err && W.e.c.alg_bytes < R.alg_bytes) {
+            const uint32_t words_b = em.size;
+            wv::gsync();
+            const uint32_t *src = slot + base;
+            for (uint32_t i = (uint32_t)wv::lane(); i < words_b; i += (uint32_t)wv::kWidth) slot[i] = src[i];  // (ascending: the ranges may overlap)
+            R.words = words_b;
+            R.n_tags = (uint32_t)em.n_tags;
+            R.alg_bytes = W.e.c.alg_bytes; R.alg_flops = W.e.c.alg_flops; R.n_steps = W.e.c.n_steps; R.max_step_cells = W.e.c.max_step_cells;
+            R.arena_cells = em.top;
+        } else {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(W.e.tags);
+            wv::for_n((int)(R.n_tags * kTagWords), [&](int i) { dst[i] = tag_stash[i]; });
+            wv::sync();
+        }
+    }
 }
 
 }  // namespace mibn

@@ -33,7 +33,7 @@ struct WavePlanArgs {
     uint32_t prog_stride;
     EmitMeta *meta;                          // [B]
     Tag *tags;                               // [tag_cap]
-    uint32_t *tag_cursor;
+    uint32_t *tag_cursor;                    // [0] work items handed out, [1] requests handed out (both zeroed by reset_cursor_kernel)
     uint32_t tag_cap;
 };
 constexpr int kWaveWG = 4;  // waves (requests) per workgroup
@@ -44,7 +44,7 @@ struct WaveReq { int32_t q[kWaveMaxQ], e[kWaveMaxE], c[kWaveMaxE]; };
 __device__ unsigned long long g_wave_prof[24];  // ticks per phase, summed over the waves (WV_TICK in wave_plan.h)
 #endif
 
-__global__ void reset_cursor_kernel(uint32_t *cursor) { *cursor = 0; }
+__global__ void reset_cursor_kernel(uint32_t *cursor) { cursor[0] = 0; cursor[1] = 0; }
 
 #ifndef MIBN_WAVE_MIN_WGS
 #define MIBN_WAVE_MIN_WGS 4  // workgroups per CU the register budget allows (4: 128 VGPRs - 270 spilled, still the fastest: 11.0 ms per chunk against 13.8 at 3, profiles/r06_v_occupancy.log; LDS: 39.6 KB per workgroup)
@@ -61,8 +61,16 @@ __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_ker
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
-    // (a grid smaller than the chunk - option wave_wgs - walks it: the workgroup keeps its copy of the network, the launch its footprint)
-    for (int64_t b = (int64_t)blockIdx.x * kWaveWG + wave; b < A.B; b += (int64_t)gridDim.x * kWaveWG) {
+    // Every wave takes the next request when it is done with its own (a counter): requests differ by a factor of ten in planning time - and
+    // by two more where two orders are emitted - and a workgroup of four fixed requests would hold its LDS until the slowest is through.
+    // The grid is what the chip holds at once; the workgroup keeps its copy of the network.
+    // (Every lane adds - lane 0 one, the others nothing - and lane 0's result is the wave's: written as "if (lane == 0) x = atomicAdd(..)"
+    //  with x = 0 for the others, the compiler threads the constant into the other lanes' path behind the readfirstlane, the loop becomes
+    //  divergent and the lanes of a wave run different requests.  Measured: profiles/NOTES_r06.md, session AX.)
+    for (;;) {
+        const uint32_t next = atomicAdd(A.tag_cursor + 1, lane == 0 ? 1u : 0u);
+        const int64_t b = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        if (b >= A.B) break;
         EmitMeta m;
         m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
         m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
@@ -97,8 +105,7 @@ __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_ker
     #endif
         int err = R.err;
         if (!err) {
-            uint32_t first = 0;
-            if (lane == 0) first = atomicAdd(A.tag_cursor, R.n_tags);
+            uint32_t first = atomicAdd(A.tag_cursor, lane == 0 ? R.n_tags : 0u);  // (every lane adds, see above)
             first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
             if (first + R.n_tags <= A.tag_cap) {
                 // (the lanes copy the items a dword each)

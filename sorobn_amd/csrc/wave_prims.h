@@ -28,6 +28,13 @@ __device__ inline void sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// the same for GLOBAL memory the wave wrote and reads back itself (the runner-up's order and the first program's work items parked behind the
+// program slot, wave_plan_request): the stores have left the wave before any lane loads
+__device__ inline void gsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // a value every lane holds alike, told to the compiler (scalar registers, scalar branches)
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -113,6 +120,7 @@ template <class P, class E> __device__ inline int compact_n(int n, int base, P p
 constexpr int kWidth = 1;
 inline int lane() { return 0; }
 inline void sync() {}
+inline void gsync() {}
 template <class T> inline T uni(T v) { return v; }
 
 template <class F> inline void for_n(int n, F f) {

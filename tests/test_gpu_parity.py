@@ -531,8 +531,11 @@ def test_schedule_and_effort_options_do_not_change_answers(amd):
     assert float(np.max(np.abs(sweeps - base))) <= 1e-12
 
 
-def test_device_planner_writes_the_host_programs(amd):
-    """Option gpu_emit: whole chunks are planned on the device - order_kernel, then emit_kernel: one request per lane runs
+@pytest.mark.parametrize("order_effort", [0, 1])
+def test_device_planner_writes_the_host_programs(amd, order_effort):
+    """(order_effort 1: more candidate orders and the byte model's best two both emitted where the best is expensive - the wave planner
+    has it, order_kernel / emit_kernel do not: with wave_plan = 0 the host plans those streams.)
+    Option gpu_emit: whole chunks are planned on the device - order_kernel, then emit_kernel: one request per lane runs
     the very code of csrc/emit_core.h that the host's planning workers run, and writes the step program into the chunk's
     device buffer.  Mode 2 makes the engine plan every chunk on the host as well and compare programs, work items and
     statistics word for word (an error otherwise); the posteriors are then the host-planned ones bit for bit - on the C3
@@ -541,6 +544,7 @@ def test_device_planner_writes_the_host_programs(amd):
     spec = netspec.grid_spec(10, 10, 4, seed=0)
     bn = netspec.build(spec, amd.BayesNet)
     be = bn.backend
+    be.engine.set_option("order_effort", order_effort)
     q, ev, ec = netspec.c3_requests(100, 4, 6144, 4, seed=1)
     to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
     host = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
@@ -578,6 +582,7 @@ def test_device_planner_writes_the_host_programs(amd):
         be.engine.set_option("plan_waves", waves)
         assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), host), (lanes, waves)
     be.engine.set_option("wave_plan", 1)
+    assert np.array_equal(be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec), host)
     names = [k["name"] for k in be.engine.kernel_stats()]
     assert "order_kernel+emit_kernel" in names and "ve_sweep_dma_kernel" in names
     be.engine.set_option("gpu_emit", 2)

@@ -30,7 +30,7 @@ def lib(name):
     return _libs[name]
 
 
-def both_programs(L, f, q, ev, codes, options, no_prune=0):
+def both_programs(L, f, q, ev, codes, options, no_prune=0, effort=(0, 1e7)):
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
     hints = np.ascontiguousarray(np.stack(f.hints).reshape(-1) if f.hints else [0], np.int32)
     q = np.ascontiguousarray(q, np.int32)
@@ -44,6 +44,7 @@ def both_programs(L, f, q, ev, codes, options, no_prune=0):
     L.plan_sim_set_sweep(int(sweep))
     L.plan_sim_set_sweep_min(int(sweep_min))
     L.plan_sim_set_prune(1)
+    L.plan_sim_set_order_effort(C.c_int(int(effort[0])), C.c_double(float(effort[1])))
     res = []
     for fn in (L.plan_sim_program_tags, L.wave_plan_program):
         out, tags, stats = np.zeros(1 << 16, np.uint32), np.zeros(4 * 256, np.uint32), np.zeros(6)
@@ -90,7 +91,22 @@ def test_wave_planner_writes_the_host_programs_on_the_c3_streams(libname):
         if host[0] > 0:
             assert same(host, wave), i
             n_checked += 1
+    # order_effort 1 (order_search.h: more candidate orders, the runner-up emitted too where the best is expensive - second_above 1e7 bytes
+    # by default, 0 here as well: every request emits both): the wave planner's second emission, its parked order and work items
+    n_effort = 0
+    for n_ev, n_req, effort in ((4, 300, (1, 1e7)), (4, 150, (1, 0.0)), (8, 150, (1, 1e7)), (16, 150, (1, 0.0)), (1, 100, (1, 0.0))):
+        q, ev, ec = netspec.c3_requests(100, 4, n_req, n_ev, seed=21 + n_ev)
+        for i in range(n_req):
+            host, wave = both_programs(L, f, [to_var[q[i]]], to_var[ev[i]], ec[i], DEFAULT, effort=effort)
+            assert host[0] > 0 and same(host, wave), (n_ev, i, effort, host[0], wave[0])
+            n_effort += 1
+    # (and it moves fewer bytes than effort 0 on the same requests)
+    q, ev, ec = netspec.c3_requests(100, 4, 200, 4, seed=25)
+    b0 = sum(both_programs(L, f, [to_var[q[i]]], to_var[ev[i]], ec[i], DEFAULT)[0][3][0] for i in range(200))
+    b1 = sum(both_programs(L, f, [to_var[q[i]]], to_var[ev[i]], ec[i], DEFAULT, effort=(1, 1e7))[0][3][0] for i in range(200))
+    assert b1 < 0.97 * b0, (b0, b1)
     assert beyond <= 0.1 * n_checked, (beyond, n_checked)
+    print(f"{libname}: {n_effort} requests at order_effort 1 word for word, {100 * (1 - b1 / b0):.1f} % fewer bytes than effort 0")
     print(f"{libname}: {n_checked} C3 requests, programs / work items / statistics word for word; {beyond} beyond a device limit under non-default options")
 
 

@@ -46,6 +46,8 @@ int main(int argc, char **argv) {
     std::vector<int32_t> hint(n);
     for (int v = 0; v < n; ++v) hint[v] = v;
     net.set_hints(1, hint.data());
+    if (const char *s_ = std::getenv("ORDER_EFFORT")) net.order_effort = atoi(s_);  // 1: more candidate orders, the best two emitted where the best is expensive
+    if (const char *s_ = std::getenv("SECOND_ABOVE")) net.second_above = atof(s_);
     WNet *wn = new WNet;
     if (!net.wave_view(*wn)) { printf("network outside the wave planner's coverage\n"); return 1; }
     std::vector<int64_t> q_off(B + 1), e_off(B + 1), out_off(B + 1);
@@ -63,7 +65,7 @@ int main(int argc, char **argv) {
         for (int k = 0; k < NE; ++k) { ev[NE * b + k] = pick[1 + k]; ec[NE * b + k] = (int)(rng() % K); }
     }
     for (int64_t b = 0; b <= B; ++b) { q_off[b] = b; e_off[b] = NE * b; out_off[b] = 4 * b; }
-    const uint32_t stride = 6144;
+    const uint32_t stride = net.order_effort ? 12288 : 6144;
     const size_t tag_cap = (size_t)B * 64;
     WNet *d_net; B2 *d_anc; int64_t *d_qo, *d_eo, *d_oo; int32_t *d_qv, *d_ev, *d_ec; char *d_skip; uint32_t *d_prog, *d_cursor; EmitMeta *d_meta; Tag *d_tags;
     CHECK(hipMalloc(&d_net, sizeof(WNet))); CHECK(hipMemcpy(d_net, wn, sizeof(WNet), hipMemcpyHostToDevice));
@@ -81,7 +83,7 @@ int main(int argc, char **argv) {
     A.net = d_net; A.anc = d_anc; A.q_off = d_qo; A.e_off = d_eo; A.out_off = d_oo; A.q_vars = d_qv; A.e_vars = d_ev; A.e_codes = d_ec; A.skip = d_skip;
     A.B = B; A.flags = 0; A.prog = d_prog; A.prog_stride = stride; A.meta = d_meta; A.tags = d_tags; A.tag_cursor = d_cursor; A.tag_cap = (uint32_t)tag_cap;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    const unsigned grid = (unsigned)((B + kWaveWG - 1) / kWaveWG);
+    const unsigned grid = (unsigned)std::min<int64_t>((B + kWaveWG - 1) / kWaveWG, std::getenv("WAVE_WGS") ? atoll(std::getenv("WAVE_WGS")) : 256 * MIBN_WAVE_MIN_WGS);  // (the waves draw requests from a counter: what the chip holds at once)
     float best_ms = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
         hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, 0, d_cursor);

@@ -38,6 +38,8 @@ int main(int argc, char **argv) {
     std::string e = net.set(n, card.data(), scope_off.data(), scope_vars.data(), value_off.data(), values.data());
     if (!e.empty()) { std::fprintf(stderr, "%s\n", e.c_str()); return 1; }
     if (const char *s = std::getenv("MINFILL_ABOVE")) net.minfill_above = atof(s);
+    if (const char *s = std::getenv("ORDER_EFFORT")) net.order_effort = atoi(s);
+    if (const char *s = std::getenv("SECOND_ABOVE")) net.second_above = atof(s);
     std::vector<int32_t> hint(n);
     for (int v = 0; v < n; ++v) hint[v] = v;
     net.set_hints(1, hint.data());
@@ -78,7 +80,7 @@ int main(int argc, char **argv) {
         if (!pe.empty()) { std::printf("request %lld: host planner: %s\n", (long long)b, pe.c_str()); ++bad; continue; }
         std::vector<Tag> htags;
         tag_program(net.emit_view(), hp.data(), [&](const Tag &t) { htags.push_back(t); });
-        std::vector<uint32_t> slot(8192 + kMaxStepWords, 0xdeadbeefu);
+        std::vector<uint32_t> slot(2 * 8192 + kWStashWords + 4 * kMaxStepWords, 0xdeadbeefu);
         WResult R;
         wave_plan_request(*wn, *ws, net.anc2.data(), 1, qv, NE, ev, ec, false, 4 * b, slot.data(), (uint32_t)slot.size(), R);
         bool same = R.err == 0 && R.words == hp.size() && std::memcmp(slot.data(), hp.data(), hp.size() * 4) == 0;
