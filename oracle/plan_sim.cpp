@@ -684,7 +684,7 @@ extern "C" int64_t wave_plan_program(int32_t n_vars, const int32_t *card, const 
     if (R.err == kEmitErrDevice) return -4;
     if (R.err) { g_err = emit_error_message(R.err); return -5; }
     if ((int64_t)R.words > cap || (int64_t)R.n_tags > tags_cap) return -2;
-    std::memcpy(out, slot.data(), (size_t)R.words * 4);
+    std::memcpy(out, slot.data() + R.base, (size_t)R.words * 4);
     std::memcpy(tags_out, ws->e.tags, (size_t)R.n_tags * sizeof(Tag));
     stats[0] = R.alg_bytes; stats[1] = R.alg_flops; stats[2] = R.n_steps; stats[3] = R.max_step_cells; stats[4] = (double)R.arena_cells; stats[5] = (double)R.n_tags;
     return (int64_t)R.words;

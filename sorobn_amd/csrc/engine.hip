@@ -121,7 +121,7 @@ __global__ __launch_bounds__(MIBN_PLAN_WG, MIBN_EMIT_WAVES_PER_EU) void emit_ker
     if (pos >= A.B) return;
     const int64_t b = A.perm ? A.perm[pos] : pos;
     EmitMeta m;
-    m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
+    m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0; m.prog_first = 0; m.pad_ = 0;
     m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
     m.arena_cells = 0;
     uint32_t *slot = A.prog + (size_t)b * A.prog_stride;
@@ -1223,7 +1223,7 @@ int plan_on_device_collect(mibn_ctx *h, int64_t b0, int64_t n, BatchPlan &ck, do
             refused = true; beyond = true; continue;
         }
         if (m.err) { h->err = "request " + std::to_string(b0 + i) + ": " + emit_error_message(m.err); return MIBN_E_LIMIT; }
-        ck.prog_off[i] = (uint64_t)i * stride;
+        ck.prog_off[i] = (uint64_t)i * stride + m.prog_first;
         ck.local_off[i] = ck.prog_off[i];
         ck.tag_first[i] = m.tag_first;
         ck.tag_count[i] = m.n_tags;
@@ -1732,13 +1732,16 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                        (flags & MIBN_Q_NOPRUNE) != 0, nullptr, nullptr);
             if (!ref.err.empty()) { h->err = ref.err; return bail(MIBN_E_LIMIT); }
             for (int64_t i = 0; i < n; ++i) {
-                const uint32_t *hw = st.bufs[ref.thread_of[i]].data + ref.local_off[i], *dw = dev.data() + (size_t)i * stride;
+                const uint32_t *hw = st.bufs[ref.thread_of[i]].data + ref.local_off[i], *dw = dev.data() + (size_t)ck.prog_off[(size_t)i];  // (= i x stride + the words in front of the program)
                 size_t words = 1;
                 for (uint32_t k = 0; k < hw[0]; ++k) words += hw[words + 6];
                 for (size_t k = 0; k < words; ++k)
                     if (hw[k] != dw[k]) {
-                        h->err = "device planner: request " + std::to_string(b0 + i) + " word " + std::to_string(k) + " of " + std::to_string(words) + ": host " +
-                                 std::to_string(hw[k]) + " device " + std::to_string(dw[k]);
+                        size_t off = 1, step = 0;  // (which step holds the word)
+                        while (step + 1 < hw[0] && off + hw[off + 6] <= k) { off += hw[off + 6]; ++step; }
+                        h->err = "device planner: request " + std::to_string(b0 + i) + " word " + std::to_string(k) + " of " + std::to_string(words) + " (step " + std::to_string(step) + " of " +
+                                 std::to_string(hw[0]) + ", kind " + std::to_string(hw[off] & 0xff) + ", word " + std::to_string(k - off) + " of the step's " + std::to_string(hw[off + 6]) + "): host " +
+                                 std::to_string(hw[k]) + " device " + std::to_string(dw[k]) + "; device program " + std::to_string(dw[0]) + " steps";
                         return bail(MIBN_E_STATE);
                     }
                 const Tag *ht = ref.tags[ref.thread_of[i]].data() + ref.tag_first[i], *dt = ck.tags[(size_t)ck.thread_of[i]].data() + ck.tag_first[i];

@@ -158,6 +158,7 @@ struct WState {
 // what the kernel hands back per request (EmitMeta of engine.hip, field for field)
 struct WResult {
     uint32_t words, n_tags;
+    uint32_t base;  // words of the slot in front of the program (effort 1: the runner-up's program, where it won, stays behind the first one)
     int32_t err;
     double alg_bytes, alg_flops, n_steps, max_step_cells;
     int64_t arena_cells;
@@ -1906,7 +1907,7 @@ WV_HD void wave_plan_request(const WNet &N, WState &W, const B2 *anc, int nq, co
                              const int32_t *ecodes, bool no_prune, int64_t out_off, uint32_t *slot, uint32_t cap, WResult &R WV_PROF_ARG) {
     WOrderCtx oc(N, W);
     const int n_best = oc.search(nq, qvars, ne, evars, anc, no_prune WV_PROF_PASS);
-    R.words = 1; R.n_tags = 0; R.err = 0;
+    R.words = 1; R.n_tags = 0; R.err = 0; R.base = 0;
     R.alg_bytes = R.alg_flops = R.n_steps = R.max_step_cells = 0;
     R.arena_cells = 0;
     if (n_best < 0) { R.err = kEmitErrDevice; return; }
@@ -1957,16 +1958,15 @@ WV_HD void wave_plan_request(const WNet &N, WState &W, const B2 *anc, int nq, co
             R.arena_cells = em.top;
             if (err || !try_second) return;
             base = R.words;
+            // (the emitter parks an overflowing step kMaxStepWords below the end of its buffer: the second program needs at least that much)
+            if (cap - base < 2 * (uint32_t)kMaxStepWords) { R.err = kEmitErrWords; return; }
             continue;
         }
         // what only the device's limits refuse is not "the second order cannot be emitted": the request (its chunk, for the slot size) goes to the host
         if (err == kEmitErrDevice || err == kEmitErrWords) { R.err = err; return; }
         if (!err && W.e.c.alg_bytes < R.alg_bytes) {
-            const uint32_t words_b = em.size;
-            wv::gsync();
-            const uint32_t *src = slot + base;
-            for (uint32_t i = (uint32_t)wv::lane(); i < words_b; i += (uint32_t)wv::kWidth) slot[i] = src[i];  // (ascending: the ranges may overlap)
-            R.words = words_b;
+            R.base = base;  // (it stays where it is: the work items' offsets are relative to the program's first word)
+            R.words = em.size;
             R.n_tags = (uint32_t)em.n_tags;
             R.alg_bytes = W.e.c.alg_bytes; R.alg_flops = W.e.c.alg_flops; R.n_steps = W.e.c.n_steps; R.max_step_cells = W.e.c.max_step_cells;
             R.arena_cells = em.top;

@@ -11,6 +11,7 @@ using namespace mibn;
 struct EmitMeta {  // per request
     uint32_t words, n_tags, tag_first;
     int32_t err;  // kEmitErr* (any error: the host plans the chunk itself)
+    uint32_t prog_first, pad_;  // words of the slot in front of the program (order_effort 1: the runner-up's program stays behind the first one)
     double alg_bytes, alg_flops, n_steps, max_step_cells;
     int64_t arena_cells;
 };
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_ker
         const int64_t b = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)next);
         if (b >= A.B) break;
         EmitMeta m;
-        m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0;
+        m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0; m.prog_first = 0; m.pad_ = 0;
         m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;
         m.arena_cells = 0;
         uint32_t *slot = A.prog + (size_t)b * A.prog_stride;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_ker
         }
         m.err = err;
         m.words = R.words;
+        m.prog_first = R.base;
         m.alg_bytes = R.alg_bytes; m.alg_flops = R.alg_flops; m.n_steps = R.n_steps; m.max_step_cells = R.max_step_cells;
         m.arena_cells = R.arena_cells;
         if (lane == 0) A.meta[b] = m;

@@ -65,7 +65,7 @@ int main(int argc, char **argv) {
         for (int k = 0; k < NE; ++k) { ev[NE * b + k] = pick[1 + k]; ec[NE * b + k] = (int)(rng() % K); }
     }
     for (int64_t b = 0; b <= B; ++b) { q_off[b] = b; e_off[b] = NE * b; out_off[b] = 4 * b; }
-    const uint32_t stride = net.order_effort ? 12288 : 6144;
+    const uint32_t stride = std::getenv("STRIDE") ? (uint32_t)atoi(std::getenv("STRIDE")) : (net.order_effort ? 12288 : 6144);  // words of a request's slot (the engine starts at 6144 and doubles after a chunk that did not fit)
     const size_t tag_cap = (size_t)B * 64;
     WNet *d_net; B2 *d_anc; int64_t *d_qo, *d_eo, *d_oo; int32_t *d_qv, *d_ev, *d_ec; char *d_skip; uint32_t *d_prog, *d_cursor; EmitMeta *d_meta; Tag *d_tags;
     CHECK(hipMalloc(&d_net, sizeof(WNet))); CHECK(hipMemcpy(d_net, wn, sizeof(WNet), hipMemcpyHostToDevice));
@@ -133,12 +133,13 @@ int main(int argc, char **argv) {
         std::vector<Tag> ht;
         tag_program(net.emit_view(), hp.data(), [&](const Tag &t) { ht.push_back(t); });
         const EmitMeta &m = meta[b];
-        bool same = m.err == 0 && m.words == hp.size() && std::memcmp(dev.data() + (size_t)b * stride, hp.data(), hp.size() * 4) == 0 && m.alg_bytes == st.alg_bytes &&
+        if (m.err == kEmitErrWords && std::getenv("STRIDE")) continue;  // (a slot too small for the request: reported, the engine's host plans that chunk and doubles the slots)
+        bool same = m.err == 0 && m.words == hp.size() && std::memcmp(dev.data() + (size_t)b * stride + m.prog_first, hp.data(), hp.size() * 4) == 0 && m.alg_bytes == st.alg_bytes &&
                     m.n_steps == st.n_steps && m.arena_cells == st.arena_cells && m.n_tags == ht.size() &&
                     std::memcmp(tags.data() + m.tag_first, ht.data(), ht.size() * sizeof(Tag)) == 0;
         if (!same && ++bad <= 5) {
             size_t d = 0;
-            while (d < hp.size() && dev[(size_t)b * stride + d] == hp[d]) ++d;
+            while (d < hp.size() && dev[(size_t)b * stride + m.prog_first + d] == hp[d]) ++d;
             printf("request %lld: err %d words %u / %zu first difference at word %zu, steps %.0f / %.0f, tags %u / %zu\n", (long long)b, m.err, m.words, hp.size(), d, m.n_steps, st.n_steps, m.n_tags, ht.size());
         }
     }
@@ -147,5 +148,5 @@ int main(int argc, char **argv) {
            (long long)bad, (long long)n_check, (long long)errs, (long long)B, words / B, steps / B);
     printf("wave_plan_kernel: %.3f ms per %lld requests = %.3f us per request with the whole chip; the host planner + tagging on one core of this box: %.1f us per request\n", best_ms, (long long)B,
            best_ms * 1e3 / B, host_us);
-    return bad != 0 || errs != 0;
+    return bad != 0 || (errs != 0 && !std::getenv("STRIDE"));
 }

@@ -83,14 +83,14 @@ int main(int argc, char **argv) {
         std::vector<uint32_t> slot(2 * 8192 + kWStashWords + 4 * kMaxStepWords, 0xdeadbeefu);
         WResult R;
         wave_plan_request(*wn, *ws, net.anc2.data(), 1, qv, NE, ev, ec, false, 4 * b, slot.data(), (uint32_t)slot.size(), R);
-        bool same = R.err == 0 && R.words == hp.size() && std::memcmp(slot.data(), hp.data(), hp.size() * 4) == 0;
+        bool same = R.err == 0 && R.words == hp.size() && std::memcmp(slot.data() + R.base, hp.data(), hp.size() * 4) == 0;
         if (same) same = R.alg_bytes == st.alg_bytes && R.alg_flops == st.alg_flops && R.n_steps == st.n_steps && R.max_step_cells == st.max_step_cells && R.arena_cells == st.arena_cells;
         if (same) same = R.n_tags == htags.size() && std::memcmp(ws->e.tags, htags.data(), htags.size() * sizeof(Tag)) == 0;
         max_tags = std::max<size_t>(max_tags, htags.size());
         if (!same) {
             if (++bad <= 8) {
                 size_t d = 0;
-                while (d < hp.size() && d < R.words && slot[d] == hp[d]) ++d;
+                while (d < hp.size() && d < R.words && slot[R.base + d] == hp[d]) ++d;
                 // which step holds the first differing word
                 size_t off = 1, step = 0;
                 while (step < hp[0] && off + hp[off + 6] <= d) { off += hp[off + 6]; ++step; }
