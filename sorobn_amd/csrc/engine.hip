@@ -254,6 +254,8 @@ struct mibn_ctx {
     int host_bound_streak = 0;
     bool adaptive_seeded = false;
     double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
+    double base_second_above = 2e7;  // option second_above (the calls the device plans run without the second emission: run_batch)
+    int second_on_device = 0;        // option: 1 = device-planned calls emit the runner-up too (tests: the wave planner's second emission)
     double retired_requests = 0, seen_requests = 0;  // requests whose kernel time has been booked (the unit of kernel_ms in the policy's windows)
     double host_rate = 0;                            // requests per ms the host's workers planned beside the device planner (smoothed; 0: not measured)
     double kernel_ms_per_req = 0;                    // retired kernel time per request over the policy's last windows (smoothed; 0: not measured)
@@ -460,6 +462,7 @@ int mibn_device_count(int *count) {
 int mibn_create_planner(mibn_t **out) {
     if (!out) return MIBN_E_ARG;
     auto *h = new mibn_ctx();
+    h->net.order_effort = 1; h->net.second_above = h->base_second_above;  // (the engine's default; a bare Network - the tools, the oracle - keeps round 5's search)
     h->planner_only = true;
     *out = h;
     return MIBN_OK;
@@ -472,6 +475,7 @@ int mibn_create(int device, mibn_t **out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIBN_E_NODEVICE;
     if (device < 0 || device >= n) return MIBN_E_ARG;
     auto *h = new mibn_ctx();
+    h->net.order_effort = 1; h->net.second_above = h->base_second_above;
     h->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete h; return MIBN_E_NODEVICE; }
     hipDeviceProp_t prop;
@@ -618,7 +622,8 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
         }
     }
     else if (n == "order_effort") h->net.order_effort = std::max(0, std::min(1, (int)value));  // 1: more candidate orders, the byte model's best two both emitted where the best is expensive (order_search.h)
-    else if (n == "second_above") h->net.second_above = value;  // modelled bytes above which the runner-up order is emitted too
+    else if (n == "second_above") { h->base_second_above = value; h->net.second_above = value; }  // modelled bytes above which the runner-up order is emitted too
+    else if (n == "second_on_device") h->second_on_device = value != 0;  // 1: also in the calls the device plans (default: those run without the second emission)
     else if (n == "order_weights") h->net.order_weights = std::max(0, std::min(64, (int)value));  // class-weighted byte model of the order search (0: plain section-8(d) bytes)
     else if (n == "sweep_canon") h->net.sweep_canon = value != 0;  // test hook: 0 = the sweep kernel's general path for every step
     else if (n == "sweep_adapt") h->net.sweep_adapt = std::max(0, (int)value);  // fewer tiles per workgroup in sweep launches below this many workgroups
@@ -945,6 +950,7 @@ int search_orders_async(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, con
             const OrderNet hv = h->net.order_view();
             A.net.chain_weight = hv.chain_weight;
             A.net.big_cells = hv.big_cells;
+            A.net.effort = hv.effort;
         }
         A.q_off = reinterpret_cast<const int64_t *>(d_req) + s0;
         A.e_off = reinterpret_cast<const int64_t *>(d_req + off_bytes) + s0;
@@ -1123,6 +1129,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
             const OrderNet hv = h->net.order_view();
             O.net.chain_weight = hv.chain_weight;
             O.net.big_cells = hv.big_cells;
+            O.net.effort = hv.effort;
         }
         O.q_off = reinterpret_cast<const int64_t *>(d) + s0;
         O.e_off = reinterpret_cast<const int64_t *>(d + off_bytes) + s0;
@@ -1421,6 +1428,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
     ensure_pool(h);
     if (h->trace) std::fprintf(stderr, "[mibn plan] validation of %lld requests %.2f ms\n", (long long)B, now_ms() - t_start);
     double call_fixed_ms = now_ms() - t_start;  // the host's side of this call besides planning (the share rule of wave_plan_kernel)
+    double call_plan_ms = 0;  // the workers' planning of the host's shares and the waits for the device planner: what the call's time to the last launch is NOT fixed cost
     if (h->adaptive && !h->adaptive_seeded) {
         // A rank with a handful of planning threads (8 ranks on a 16-CPU quota: 2-4 each) cannot plan a stream like C3 at the rate
         // its GPU executes it (67 / 133 k queries/s at 2 / 4 threads against 280 k): it starts with the device planner instead of
@@ -1511,6 +1519,10 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
         effort_ok = h->wave_plan && h->net.wave_view(*probe);
     }
     const bool emit_on = h->gpu_emit && h->order_net_ok && h->emit_net_ok && effort_ok;  // whole chunks planned on the device
+    // A rank that needs the device planner has no planning time to spare - and on the device the second emission costs more GPU time than
+    // the bytes it saves give back (a two-thread rank: 243 against 273 k queries/s, profiles/r06_bh_ab.log): its calls take the extra
+    // candidates only, on the host's share and on the device's alike.  (Like minfill_above below: the search effort follows the load.)
+    h->net.second_above = (emit_on && !h->second_on_device) ? 1e300 : h->base_second_above;
     const bool search_on = !emit_on && h->gpu_search && h->order_net_ok && h->net.order_effort < 1;
     int64_t search_b0 = -1;
     bool search_done = false;
@@ -1589,11 +1601,13 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 plan_batch(h->net, *h->pool, st.bufs, b0 + nd, b1, q_off, q_vars, e_off, e_vars, e_codes, out_off, skip.data(), hp,
                            (flags & MIBN_Q_NOPRUNE) != 0, nullptr, nullptr, b0);
                 host_ms = now_ms() - th;
+                call_plan_ms += host_ms;
                 if (!hp.err.empty()) { h->err = hp.err; return bail(MIBN_E_LIMIT); }
             }
             const double tw = now_ms();
             rc = plan_on_device_collect(h, b0, nd, nd < n ? dp : ck, &dev_ms, &beyond);
             h->emit_ms += now_ms() - tw;
+            call_plan_ms += now_ms() - tw;
             if (h->trace >= 2) std::fprintf(stderr, "[mibn plan] collect returned %d at %.2f ms of the block\n", rc, now_ms() - t0);
             for (mibn_kernel_stat *ks : {&h->kstats[kNumKernels + 3], &h->ktotal[kNumKernels + 3]}) {  // (beside the chunk in flight: their time is not GPU busy time of its own)
                 if (!ks->name[0]) std::snprintf(ks->name, sizeof(ks->name), "%s", stat_name(kNumKernels + 3));
@@ -1941,6 +1955,10 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
         HIP_TRY(h, hipEventRecord(h->lane_ev, h->stream2));
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->lane_ev, 0));
     }
+    // (the fixed cost of a device-planned call is everything up to its last launch but the planning itself - validation, the fallbacks, the schedule,
+    //  the uploads and some 600 launches: counting validation and schedule alone - 7.7 ms of 20 - left a two-thread rank host-bound once order_effort 1
+    //  made its planning dearer, profiles/r06_bi_share.log)
+    if (call_plan_ms > 0) call_fixed_ms = std::max(call_fixed_ms, now_ms() - t_start - call_plan_ms);
     if (B > 0) h->fixed_ms_per_req = h->fixed_ms_per_req > 0 ? 0.5 * h->fixed_ms_per_req + 0.5 * call_fixed_ms / (double)B : call_fixed_ms / (double)B;
     if (h->trace) std::fprintf(stderr, "[mibn plan] call of %lld requests: %.2f ms to the last launch (plan %.2f, h2d %.2f)\n", (long long)B, now_ms() - t_start, h->stats.plan_ms, h->stats.h2d_ms);
     if (ticket) {

@@ -545,6 +545,8 @@ def test_device_planner_writes_the_host_programs(amd, order_effort):
     bn = netspec.build(spec, amd.BayesNet)
     be = bn.backend
     be.engine.set_option("order_effort", order_effort)
+    be.engine.set_option("second_above", 1e7)
+    be.engine.set_option("second_on_device", 1)  # (by default a device-planned call runs without the second emission: here the wave planner's is checked)
     q, ev, ec = netspec.c3_requests(100, 4, 6144, 4, seed=1)
     to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
     host = be.engine.query_fixed(to_var[q][:, None], to_var[ev], ec)
