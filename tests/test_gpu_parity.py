@@ -638,6 +638,7 @@ def test_wave_planner_hands_what_it_does_not_cover_to_the_host(amd):
     spec = netspec.grid_spec(10, 10, 4, seed=0)
     bn = netspec.build(spec, amd.BayesNet)
     be = bn.backend
+    be.engine.set_option("second_on_device", 1)  # (the same search in the host-planned and in the device-planned call: bit for bit below)
     to_var = np.array([be.flat.id[f"{i:03d}"] for i in range(100)], np.int32)
     q, ev, ec = netspec.c3_requests(100, 4, 1024, 40, seed=11)
     q4, ev4, ec4 = netspec.c3_requests(100, 4, 1024, 4, seed=12)
@@ -683,10 +684,17 @@ def test_adaptive_policy_starts_a_starved_rank_on_the_device_planner(amd):
     eng = bn.backend.engine
     eng.set_option("threads", 2)
     eng.set_option("adaptive", 1)
+    # (order_effort 1: by default the calls the device plans skip the second emission - a starved rank has no time for it - and their plans,
+    #  hence the last bits of the posteriors, differ from a host-planned call's; with second_on_device the search is the same and so are the bits)
+    eng.set_option("second_on_device", 1)
     for _ in range(2):
         assert np.array_equal(eng.query_fixed(to_var[q][:, None], to_var[ev], ec), host)
         planned = [k for k in eng.kernel_stats() if k["name"] == "order_kernel+emit_kernel"]
         assert planned and planned[0]["items"] > 0
+    eng.set_option("second_on_device", 0)  # the default: cheaper plans for the device-planned calls, the same posteriors to the last few bits
+    loose = eng.query_fixed(to_var[q][:, None], to_var[ev], ec)
+    assert [k for k in eng.kernel_stats() if k["name"] == "order_kernel+emit_kernel"]
+    assert float(np.max(np.abs(loose - host))) <= 1e-12 and eng.stats()["alg_bytes"] > ref_bn.backend.engine.stats()["alg_bytes"]
     eng.set_option("adaptive", 0)
     assert np.array_equal(eng.query_fixed(to_var[q][:, None], to_var[ev], ec), host)
     assert "order_kernel+emit_kernel" not in [k["name"] for k in eng.kernel_stats()]
@@ -933,6 +941,7 @@ def _stratified_sample(cost, per_decile, extra_top=0):
 def _host_and_device_planned(be, to_var, q, ev, ec, idx):
     """Posteriors of the sample planned by the host's workers and by order_kernel + emit_kernel (bit for bit the same)."""
     eng = be.engine
+    eng.set_option("second_on_device", 1)  # (the same search - order_effort 1 with its second emission - in both calls)
     host = eng.query_fixed(to_var[q[idx]][:, None], to_var[ev[idx]], ec[idx])
     eng.set_option("gpu_emit", 1)
     try:
