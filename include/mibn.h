@@ -177,7 +177,9 @@ int mibn_device_synchronize(mibn_t *h);
  * a single pass may eliminate with the tile resident in LDS - ve_sweep_kernel; below 3: off), "sweep_iters" (tiles per
  * workgroup of that kernel; "sweep_adapt": fewer - down to 2 - in launches of fewer workgroups than this, 0 = off),
  * "order_weights" (0: compare candidate elimination orders by plain section-8(d) bytes instead of the class-weighted
- * model), "builtin_sweeps" (1: two depth-first topological orders as additional candidates), "streams" (2: consecutive chunks of a call run concurrently on two streams with an arena each), "first_chunk" (short first chunk of a call: 0 never, 1 when the GPU is idle, 2 always).
+ * model), "order_effort" (default 1: more candidate orders, and the byte model's best two both emitted where the best costs
+ * more than "second_above" modelled bytes - the program that moves fewer bytes stays; 0: round 5's search; calls the device
+ * plans skip the second emission unless "second_on_device" is 1), "builtin_sweeps" (1: two depth-first topological orders as additional candidates), "streams" (2: consecutive chunks of a call run concurrently on two streams with an arena each), "first_chunk" (short first chunk of a call: 0 never, 1 when the GPU is idle, 2 always).
  * Test and profiling hooks: "sweep_canon" (0: the sweep kernel's general path for every step), "small_cells", "big_iters", "tile_h", "fuse", "chain", "outer" (force the
  * kernels' step forms onto small networks), "split_kinds" (one launch per class of work and level, so that
  * mibn_last_kernel_stats reports per-class rates), "trace" (one stderr line per launch), "gibbs_lds" (0: the Gibbs

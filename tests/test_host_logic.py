@@ -264,6 +264,39 @@ def test_sweep_form_on_the_simulator():
     assert b["sweep5"][0] <= b["sweep4"][0] <= b["sweep3"][0] <= b["chain"][0]
 
 
+def test_order_effort_1_answers_the_same_with_fewer_bytes():
+    """Round 6, `order_effort` 1 (csrc/order_search.h, planner.cpp::plan_request_rec; the engine's default): more candidate orders and,
+    where the byte model's best order is expensive, its best TWO both emitted and the cheaper program kept.  Any elimination order gives
+    the reference's posterior (bayes_net.py:779 eliminates in set-iteration order): the programs of effort 1 - with the second emission
+    forced for every request, and at the default threshold - executed on the CPU answer like those of effort 0 within 1e-12, on the
+    6 x 6 and 10 x 10 four-state grids, and never move more bytes; on the C3 stream fewer."""
+    L = simengine.lib()
+    try:
+        for rows, cols, n_req, n_ev in ((6, 6, 40, 3), (10, 10, 24, 4), (10, 10, 12, 8)):
+            spec = netspec.grid_spec(rows, cols, 4, seed=0)
+            f = flatten(netspec.build(spec, sorobn_amd.BayesNet))
+            n = rows * cols
+            to_var = np.array([f.id[f"{i:03d}"] for i in range(n)], np.int32)
+            q, ev, ec = netspec.c3_requests(n, 4, n_req, n_ev, seed=3)
+            eng = simengine.SimEngine(f)
+            got, moved = {}, {}
+            for key in ((0, 1e7), (1, 0.0), (1, 1e7)):
+                L.plan_sim_set_order_effort(ctypes.c_int(key[0]), ctypes.c_double(key[1]))
+                got[key], moved[key] = [], 0.0
+                for i in range(n_req):
+                    got[key].append(eng._one([to_var[q[i]]], to_var[ev[i]], ec[i]))
+                    moved[key] += eng.last_stats[0]
+            for key in ((1, 0.0), (1, 1e7)):
+                worst = max(float(np.max(np.abs(a - b))) for a, b in zip(got[0, 1e7], got[key]))
+                assert worst <= 1e-12, (rows, cols, key, worst)
+            # (the second emission can only help; the extra candidates are ranked by the MODEL and may lose a little on a small sample)
+            assert moved[1, 0.0] <= moved[1, 1e7] * (1 + 1e-12), (rows, cols, moved)
+            if rows == 10:
+                assert moved[1, 0.0] < 0.99 * moved[0, 1e7], moved
+    finally:
+        L.plan_sim_set_order_effort(ctypes.c_int(0), ctypes.c_double(1e7))
+
+
 def test_chain_form_on_the_simulator():
     """CHAIN steps (three variables per pass, option chain=1): the planner's programs, executed by the simulator,
     reproduce the reference's answers on the 10x10 grid and move fewer bytes than the two-variable passes."""
