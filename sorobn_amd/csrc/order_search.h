@@ -62,7 +62,7 @@ struct OrderNet {
     // effort 1 (Network::order_effort): more candidate orders - the meet sweep around the query's depth, and the small eliminations min-fill
     // starts with followed by the meet sweep of the rest - and the SECOND best order kept beside the best: where the best is expensive the
     // planner emits both and keeps the program that moves fewer bytes (the byte model ranks candidates well - among its best two the
-    // emitter finds 8 % fewer bytes on the C3 stream than the model's first choice of round 5's four, tools/order_exp.cpp)
+    // emitter finds 8 % fewer bytes on the C3 stream than the model's first choice of round 5's four, tools/order_quality.cpp)
     int32_t effort = 0;
 };
 

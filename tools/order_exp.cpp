@@ -1,290 +1,98 @@
-// How far is the planner's elimination order from the best one?  (CPU only; profiles/NOTES_r06.md, "order quality".)
-// For every request of a C3 stream: the planner's own order (order_search: sweeps, hints, min-fill ranked by the section-8(d) byte
-// model), emitted (emit_core.h) = the algorithmic bytes the VE kernels would move.  Then a hill climb on that order - move one
-// variable to another position, keep the move if the EMITTED bytes drop - as a probe of what a better search could find, and the
-// modelled cost (order_simulate) beside it to see whether the model ranks the way the emitter does.
-//   g++ -O2 -mpopcnt -std=c++17 tools/order_exp.cpp sorobn_amd/csrc/planner.cpp -lpthread -o /tmp/order_exp && /tmp/order_exp [requests] [evidence nodes] [tries]
-#include <time.h>
-#include <algorithm>
+// Order-search experiment (CPU only, round 5): per request of the C3 stream the byte-model cost of EVERY candidate order (meet, reverse
+// topological, the hint lists) and of greedy min-fill - who wins how often, what each piece costs in time, and what cheaper searches
+// (fewer candidates, a higher min-fill threshold, min-degree instead of min-fill) would cost in bytes.  Results: profiles/NOTES_r05.md.
+//   g++ -O3 -mpopcnt -std=c++17 tools/order_exp.cpp sorobn_amd/csrc/planner.cpp -lpthread -o /tmp/order_exp && /tmp/order_exp; NEV=16 /tmp/order_exp
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <random>
-#include <string>
 #include <vector>
-
 #include "../sorobn_amd/csrc/planner.h"
 using namespace mibn;
+static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static bool greedy_minweight(const OrderNet &net, OrderScratch &S, const B2 &hidden, int mode) {
+    B2 *adj = S.adj; const B2 rel = S.rel;
+    b2_each(rel, [&](int v) { adj[v] = B2{}; });
+    b2_each(rel, [&](int i) { const B2 sc = S.f[i]; b2_each(sc, [&](int v) { adj[v].a |= sc.a; adj[v].b |= sc.b; }); });
+    b2_each(rel, [&](int v) { adj[v].clr(v); });
+    B2 alive = hidden; int total = b2_count(hidden); S.n_cand = 0;
+    for (int it = 0; it < total; ++it) {
+        int best = -1; long bk = 0;
+        b2_each(alive, [&](int x) {
+            long k;
+            const int deg = b2_count(adj[x]);
+            if (mode == 0) k = ((long)deg << 16) | (net.depth[x] << 8) | x;            // min degree (= min weight for uniform cards)
+            else { // min degree, ties by fewer alive neighbours... (mode 1: prefer deeper)
+                k = ((long)deg << 16) | ((255 - net.depth[x]) << 8) | x; }
+            if (best < 0 || k < bk) { best = x; bk = k; }
+        });
+        S.cand[S.n_cand++] = (uint8_t)best; alive.clr(best);
+        const B2 nb = adj[best];
+        b2_each(nb, [&](int y) { adj[y].a |= nb.a; adj[y].b |= nb.b; adj[y].clr(best); adj[y].clr(y); });
+    }
+    return true;
+}
 
 int main(int argc, char **argv) {
-    const int64_t B = argc > 1 ? atoll(argv[1]) : 300;
-    const int NE = argc > 2 ? atoi(argv[2]) : 4;
-    const int TRIES = argc > 3 ? atoi(argv[3]) : 300;
-    const int R = 10, C = 10, K = 4, n = R * C;
-    std::vector<int32_t> card(n, K), scope_vars;
-    std::vector<int64_t> scope_off{0}, value_off{0};
-    std::vector<double> values;
-    std::mt19937_64 rng(1);
-    std::uniform_real_distribution<double> U(0.1, 1.0);
-    for (int v = 0; v < n; ++v) {
-        const int r = v / C, c = v % C;
-        if (r) scope_vars.push_back(v - C);
-        if (c) scope_vars.push_back(v - 1);
-        scope_vars.push_back(v);
-        scope_off.push_back((int64_t)scope_vars.size());
-        int64_t cells = K;
-        if (r) cells *= K;
-        if (c) cells *= K;
-        for (int64_t i = 0; i < cells; ++i) values.push_back(U(rng));
-        value_off.push_back((int64_t)values.size());
-    }
-    Network net;
-    std::string e = net.set(n, card.data(), scope_off.data(), scope_vars.data(), value_off.data(), values.data());
-    if (!e.empty()) { std::fprintf(stderr, "%s\n", e.c_str()); return 1; }
-    const EmitNet en = net.emit_view();
-    const OrderNet on = net.order_view();
-    std::vector<char> slice(emit_scratch_bytes(n) + 64);
-    std::vector<uint32_t> slot(1 << 16);
-    OrderScratch *os = new OrderScratch;
-    char *base = slice.data() + ((64 - (reinterpret_cast<uintptr_t>(slice.data()) & 63)) & 63);
-    int32_t qv[1], ev[40], ec[40];
-    auto emitted = [&](const uint8_t *order, int n_order, double *steps = nullptr) -> double {
-        EmitScratch S;
-        emit_scratch_carve(S, base, n);
-        if (emit_begin(en, S, 1, qv, NE, ev, ec, false)) return -1;
-        EmitBuf buf;
-        buf.data = slot.data();
-        buf.cap = slot.size();
-        EmitStats st;
-        if (emit_run(en, S, buf, st, nullptr, 1, qv, 0, order, n_order)) return -1;
-        if (steps) *steps = st.n_steps;
-        return st.alg_bytes;
-    };
-    std::vector<int32_t> hint(n);
-    for (int v = 0; v < n; ++v) hint[v] = v;
-    if (!std::getenv("NO_HINT")) net.set_hints(1, hint.data());
-    const OrderNet on2 = net.order_view();
-    if (std::getenv("PLANNER")) {
-        // the planner itself (plan_request) at order_effort 0 and 1: bytes per request and planning time on this core
-        std::vector<std::vector<int32_t>> reqs;
-        for (int64_t b = 0; b < B; ++b) {
-            int pick[40];
-            for (int k = 0; k < NE + 1;) {
-                const int v = (int)(rng() % n);
-                bool dup = false;
-                for (int j = 0; j < k; ++j) dup = dup || pick[j] == v;
-                if (!dup) pick[k++] = v;
-            }
-            reqs.emplace_back(pick, pick + NE + 1);
-        }
-#ifdef ORDER_EXP_MASK
-        if (std::getenv("MASK")) g_order_exp_mask = (int)strtol(std::getenv("MASK"), nullptr, 0);
-#endif
-        double bytes[2] = {0, 0}, us[2] = {0, 0};
-        for (int eff = 0; eff < 2; ++eff) {
-            net.order_effort = eff;
-            if (std::getenv("SECOND_ABOVE")) net.second_above = atof(std::getenv("SECOND_ABOVE"));
-            std::vector<uint32_t> prog;
-            timespec t0, t1;
-            clock_gettime(CLOCK_MONOTONIC, &t0);
-            for (auto &r : reqs) {
-                for (int k = 0; k < NE; ++k) { ev[k] = r[1 + k]; ec[k] = 0; }
-                qv[0] = r[0];
-                Request rq;
-                rq.nq = 1; rq.qvars = qv; rq.ne = NE; rq.evars = ev; rq.ecodes = ec;
-                prog.clear();
-                PlanStats st;
-                const std::string err = plan_request(net, rq, prog, st);
-                if (!err.empty()) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
-                bytes[eff] += st.alg_bytes;
-            }
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            us[eff] = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 1e3 / (double)B;
-        }
-        std::printf("%lld requests, %d evidence nodes: order_effort 0: %.3f MB per request, %.1f us per request planned; order_effort 1: %.3f MB (%.1f %% less), %.1f us\n", (long long)B, NE,
-                    bytes[0] / B / 1e6, us[0], bytes[1] / B / 1e6, 100.0 * (1 - bytes[1] / bytes[0]), us[1]);
-        return 0;
-    }
-    if (std::getenv("CANDIDATES")) {
-        // every candidate of the search emitted: what the model chose against what the emitter would have chosen - and what further
-        // generators (EXTRA=1) would add: the meet sweep at other depths, a min-fill prefix (the eliminations that create small factors)
-        // followed by the meet sweep of the rest
-        const bool extra = std::getenv("EXTRA") != nullptr;
-        std::vector<std::string> names = {"meet", "reverse", "row-major hint", "min-fill"};
-        if (extra) for (const char *x : {"meet -2", "meet -1", "meet +1", "meet +2", "min-fill <= 3 then meet", "min-fill <= 4 then meet", "min-fill <= 5 then meet", "min-fill <= 6 then meet", "min-fill <= 7 then meet"}) names.push_back(x);
-        const int NC = (int)names.size();
-        double chosen = 0, best_e = 0, chosen4 = 0, topk[4] = {0, 0, 0, 0}, extra_emits[4] = {0, 0, 0, 0};
-        std::vector<double> per(NC, 0.0);
-        std::vector<int64_t> wins_model(NC, 0), wins_emit(NC, 0);
-        std::vector<double> costs;
-        for (int64_t b = 0; b < B; ++b) {
-            int pick[40];
-            for (int k = 0; k < NE + 1;) {
-                const int v = (int)(rng() % n);
-                bool dup = false;
-                for (int j = 0; j < k; ++j) dup = dup || pick[j] == v;
-                if (!dup) pick[k++] = v;
-            }
-            qv[0] = pick[0];
-            for (int k = 0; k < NE; ++k) { ev[k] = pick[1 + k]; ec[k] = 0; }
-            B2 rel, hidden;
-            order_prepare(on2, *os, 1, qv, NE, ev, false, rel, hidden);
-            if (!hidden.any()) continue;
-            std::vector<double> em(NC), mo(NC);
-            order_greedy(on2, *os, hidden, __builtin_inf());
-            const std::vector<uint8_t> G(os->cand, os->cand + os->n_cand);
-            // widths of min-fill's eliminations (replay on scopes)
-            std::vector<int> gw;
-            {
-                std::vector<B2> fs;
-                B2 eb;
-                for (int k = 0; k < NE; ++k) eb.set(ev[k]);
-                b2_each(rel, [&](int v) { B2 sc = net.scope2[v]; sc.a &= ~eb.a; sc.b &= ~eb.b; fs.push_back(sc); });
-                std::vector<char> alive(fs.size(), 1);
-                for (uint8_t x : G) {
-                    B2 u;
-                    for (size_t i = 0; i < fs.size(); ++i)
-                        if (alive[i] && fs[i].test(x)) { alive[i] = 0; u.a |= fs[i].a; u.b |= fs[i].b; }
-                    u.clr(x);
-                    fs.push_back(u);
-                    alive.push_back(1);
-                    gw.push_back(b2_count(u));
-                }
-            }
-            for (int c = 0; c < NC; ++c) {
-                std::vector<uint8_t> o;
-                if (c < 2) { order_sweep(on2, *os, hidden, on2.depth[qv[0]], c); o.assign(os->cand, os->cand + os->n_cand); }
-                else if (c == 2) { for (int i = 0; i < n; ++i) if (hidden.test(on2.hint_sorted[i])) o.push_back((uint8_t)on2.hint_sorted[i]); }
-                else if (c == 3) o = G;
-                else if (c < 8) { const int d = std::max(0, on2.depth[qv[0]] + (c < 6 ? c - 6 : c - 5)); order_sweep(on2, *os, hidden, d, 0); o.assign(os->cand, os->cand + os->n_cand); }
-                else {
-                    const int w = c - 8 + 3;
-                    B2 rest = hidden;
-                    for (size_t i = 0; i < G.size() && gw[i] <= w; ++i) { o.push_back(G[i]); rest.clr(G[i]); }
-                    order_sweep(on2, *os, rest, on2.depth[qv[0]], 0);
-                    o.insert(o.end(), os->cand, os->cand + os->n_cand);
-                }
-                mo[c] = order_simulate(on2, *os, o.data(), (int)o.size(), __builtin_inf());
-                em[c] = emitted(o.data(), (int)o.size());
-                if (em[c] < 0) em[c] = 1e30;
-                per[c] += em[c] < 1e29 ? em[c] : 0;
-            }
-            int cm = 0, ce = 0, cm4 = 0;
-            for (int c = 1; c < NC; ++c) { if (mo[c] < mo[cm]) cm = c; if (em[c] < em[ce]) ce = c; if (c < 4 && mo[c] < mo[cm4]) cm4 = c; }
-            {   // two stages: the model's best k, the emitter among them (only where the model's best is heavy)
-                std::vector<int> idx(NC);
-                for (int c = 0; c < NC; ++c) idx[c] = c;
-                std::sort(idx.begin(), idx.end(), [&](int a_, int b_) { return mo[a_] < mo[b_]; });
-                const double heavy = std::getenv("HEAVY_ABOVE") ? atof(std::getenv("HEAVY_ABOVE")) * 1e6 : 0;
-                for (int k = 1; k <= 4; ++k) {
-                    double bestk = em[idx[0]];
-                    if (mo[idx[0]] >= heavy) { for (int q = 1; q < k; ++q) bestk = std::min(bestk, em[idx[q]]); extra_emits[k - 1] += k - 1; }
-                    topk[k - 1] += bestk;
-                }
-            }
-            chosen += em[cm]; best_e += em[ce]; chosen4 += em[cm4];
-            ++wins_model[cm]; ++wins_emit[ce];
-            costs.push_back(em[cm]);
-        }
-        std::printf("%zu requests, %d evidence nodes: today's four candidates by the model %.3f MB per request emitted; all %d by the model %.3f MB (%.1f %% less); all by the emitter %.3f MB (%.1f %% less)\n", costs.size(), NE,
-                    chosen4 / costs.size() / 1e6, NC, chosen / costs.size() / 1e6, 100.0 * (1 - chosen / chosen4), best_e / costs.size() / 1e6, 100.0 * (1 - best_e / chosen4));
-        for (int k = 1; k <= 4; ++k) std::printf("  the model's best %d, the emitter among them: %.3f MB (%.1f %% less than today), %.2f extra emissions per request\n", k, topk[k - 1] / costs.size() / 1e6, 100.0 * (1 - topk[k - 1] / chosen4), extra_emits[k - 1] / costs.size());
-        for (int c = 0; c < NC; ++c) std::printf("  %-26s alone %.3f MB; chosen by the model %lld times, by the emitter %lld times\n", names[c].c_str(), per[c] / costs.size() / 1e6, (long long)wins_model[c], (long long)wins_emit[c]);
-        std::sort(costs.begin(), costs.end());
-        double tot = 0, acc = 0;
-        for (double c : costs) tot += c;
-        std::printf("  bytes by decile of requests (cheapest first):");
-        for (size_t i = 0; i < costs.size(); ++i) { acc += costs[i]; if ((i + 1) % (costs.size() / 10) == 0) std::printf(" %.1f%%", 100.0 * acc / tot); }
-        std::printf("   median %.2f MB, 90th percentile %.2f MB, max %.2f MB\n", costs[costs.size() / 2] / 1e6, costs[costs.size() * 9 / 10] / 1e6, costs.back() / 1e6);
-        return 0;
-    }
-    double base_bytes = 0, climbed_bytes = 0, base_model = 0, climbed_model = 0, model_of_best_model = 0, bytes_of_best_model = 0;
-    int64_t improved = 0, moves = 0, failed = 0, searched = 0;
+    const int R = 10, C = 10, K = 4, n = 100;
+    const int64_t B = 8192;
+    const int NE = getenv("NEV") ? atoi(getenv("NEV")) : 4;
+    std::vector<int32_t> card(n, K), scope_vars; std::vector<int64_t> scope_off{0}, value_off{0}; std::vector<double> values;
+    std::mt19937_64 rng(1); std::uniform_real_distribution<double> U(0.1, 1.0);
+    for (int v = 0; v < n; ++v) { int r = v / C, c = v % C; if (r) scope_vars.push_back(v - C); if (c) scope_vars.push_back(v - 1); scope_vars.push_back(v);
+        scope_off.push_back(scope_vars.size()); int64_t cells = K; if (r) cells *= K; if (c) cells *= K; for (int64_t i = 0; i < cells; ++i) values.push_back(U(rng)); value_off.push_back(values.size()); }
+    Network net; net.set(n, card.data(), scope_off.data(), scope_vars.data(), value_off.data(), values.data());
+    std::vector<int32_t> hint(n); for (int v = 0; v < n; ++v) hint[v] = v; net.set_hints(1, hint.data());
+    OrderNet on = net.order_view();
+    printf("n_hints %d chain_weight %g minfill_above %g\n", on.n_hints, on.chain_weight, on.minfill_above);
+    static OrderScratch S;
+    const int NC = 2 + on.n_hints + 3;
+    std::vector<double> cost(B * NC, 0.0); std::vector<double> t(NC + 2, 0.0);
     for (int64_t b = 0; b < B; ++b) {
-        int pick[40];
-        for (int k = 0; k < NE + 1;) {
-            const int v = (int)(rng() % n);
-            bool dup = false;
-            for (int j = 0; j < k; ++j) dup = dup || pick[j] == v;
-            if (!dup) pick[k++] = v;
-        }
-        qv[0] = pick[0];
-        for (int k = 0; k < NE; ++k) { ev[k] = pick[1 + k]; ec[k] = 0; }
-        order_search(on2, *os, 1, qv, NE, ev, false);
-        const int m = os->n_best;
-        std::vector<uint8_t> cur(os->best, os->best + m), best_model_order = cur;
-        double cur_bytes = emitted(cur.data(), m);
-        if (cur_bytes < 0 || m < 3) { ++failed; continue; }
-        const double b0 = cur_bytes;
-        if (std::getenv("HEAVY_ABOVE") && b0 < atof(std::getenv("HEAVY_ABOVE")) * 1e6) {  // only the heavy requests are searched
-            base_bytes += b0; climbed_bytes += b0; bytes_of_best_model += b0;
-            continue;
-        }
-        ++searched;
-        double cur_model = order_simulate(on, *os, cur.data(), m, __builtin_inf());
-        const double m0 = cur_model;
-        double bm = cur_model;  // a second climb, on the model alone (what a better SEARCH with the same model would find)
-        for (int t = 0; t < TRIES; ++t) {
-            const int i = (int)(rng() % m);
-            int j = (int)(rng() % m);
-            if (i == j) continue;
-            std::vector<uint8_t> cand = cur;
-            const uint8_t v = cand[i];
-            cand.erase(cand.begin() + i);
-            cand.insert(cand.begin() + j, v);
-            const double cb = emitted(cand.data(), m);
-            if (cb >= 0 && cb < cur_bytes) {
-                if (std::getenv("MOVES")) std::printf("move: request %lld m %d: %d%d from %d to %d (%+d), %.2f -> %.2f MB (%.1f %%)\n", (long long)b, m, v / 10, v % 10, i, j, j - i, cur_bytes / 1e6, cb / 1e6, 100.0 * (1 - cb / cur_bytes));
-                cur = cand; cur_bytes = cb; ++moves;
-            }
-            std::vector<uint8_t> cm = best_model_order;
-            const uint8_t u = cm[i];
-            cm.erase(cm.begin() + i);
-            cm.insert(cm.begin() + j, u);
-            const double mm = order_simulate(on, *os, cm.data(), m, bm);
-            if (mm < bm) { bm = mm; best_model_order = cm; }
-        }
-        base_bytes += b0;
-        climbed_bytes += cur_bytes;
-        base_model += m0;
-        climbed_model += order_simulate(on, *os, cur.data(), m, __builtin_inf());
-        model_of_best_model += bm;
-        const double bb = emitted(best_model_order.data(), m);
-        bytes_of_best_model += bb < 0 ? b0 : bb;
-        improved += cur_bytes < b0;
-        if (std::getenv("ORDER_DUMP") && b < atoi(std::getenv("ORDER_DUMP"))) {
-            auto show = [&](const char *name, const std::vector<uint8_t> &o, double bytes) {
-                std::printf("  %s %.2f MB:", name, bytes / 1e6);
-                // replay on scopes: the width (variables of the created factor) of every elimination
-                std::vector<B2> fs;
-                B2 rel = os->rel, eb;
-                for (int k = 0; k < NE; ++k) eb.set(ev[k]);
-                b2_each(rel, [&](int v) { B2 sc = net.scope2[v]; sc.a &= ~eb.a; sc.b &= ~eb.b; fs.push_back(sc); });
-                std::vector<char> alive(fs.size(), 1);
-                for (uint8_t x : o) {
-                    B2 u;
-                    for (size_t i = 0; i < fs.size(); ++i)
-                        if (alive[i] && fs[i].test(x)) { alive[i] = 0; u.a |= fs[i].a; u.b |= fs[i].b; }
-                    u.clr(x);
-                    fs.push_back(u);
-                    alive.push_back(1);
-                    std::printf(" %d%d:%d", x / 10, x % 10, b2_count(u));
-                }
-                std::printf("\n");
-            };
-            std::printf("request %lld: query %d%d evidence", (long long)b, qv[0] / 10, qv[0] % 10);
-            for (int k = 0; k < NE; ++k) std::printf(" %d%d", ev[k] / 10, ev[k] % 10);
-            std::printf("\n");
-            show("planner", std::vector<uint8_t>(os->best, os->best + m), b0);
-            show("climbed", cur, cur_bytes);
+        int pick[40]; for (int k = 0; k < NE + 1;) { int v = rng() % n; bool dup = false; for (int j = 0; j < k; ++j) dup |= pick[j] == v; if (!dup) pick[k++] = v; }
+        int32_t q = pick[0]; int32_t ev[40]; for (int k = 0; k < NE; ++k) { ev[k] = pick[1 + k]; rng(); }
+        B2 rel, hidden; double t0 = now();
+        order_prepare(on, S, 1, &q, NE, ev, false, rel, hidden);
+        t[NC] += now() - t0;
+        int qd = on.depth[q];
+        const double inf = __builtin_inf();
+        for (int c = 0; c < NC; ++c) {
+            t0 = now();
+            bool ok = true;
+            if (c < 2) order_sweep(on, S, hidden, qd, c);
+            else if (c < 2 + on.n_hints) { const int32_t *s = on.hint_sorted + (int64_t)(c - 2) * on.n_vars; S.n_cand = 0; for (int i = 0; i < on.n_vars; ++i) if (hidden.test(s[i])) S.cand[S.n_cand++] = s[i]; }
+            else if (c == NC - 3) { ok = order_greedy(on, S, hidden, inf); t[NC + 1] += now() - t0; t0 = now(); }
+            else { greedy_minweight(on, S, hidden, c - (NC - 2)); }
+            cost[b * NC + c] = ok ? order_simulate(on, S, S.cand, S.n_cand, inf) : inf;
+            t[c] += now() - t0;
         }
     }
-    const double nb = (double)(B - failed);
-    std::printf("%lld requests (%lld skipped, %lld searched), %d evidence nodes, %d moves tried per searched request\n", (long long)B, (long long)failed, (long long)searched, NE, TRIES);
-    std::printf("  the planner's order:                      emitted %.3f MB per request, modelled %.3f MB\n", base_bytes / nb / 1e6, base_model / nb / 1e6);
-    std::printf("  hill climb on the EMITTED bytes:          emitted %.3f MB (%.1f %% less; %lld requests improved, %.1f moves kept each), modelled %.3f MB\n", climbed_bytes / nb / 1e6,
-                100.0 * (1 - climbed_bytes / base_bytes), (long long)improved, (double)moves / nb, climbed_model / nb / 1e6);
-    std::printf("  hill climb on the MODEL (order_simulate): emitted %.3f MB (%.1f %% less), modelled %.3f MB (%.1f %% less)\n", bytes_of_best_model / nb / 1e6,
-                100.0 * (1 - bytes_of_best_model / base_bytes), model_of_best_model / nb / 1e6, 100.0 * (1 - model_of_best_model / base_model));
+    for (int c = 0; c < NC; ++c) printf("cand %d: sim+gen %.2f us/request\n", c, t[c] / B);
+    printf("prepare %.2f us, greedy itself %.2f us\n", t[NC] / B, t[NC + 1] / B);
+    // strategies
+    auto eval = [&](const char *name, std::vector<int> sweeps, bool greedy, double thr, int gi = -1) { if (gi < 0) gi = NC - 3;
+        double tot = 0, ng = 0; std::vector<int> wins(NC, 0);
+        for (int64_t b = 0; b < B; ++b) { double best = 1e300; int w = -1; for (int c : sweeps) if (cost[b * NC + c] < best) { best = cost[b * NC + c]; w = c; }
+            if (greedy && best > thr) { ng++; if (cost[b * NC + gi] < best) { best = cost[b * NC + gi]; w = gi; } } tot += best; wins[w]++; }
+        printf("%-40s mean weighted cost %.3f MB  greedy runs %.1f%%  wins:", name, tot / B / 1e6, 100 * ng / B); for (int c = 0; c < NC; ++c) printf(" %d", wins[c]); printf("\n");
+    };
+    const double thr = on.minfill_above * on.chain_weight;
+    eval("current (4 sweeps + greedy>thr)", {0, 1, 2, 3}, true, thr);
+    eval("all + mindeg(shallow first) > thr", {0, 1, 2, 3}, true, thr, NC - 2);
+    eval("all + mindeg(deep first) > thr", {0, 1, 2, 3}, true, thr, NC - 1);
+    eval("all + mindeg always", {0, 1, 2, 3}, true, 0, NC - 2);
+    eval("no rev", {0, 2, 3}, true, thr);
+    eval("no meet", {1, 2, 3}, true, thr);
+    eval("meet + hint2", {0, 2}, true, thr);
+    eval("meet + hint3", {0, 3}, true, thr);
+    eval("meet only", {0}, true, thr);
+    eval("greedy always + meet", {0}, true, 0);
+    eval("greedy always, no sweeps at all", {}, true, -1);
+    eval("greedy always, all", {0, 1, 2, 3}, true, 0);
+    eval("no greedy", {0, 1, 2, 3}, false, 0);
+    eval("all, greedy > 2 thr", {0, 1, 2, 3}, true, 2 * thr);
+    eval("all, greedy > 4 thr", {0, 1, 2, 3}, true, 4 * thr);
+    eval("all, greedy > thr/2", {0, 1, 2, 3}, true, thr / 2);
     return 0;
 }
