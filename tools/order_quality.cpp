@@ -110,7 +110,7 @@ int main(int argc, char **argv) {
         std::vector<std::string> names = {"meet", "reverse", "row-major hint", "min-fill"};
         if (extra) for (const char *x : {"meet -2", "meet -1", "meet +1", "meet +2", "min-fill <= 3 then meet", "min-fill <= 4 then meet", "min-fill <= 5 then meet", "min-fill <= 6 then meet", "min-fill <= 7 then meet"}) names.push_back(x);
         const int NC = (int)names.size();
-        double chosen = 0, best_e = 0, chosen4 = 0, topk[4] = {0, 0, 0, 0}, extra_emits[4] = {0, 0, 0, 0};
+        double chosen = 0, best_e = 0, chosen4 = 0, topk[4] = {0, 0, 0, 0}, extra_emits[4] = {0, 0, 0, 0}, divers = 0;
         std::vector<double> per(NC, 0.0);
         std::vector<int64_t> wins_model(NC, 0), wins_emit(NC, 0);
         std::vector<double> costs;
@@ -173,6 +173,14 @@ int main(int argc, char **argv) {
                 for (int c = 0; c < NC; ++c) idx[c] = c;
                 std::sort(idx.begin(), idx.end(), [&](int a_, int b_) { return mo[a_] < mo[b_]; });
                 const double heavy = std::getenv("HEAVY_ABOVE") ? atof(std::getenv("HEAVY_ABOVE")) * 1e6 : 0;
+                {   // diversity: the runner-up = the model's best of the OTHER family (min-fill and its openings / the sweeps)
+                    auto fam = [&](int c) { return c == 3 || c >= 8; };
+                    double d = em[idx[0]];
+                    if (mo[idx[0]] >= heavy)
+                        for (int q = 1; q < NC; ++q)
+                            if (fam(idx[q]) != fam(idx[0]) && mo[idx[q]] < 1e300) { d = std::min(d, em[idx[q]]); break; }
+                    divers += d;
+                }
                 for (int k = 1; k <= 4; ++k) {
                     double bestk = em[idx[0]];
                     if (mo[idx[0]] >= heavy) { for (int q = 1; q < k; ++q) bestk = std::min(bestk, em[idx[q]]); extra_emits[k - 1] += k - 1; }
@@ -186,6 +194,7 @@ int main(int argc, char **argv) {
         std::printf("%zu requests, %d evidence nodes: today's four candidates by the model %.3f MB per request emitted; all %d by the model %.3f MB (%.1f %% less); all by the emitter %.3f MB (%.1f %% less)\n", costs.size(), NE,
                     chosen4 / costs.size() / 1e6, NC, chosen / costs.size() / 1e6, 100.0 * (1 - chosen / chosen4), best_e / costs.size() / 1e6, 100.0 * (1 - best_e / chosen4));
         for (int k = 1; k <= 4; ++k) std::printf("  the model's best %d, the emitter among them: %.3f MB (%.1f %% less than today), %.2f extra emissions per request\n", k, topk[k - 1] / costs.size() / 1e6, 100.0 * (1 - topk[k - 1] / chosen4), extra_emits[k - 1] / costs.size());
+        std::printf("  the model's best and its best of the other family (min-fill and openings / sweeps), the emitter between them: %.3f MB (%.1f %% less than today)\n", divers / costs.size() / 1e6, 100.0 * (1 - divers / chosen4));
         for (int c = 0; c < NC; ++c) std::printf("  %-26s alone %.3f MB; chosen by the model %lld times, by the emitter %lld times\n", names[c].c_str(), per[c] / costs.size() / 1e6, (long long)wins_model[c], (long long)wins_emit[c]);
         std::sort(costs.begin(), costs.end());
         double tot = 0, acc = 0;
