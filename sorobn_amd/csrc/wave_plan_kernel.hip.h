@@ -19,9 +19,11 @@ struct EmitMeta {  // per request
 // ---------------------------------------------------------------------------------------------- wave-cooperative device planner
 // Round 6 (csrc/wave_plan.h): ONE request per wave - order search and emission in one launch, the request's planning state in LDS
 // (order_kernel / emit_kernel above keep theirs in scratch and global memory, one request per lane, and wait for it 86 % of their
-// cycles: profiles/r06_a_plansq_counters.txt).  Four waves = four requests per workgroup share the network tables (WNet, 10 KB of
-// LDS); 58 KB per workgroup, two workgroups per CU.  The programs, the per-request results and the work items go where emit_kernel
-// writes them, word for word what the host plans (gpu_emit = 2 compares every word).
+// cycles: profiles/r06_a_plansq_counters.txt).  The four waves of a workgroup share the network tables (WNet, 8 KB of LDS) and plan a
+// request each - the next one from a counter when they are done; 39.8 KB per workgroup, four workgroups = sixteen waves per CU at 128
+// registers.  The programs, the per-request results and the work items go where emit_kernel writes them, word for word what the host
+// plans (gpu_emit = 2 compares every word); with order_effort 1 a request's program may start behind the first words of its slot
+// (EmitMeta::prog_first: the runner-up's program, emitted behind the first one, won).
 struct WavePlanArgs {
     const WNet *net;
     const B2 *anc;                           // [n_vars] ancestor sets
@@ -48,7 +50,7 @@ __device__ unsigned long long g_wave_prof[24];  // ticks per phase, summed over 
 __global__ void reset_cursor_kernel(uint32_t *cursor) { cursor[0] = 0; cursor[1] = 0; }
 
 #ifndef MIBN_WAVE_MIN_WGS
-#define MIBN_WAVE_MIN_WGS 4  // workgroups per CU the register budget allows (4: 128 VGPRs - 270 spilled, still the fastest: 11.0 ms per chunk against 13.8 at 3, profiles/r06_v_occupancy.log; LDS: 39.6 KB per workgroup)
+#define MIBN_WAVE_MIN_WGS 4  // workgroups per CU the register budget allows (4: 128 VGPRs - some 300 spilled, still the fastest: 11.0 ms per chunk against 13.8 at 3, profiles/r06_v_occupancy.log; LDS: 39.8 KB per workgroup)
 #endif
 __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_kernel(const WavePlanArgs A) {
     __shared__ WNet N;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -63,6 +64,36 @@ int main(int argc, char **argv) {
         }
         qv[b] = pick[0];
         for (int k = 0; k < NE; ++k) { ev[NE * b + k] = pick[1 + k]; ec[NE * b + k] = (int)(rng() % K); }
+    }
+    if (const char *so = std::getenv("SORT")) {
+        // experiment: the requests in descending order of a cost (1: the host planner's steps - the planning time's proxy; 2: the number of
+        // relevant variables, what a pre-pass could know) - the waves draw requests from a counter, the long ones first leave no tail
+        std::vector<std::pair<double, int64_t>> key(B);
+        for (int64_t b = 0; b < B; ++b) {
+            double c = 0;
+            if (atoi(so) == 1) {
+                Request rq;
+                rq.nq = 1; rq.qvars = &qv[b]; rq.ne = NE; rq.evars = &ev[NE * b]; rq.ecodes = &ec[NE * b];
+                std::vector<uint32_t> hp;
+                PlanStats st;
+                plan_request(net, rq, hp, st);
+                c = st.n_steps;
+            } else {
+                B2 rel = net.anc2[qv[b]];
+                rel.set(qv[b]);
+                for (int k = 0; k < NE; ++k) { rel.a |= net.anc2[ev[NE * b + k]].a; rel.b |= net.anc2[ev[NE * b + k]].b; rel.set(ev[NE * b + k]); }
+                c = b2_count(rel);
+            }
+            key[b] = {-c, b};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int32_t> qv2(B), ev2((size_t)NE * B), ec2((size_t)NE * B);
+        for (int64_t i = 0; i < B; ++i) {
+            const int64_t b = key[i].second;
+            qv2[i] = qv[b];
+            for (int k = 0; k < NE; ++k) { ev2[NE * i + k] = ev[NE * b + k]; ec2[NE * i + k] = ec[NE * b + k]; }
+        }
+        qv.swap(qv2); ev.swap(ev2); ec.swap(ec2);
     }
     for (int64_t b = 0; b <= B; ++b) { q_off[b] = b; e_off[b] = NE * b; out_off[b] = 4 * b; }
     const uint32_t stride = std::getenv("STRIDE") ? (uint32_t)atoi(std::getenv("STRIDE")) : (net.order_effort ? 12288 : 6144);  // words of a request's slot (the engine starts at 6144 and doubles after a chunk that did not fit)
