@@ -694,7 +694,7 @@ def test_adaptive_policy_starts_a_starved_rank_on_the_device_planner(amd):
     eng.set_option("second_on_device", 0)  # the default: cheaper plans for the device-planned calls, the same posteriors to the last few bits
     loose = eng.query_fixed(to_var[q][:, None], to_var[ev], ec)
     assert [k for k in eng.kernel_stats() if k["name"] == "order_kernel+emit_kernel"]
-    assert float(np.max(np.abs(loose - host))) <= 1e-12 and eng.stats()["alg_bytes"] > ref_bn.backend.engine.stats()["alg_bytes"]
+    assert float(np.max(np.abs(loose - host))) <= 1e-12 and eng.stats()["alg_bytes"] >= ref_bn.backend.engine.stats()["alg_bytes"]  # (equal under order_effort 0)
     eng.set_option("adaptive", 0)
     assert np.array_equal(eng.query_fixed(to_var[q][:, None], to_var[ev], ec), host)
     assert "order_kernel+emit_kernel" not in [k["name"] for k in eng.kernel_stats()]
