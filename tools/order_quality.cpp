@@ -109,6 +109,9 @@ int main(int argc, char **argv) {
         const bool extra = std::getenv("EXTRA") != nullptr;
         std::vector<std::string> names = {"meet", "reverse", "row-major hint", "min-fill"};
         if (extra) for (const char *x : {"meet -2", "meet -1", "meet +1", "meet +2", "min-fill <= 3 then meet", "min-fill <= 4 then meet", "min-fill <= 5 then meet", "min-fill <= 6 then meet", "min-fill <= 7 then meet"}) names.push_back(x);
+        // LAZY=1: the meet sweep, but whenever a vertex of the current interaction graph has at most d neighbours it goes first (the opening rule applied all along)
+        const bool lazy = extra && std::getenv("LAZY") != nullptr;
+        if (lazy) for (const char *x : {"meet, degree <= 2 first", "meet, degree <= 3 first", "meet, degree <= 4 first", "meet, degree <= 5 first"}) names.push_back(x);
         const int NC = (int)names.size();
         double chosen = 0, best_e = 0, chosen4 = 0, topk[4] = {0, 0, 0, 0}, extra_emits[4] = {0, 0, 0, 0}, divers = 0;
         std::vector<double> per(NC, 0.0);
@@ -154,6 +157,34 @@ int main(int argc, char **argv) {
                 else if (c == 2) { for (int i = 0; i < n; ++i) if (hidden.test(on2.hint_sorted[i])) o.push_back((uint8_t)on2.hint_sorted[i]); }
                 else if (c == 3) o = G;
                 else if (c < 8) { const int d = std::max(0, on2.depth[qv[0]] + (c < 6 ? c - 6 : c - 5)); order_sweep(on2, *os, hidden, d, 0); o.assign(os->cand, os->cand + os->n_cand); }
+                else if (c >= 13) {
+                    const int d = c - 13 + 2;
+                    // interaction graph of the request (scopes without evidence), eliminated as we go
+                    std::vector<B2> adj(n);
+                    B2 eb;
+                    for (int k = 0; k < NE; ++k) eb.set(ev[k]);
+                    b2_each(rel, [&](int v) {
+                        B2 sc = net.scope2[v]; sc.a &= ~eb.a; sc.b &= ~eb.b;
+                        b2_each(sc, [&](int u) { adj[u].a |= sc.a; adj[u].b |= sc.b; });
+                    });
+                    for (int v = 0; v < n; ++v) adj[v].clr(v);
+                    order_sweep(on2, *os, hidden, on2.depth[qv[0]], 0);
+                    const std::vector<uint8_t> sweep(os->cand, os->cand + os->n_cand);
+                    B2 alive = hidden;
+                    size_t next = 0;
+                    while (alive.any()) {
+                        int pick_v = -1, pick_deg = 1 << 30;
+                        b2_each(alive, [&](int v) { const int dg = b2_count(adj[v]); if (dg <= d && dg < pick_deg) { pick_deg = dg; pick_v = v; } });
+                        if (pick_v < 0) {
+                            while (!alive.test(sweep[next])) ++next;
+                            pick_v = sweep[next];
+                        }
+                        o.push_back((uint8_t)pick_v);
+                        alive.clr(pick_v);
+                        const B2 nb = adj[pick_v];
+                        b2_each(nb, [&](int y) { adj[y].a |= nb.a; adj[y].b |= nb.b; adj[y].clr(y); adj[y].clr(pick_v); });
+                    }
+                }
                 else {
                     const int w = c - 8 + 3;
                     B2 rest = hidden;
