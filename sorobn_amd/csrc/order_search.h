@@ -70,6 +70,10 @@ struct OrderNet {
 // elimination creates
 constexpr int kOrderSlotWords = 4, kOrderSlots = 64 * kOrderSlotWords;
 constexpr int kOrderOpening = 3;  // effort 1: variables of the factors min-fill's opening may create
+// The byte model overrates the opening + meet candidate: where it ranks first with a plain meet sweep within a fifth behind, the EMITTED program of the sweep
+// moves fewer bytes four times in five (/tmp-style experiment in profiles/NOTES_r06.md, session BT).  Its modelled cost counts 9/8 (exact in doubles, the same
+// number on the host and on the device): the first choice alone then emits 2.9 % fewer bytes on C3, 1.6 % with eight evidence nodes.
+constexpr double kOrderOpeningPenalty = 1.125;
 
 struct OrderScratch {
     // the request: relevant variables, and per relevant variable v the scope of its CPT without the evidence axes (f[v]) and
@@ -386,8 +390,8 @@ MIBN_HD inline double order_search(const OrderNet &net, OrderScratch &S, int nq,
             if (a[i] != b[i]) return false;
         return true;
     };
-    auto consider = [&]() {  // evaluates S.cand
-        const double c = order_simulate(net, S, S.cand, S.n_cand, two ? second_cost : best_cost);
+    auto consider = [&](double penalty = 1.0) {  // evaluates S.cand
+        const double c = penalty * order_simulate(net, S, S.cand, S.n_cand, two ? second_cost : best_cost);
         if (c < best_cost) {
             if (two && S.n_best > 0) {
                 second_cost = best_cost;
@@ -441,7 +445,7 @@ MIBN_HD inline double order_search(const OrderNet &net, OrderScratch &S, int nq,
                 B2 rest = hidden;
                 for (int i = 0; i < np; ++i) { S.cand[i] = S.greedy[i]; rest.clr(S.greedy[i]); }
                 order_sweep(net, S, rest, qdepth, 0, np);
-                consider();
+                consider(kOrderOpeningPenalty);
             }
         }
     }

@@ -427,7 +427,7 @@ struct WOrderCtx {
         if (best_cost > N.minfill_above * N.chain_weight) {
             const bool whole = greedy(nc, two ? second_cost : best_cost);
             WV_TICK(2)  // min-fill
-            int n_new = whole ? 1 : 0;
+            int n_new = whole ? 1 : 0, opening_slot = -1;
             if (two) {
                 // min-fill's opening (its leading eliminations that create factors of at most kOrderOpening variables), then the
                 // meet sweep of the rest - built before the simulations take the greedy state's memory
@@ -445,6 +445,7 @@ struct WOrderCtx {
                     n = filtered(W.o.cand[slot], n, N.topo_desc, qdepth, kNoDepth);
                     WV_LANE0 W.o.n_cand[slot] = n;
                     hidden = all_hidden;
+                    opening_slot = slot;
                     ++n_new;
                     wv::sync();
                 }
@@ -453,6 +454,10 @@ struct WOrderCtx {
                 simulate_batch(nc, nc + n_new);
                 WV_TICK(3)  // their byte model
                 if (overflow) return -1;
+                if (opening_slot >= 0) {  // (order_search.h: the model overrates this candidate)
+                    WV_LANE0 W.o.cost[opening_slot] *= kOrderOpeningPenalty;
+                    wv::sync();
+                }
                 rank(nc, nc + n_new);
             }
         }
