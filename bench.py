@@ -56,13 +56,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def pmc_ratio(kernel):
     import glob
     best = None
-    # (the newest session: by round, a round's closing session - "..._final_..." - last)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), key=lambda p: (os.path.basename(p)[:3], "_final_" in p, os.path.basename(p))):
+    # (the newest session: by round, a round's closing sessions - "..._final_...", then "..._close<n>_..." - last)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")),
+                    key=lambda p: (os.path.basename(p)[:3], 2 if "_close" in os.path.basename(p) else int("_final_" in p), os.path.basename(p))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         k = d.get("per_kernel", {}).get(kernel)
+        if k is None:  # (the engine's kernel names are 47 characters at most: the level group's name arrives cut)
+            k = next((v for name, v in d.get("per_kernel", {}).items() if len(kernel) >= 40 and name.startswith(kernel)), None)
         if k is None and kernel.startswith("level:"):  # (sessions before round 6 named the level's concurrent launches after two of its kernels)
             k = d.get("per_kernel", {}).get("ve_level_kernel||ve_sweep_dma_kernel")
         if k and k.get("alg_bytes_per_launch_same_run"):
