@@ -292,6 +292,9 @@ struct mibn_ctx {
     char *d_emit_scratch = nullptr;  // planning state, one slice per lane
     size_t emit_scratch_cap = 0;
     uint32_t *d_emit_cursor = nullptr;
+    uint32_t *d_plan_perm = nullptr;  // the order in which wave_plan_kernel's waves draw the requests of a chunk (plan_sort_kernel: the long ones first)
+    size_t plan_perm_cap = 0;
+    int wave_sort = 1;                // option: 0 = by index
     Staging emit_in, emit_out;       // pinned, read / written by the kernels themselves: request arrays in, per-request results and work items out
     hipEvent_t emit_ev[2] = {nullptr, nullptr};  // around the planner's kernels
     double emit_share = 0.75;        // the device's share of a chunk, the host's workers plan the rest meanwhile: follows the two measured
@@ -527,6 +530,7 @@ void mibn_destroy(mibn_t *h) {
         delete h->wnet_host;
         (void)hipFree(h->d_emit_scratch);
         (void)hipFree(h->d_emit_cursor);
+        if (h->d_plan_perm) (void)hipFree(h->d_plan_perm);
         if (h->emit_in.p) (void)hipHostFree(h->emit_in.p);
         if (h->emit_out.p) (void)hipHostFree(h->emit_out.p);
         if (h->search_in.p) (void)hipHostFree(h->search_in.p);
@@ -592,6 +596,7 @@ int mibn_set_option(mibn_t *h, const char *name, double value) {
     else if (n == "wave_plan") h->wave_plan = value != 0;  // 0: the device plans with order_kernel + emit_kernel (one request per lane)
     else if (n == "plan_waves") h->plan_waves = std::max(1, std::min(16, (int)value));  // waves per workgroup of the device planner's kernels
     else if (n == "plan_sort") h->plan_sort = (int)value;
+    else if (n == "wave_sort") h->wave_sort = value != 0;  // wave_plan_kernel hands out the requests with the most relevant variables first (default 1)
     else if (n == "plan_lanes") h->plan_lanes = std::max(0, std::min(64, (int)value));  // requests per wave of the device planner's kernels
     else if (n == "emit_share") { h->emit_share_opt = value > 0 ? std::min(1.0, value) : -1; if (value > 0) h->emit_share = h->emit_share_opt; }  // the device's share of a chunk (<= 0: follows the measured rates)
     else if (n == "emit_words") h->emit_words = (uint32_t)std::max(1024, std::min(1 << 20, (int)value));  // words of a request's device program slot
@@ -1110,7 +1115,13 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         A.tags = tags_out;
         A.tag_cursor = h->d_emit_cursor;
         A.tag_cap = (uint32_t)tag_cap;
+        A.perm = nullptr;
+        if (h->wave_sort && n > 4 * kWaveWG * (int64_t)h->n_cu) {  // (fewer requests than waves in flight: nothing to order)
+            if ((rc = ensure(h, h->d_plan_perm, h->plan_perm_cap, (size_t)n))) return rc;
+            A.perm = h->d_plan_perm;
+        }
         hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, P, h->d_emit_cursor);
+        if (A.perm) hipLaunchKernelGGL(plan_sort_kernel, dim3(1), dim3(kPlanSortThreads), 0, P, A);
         {
             // (the waves draw requests from a counter: the grid is what the chip holds at once - MIBN_WAVE_MIN_WGS workgroups per CU)
             int64_t grid = std::min<int64_t>((n + kWaveWG - 1) / kWaveWG, (int64_t)h->n_cu * MIBN_WAVE_MIN_WGS);

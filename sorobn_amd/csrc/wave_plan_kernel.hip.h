@@ -38,6 +38,7 @@ struct WavePlanArgs {
     Tag *tags;                               // [tag_cap]
     uint32_t *tag_cursor;                    // [0] work items handed out, [1] requests handed out (both zeroed by reset_cursor_kernel)
     uint32_t tag_cap;
+    uint32_t *perm;                          // [B] the order in which the requests are handed out (plan_sort_kernel), or null: by index
 };
 constexpr int kWaveWG = 4;  // waves (requests) per workgroup
 constexpr int kWaveMaxQ = 8, kWaveMaxE = 32;  // query / evidence variables of a request (more: the host plans the chunk)
@@ -48,6 +49,34 @@ __device__ unsigned long long g_wave_prof[24];  // ticks per phase, summed over 
 #endif
 
 __global__ void reset_cursor_kernel(uint32_t *cursor) { cursor[0] = 0; cursor[1] = 0; }
+
+// The long requests first: the waves draw requests from a counter, and a chunk that ends with its longest requests ends with a tail of a few busy
+// waves (handed out in descending order of their relevant-variable count - query, evidence and ancestors: what the planning time follows - a chunk of
+// 32 768 C3 requests takes 8.4 instead of 9.3 ms, profiles/NOTES_r06.md session BQ).  One workgroup: a counting sort over the 129 possible counts.
+constexpr int kPlanSortThreads = 1024;
+__global__ __launch_bounds__(kPlanSortThreads) void plan_sort_kernel(const WavePlanArgs A) {
+    __shared__ uint32_t hist[kWVars + 2];
+    for (int i = threadIdx.x; i < kWVars + 2; i += kPlanSortThreads) hist[i] = 0;
+    __syncthreads();
+    auto key_of = [&](int64_t b) -> int {
+        if (A.skip[b]) return 0;
+        const int64_t q0 = A.q_off[b], e0 = A.e_off[b];
+        const int nq = (int)(A.q_off[b + 1] - q0), ne = (int)(A.e_off[b + 1] - e0);
+        if (nq > kWaveMaxQ || ne > kWaveMaxE) return 0;
+        B2 rel;
+        for (int i = 0; i < nq; ++i) { const int v = A.q_vars[q0 + i]; rel.set(v); rel.a |= A.anc[v].a; rel.b |= A.anc[v].b; }
+        for (int i = 0; i < ne; ++i) { const int v = A.e_vars[e0 + i]; rel.set(v); rel.a |= A.anc[v].a; rel.b |= A.anc[v].b; }
+        return __builtin_popcountll(rel.a) + __builtin_popcountll(rel.b);
+    };
+    for (int64_t b = threadIdx.x; b < A.B; b += kPlanSortThreads) atomicAdd(&hist[kWVars - key_of(b)], 1u);  // (bin 0: the longest)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t at = 0;
+        for (int i = 0; i <= kWVars; ++i) { const uint32_t c = hist[i]; hist[i] = at; at += c; }
+    }
+    __syncthreads();
+    for (int64_t b = threadIdx.x; b < A.B; b += kPlanSortThreads) A.perm[atomicAdd(&hist[kWVars - key_of(b)], 1u)] = (uint32_t)b;
+}
 
 #ifndef MIBN_WAVE_MIN_WGS
 #define MIBN_WAVE_MIN_WGS 4  // workgroups per CU the register budget allows (4: 128 VGPRs - some 300 spilled, still the fastest: 11.0 ms per chunk against 13.8 at 3, profiles/r06_v_occupancy.log; LDS: 39.8 KB per workgroup)
@@ -72,8 +101,9 @@ __global__ __launch_bounds__(64 * kWaveWG, MIBN_WAVE_MIN_WGS) void wave_plan_ker
     //  divergent and the lanes of a wave run different requests.  Measured: profiles/NOTES_r06.md, session AX.)
     for (;;) {
         const uint32_t next = atomicAdd(A.tag_cursor + 1, lane == 0 ? 1u : 0u);
-        const int64_t b = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-        if (b >= A.B) break;
+        const int64_t at = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        if (at >= A.B) break;
+        const int64_t b = A.perm ? (int64_t)A.perm[at] : at;
         EmitMeta m;
         m.words = 1; m.n_tags = 0; m.tag_first = 0; m.err = 0; m.prog_first = 0; m.pad_ = 0;
         m.alg_bytes = m.alg_flops = m.n_steps = m.max_step_cells = 0;

@@ -81,6 +81,7 @@ int main(int argc, char **argv) {
         for (int eff = 0; eff < 2; ++eff) {
             net.order_effort = eff;
             if (std::getenv("SECOND_ABOVE")) net.second_above = atof(std::getenv("SECOND_ABOVE"));
+            if (std::getenv("ORDER_WEIGHTS")) net.order_weights = atoi(std::getenv("ORDER_WEIGHTS"));  // (k > 1: a single-table elimination counts 1 / k of its bytes in the model)
             std::vector<uint32_t> prog;
             timespec t0, t1;
             clock_gettime(CLOCK_MONOTONIC, &t0);

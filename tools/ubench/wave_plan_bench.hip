@@ -112,6 +112,9 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&d_tags, tag_cap * sizeof(Tag)));
     WavePlanArgs A;
     A.net = d_net; A.anc = d_anc; A.q_off = d_qo; A.e_off = d_eo; A.out_off = d_oo; A.q_vars = d_qv; A.e_vars = d_ev; A.e_codes = d_ec; A.skip = d_skip;
+    uint32_t *d_perm = nullptr;
+    if (std::getenv("PERM")) CHECK(hipMalloc(&d_perm, B * 4));  // the device's own sort (plan_sort_kernel): the long requests first
+    A.perm = d_perm;
     A.B = B; A.flags = 0; A.prog = d_prog; A.prog_stride = stride; A.meta = d_meta; A.tags = d_tags; A.tag_cursor = d_cursor; A.tag_cap = (uint32_t)tag_cap;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const unsigned grid = (unsigned)std::min<int64_t>((B + kWaveWG - 1) / kWaveWG, std::getenv("WAVE_WGS") ? atoll(std::getenv("WAVE_WGS")) : 256 * MIBN_WAVE_MIN_WGS);  // (the waves draw requests from a counter: what the chip holds at once)
@@ -119,6 +122,7 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 4; ++rep) {
         hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, 0, d_cursor);
         CHECK(hipEventRecord(e0, 0));
+        if (d_perm) hipLaunchKernelGGL(plan_sort_kernel, dim3(1), dim3(kPlanSortThreads), 0, 0, A);
         hipLaunchKernelGGL(wave_plan_kernel, dim3(grid), dim3(64 * kWaveWG), 0, 0, A);
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
