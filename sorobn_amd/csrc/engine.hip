@@ -1117,7 +1117,7 @@ int plan_on_device_launch(mibn_ctx *h, uint32_t flags, int64_t b0, int64_t b1, c
         A.tag_cap = (uint32_t)tag_cap;
         A.perm = nullptr;
         if (h->wave_sort && n > 4 * kWaveWG * (int64_t)h->n_cu) {  // (fewer requests than waves in flight: nothing to order)
-            if ((rc = ensure(h, h->d_plan_perm, h->plan_perm_cap, (size_t)n))) return rc;
+            if ((rc = ensure(h, h->d_plan_perm, h->plan_perm_cap, 2 * (size_t)n))) return rc;
             A.perm = h->d_plan_perm;
         }
         hipLaunchKernelGGL(reset_cursor_kernel, dim3(1), dim3(1), 0, P, h->d_emit_cursor);

@@ -38,7 +38,7 @@ struct WavePlanArgs {
     Tag *tags;                               // [tag_cap]
     uint32_t *tag_cursor;                    // [0] work items handed out, [1] requests handed out (both zeroed by reset_cursor_kernel)
     uint32_t tag_cap;
-    uint32_t *perm;                          // [B] the order in which the requests are handed out (plan_sort_kernel), or null: by index
+    uint32_t *perm;                          // [2 B] the order in which the requests are handed out (plan_sort_kernel; behind it the sort's bins), or null: by index
 };
 constexpr int kWaveWG = 4;  // waves (requests) per workgroup
 constexpr int kWaveMaxQ = 8, kWaveMaxE = 32;  // query / evidence variables of a request (more: the host plans the chunk)
@@ -68,14 +68,19 @@ __global__ __launch_bounds__(kPlanSortThreads) void plan_sort_kernel(const WaveP
         for (int i = 0; i < ne; ++i) { const int v = A.e_vars[e0 + i]; rel.set(v); rel.a |= A.anc[v].a; rel.b |= A.anc[v].b; }
         return __builtin_popcountll(rel.a) + __builtin_popcountll(rel.b);
     };
-    for (int64_t b = threadIdx.x; b < A.B; b += kPlanSortThreads) atomicAdd(&hist[kWVars - key_of(b)], 1u);  // (bin 0: the longest)
+    uint32_t *bin = A.perm + A.B;  // (the buffer holds 2 B words: the request arrays are in pinned host memory, read once)
+    for (int64_t b = threadIdx.x; b < A.B; b += kPlanSortThreads) {
+        const uint32_t k = (uint32_t)(kWVars - key_of(b));  // (bin 0: the longest)
+        bin[b] = k;
+        atomicAdd(&hist[k], 1u);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t at = 0;
         for (int i = 0; i <= kWVars; ++i) { const uint32_t c = hist[i]; hist[i] = at; at += c; }
     }
     __syncthreads();
-    for (int64_t b = threadIdx.x; b < A.B; b += kPlanSortThreads) A.perm[atomicAdd(&hist[kWVars - key_of(b)], 1u)] = (uint32_t)b;
+    for (int64_t b = threadIdx.x; b < A.B; b += kPlanSortThreads) A.perm[atomicAdd(&hist[bin[b]], 1u)] = (uint32_t)b;
 }
 
 #ifndef MIBN_WAVE_MIN_WGS

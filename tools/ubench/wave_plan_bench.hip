@@ -113,7 +113,7 @@ int main(int argc, char **argv) {
     WavePlanArgs A;
     A.net = d_net; A.anc = d_anc; A.q_off = d_qo; A.e_off = d_eo; A.out_off = d_oo; A.q_vars = d_qv; A.e_vars = d_ev; A.e_codes = d_ec; A.skip = d_skip;
     uint32_t *d_perm = nullptr;
-    if (std::getenv("PERM")) CHECK(hipMalloc(&d_perm, B * 4));  // the device's own sort (plan_sort_kernel): the long requests first
+    if (std::getenv("PERM")) CHECK(hipMalloc(&d_perm, 2 * B * 4));  // the device's own sort (plan_sort_kernel): the long requests first
     A.perm = d_perm;
     A.B = B; A.flags = 0; A.prog = d_prog; A.prog_stride = stride; A.meta = d_meta; A.tags = d_tags; A.tag_cursor = d_cursor; A.tag_cap = (uint32_t)tag_cap;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
