@@ -20,7 +20,8 @@ int main(int argc, char **argv) {
     const int64_t B = argc > 1 ? atoll(argv[1]) : 300;
     const int NE = argc > 2 ? atoi(argv[2]) : 4;
     const int TRIES = argc > 3 ? atoi(argv[3]) : 300;
-    const int R = 10, C = 10, K = 4, n = R * C;
+    // (ROWS / COLS / CARD: other grids than C3's 10 x 10 four-state one - does what was tuned there hold elsewhere?)
+    const int R = std::getenv("ROWS") ? atoi(std::getenv("ROWS")) : 10, C = std::getenv("COLS") ? atoi(std::getenv("COLS")) : 10, K = std::getenv("CARD") ? atoi(std::getenv("CARD")) : 4, n = R * C;
     std::vector<int32_t> card(n, K), scope_vars;
     std::vector<int64_t> scope_off{0}, value_off{0};
     std::vector<double> values;
