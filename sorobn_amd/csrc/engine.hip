@@ -462,10 +462,16 @@ int mibn_device_count(int *count) {
     return MIBN_OK;
 }
 
+// Factors of at most this many cells are "small" (segments, the small inputs of the passes, the byte model's big / small line).  1 024 from round 2 to the
+// last day of round 6; with order_effort 1's plans 512 runs 1.3 % less GPU time per step (808.6 - 810.1 against 819.0 - 820.4 ms, interleaved; 256: 810.5; 2 048: 824.7 -
+// profiles/r06_ca_ab.log, r06_cb_ab.log).  A bare Network (tools, oracle, the pinned fingerprints) keeps 1 024.
+constexpr int kEngineSmallCells = 512;
+
 int mibn_create_planner(mibn_t **out) {
     if (!out) return MIBN_E_ARG;
     auto *h = new mibn_ctx();
     h->net.order_effort = 1; h->net.second_above = h->base_second_above;  // (the engine's default; a bare Network - the tools, the oracle - keeps round 5's search)
+    h->net.small_cells = kEngineSmallCells;
     h->planner_only = true;
     *out = h;
     return MIBN_OK;
@@ -479,6 +485,7 @@ int mibn_create(int device, mibn_t **out) {
     if (device < 0 || device >= n) return MIBN_E_ARG;
     auto *h = new mibn_ctx();
     h->net.order_effort = 1; h->net.second_above = h->base_second_above;
+    h->net.small_cells = kEngineSmallCells;
     h->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete h; return MIBN_E_NODEVICE; }
     hipDeviceProp_t prop;
