@@ -253,7 +253,7 @@ struct mibn_ctx {
     bool auto_emit = false;    // gpu_emit was
     int host_bound_streak = 0;
     bool adaptive_seeded = false;
-    double base_minfill = 2e7, seen_plan_ms = 0, seen_kernel_ms = 0;
+    double base_minfill = 5e6, seen_plan_ms = 0, seen_kernel_ms = 0;  // (minfill_above: 2e7 up to round 6's last day; with order_effort 1 min-fill also supplies the opening candidate - 5e6: 1.7 % less GPU time per step for a tenth more planning, profiles/r06_cd_ab.log)
     double base_second_above = 2e7;  // option second_above (the calls the device plans run without the second emission: run_batch)
     int second_on_device = 0;        // option: 1 = device-planned calls emit the runner-up too (tests: the wave planner's second emission)
     double retired_requests = 0, seen_requests = 0;  // requests whose kernel time has been booked (the unit of kernel_ms in the policy's windows)
@@ -472,6 +472,7 @@ int mibn_create_planner(mibn_t **out) {
     auto *h = new mibn_ctx();
     h->net.order_effort = 1; h->net.second_above = h->base_second_above;  // (the engine's default; a bare Network - the tools, the oracle - keeps round 5's search)
     h->net.small_cells = kEngineSmallCells;
+    h->net.minfill_above = h->base_minfill;
     h->planner_only = true;
     *out = h;
     return MIBN_OK;
@@ -486,6 +487,7 @@ int mibn_create(int device, mibn_t **out) {
     auto *h = new mibn_ctx();
     h->net.order_effort = 1; h->net.second_above = h->base_second_above;
     h->net.small_cells = kEngineSmallCells;
+    h->net.minfill_above = h->base_minfill;
     h->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete h; return MIBN_E_NODEVICE; }
     hipDeviceProp_t prop;
@@ -1478,7 +1480,7 @@ int run_batch_body(mibn_t *h, uint32_t flags, int64_t B, const int64_t *q_off, c
                 h->gpu_emit = 0;
                 h->auto_emit = false;
                 h->host_bound_streak = 0;
-            } else if (dp > MIBN_HOST_BOUND_RATIO * dk && ++h->host_bound_streak >= (h->pool->size() <= 4 ? 2 : 1)) {  // (the long windows of a rank that is not starved need no second look)  // (twice in a row: the kernel time of a call is booked when its
+            } else if (dp > MIBN_HOST_BOUND_RATIO * dk && ++h->host_bound_streak >= 2) {  // (round 6: twice in a row for every rank - a full-quota rank used to switch on one window, and the window behind a step's barrier, with the first call's planning exposed, tripped it for a per mille of the requests: profiles/r06_ce_ab.log, r06_cf_ab.log)  // (twice in a row: the kernel time of a call is booked when its
                                                                           // launches retire, up to two calls late - one window can mislead)
                 // host-bound: first hand the order search to the device (same orders, no more bytes); networks it does
                 // not cover give up the min-fill search for ever more expensive requests instead
